@@ -1,0 +1,183 @@
+/*
+ * friendship_render.h -- C-ABI boundary of the MI355X-native render engine.
+ *
+ * This header is the drop-in boundary for libfriendship's render hot path.  Each entry point
+ * replaces one method of the reference's `render::Renderer` / `routing::GraphWatcher` traits
+ * (all citations relative to the reference checkout):
+ *
+ *   fr_renderer_create / _destroy   <- `Default::default()` / drop of a renderer
+ *                                      (src/render/reference.rs:20, src/dispatch.rs:99-106)
+ *   fr_on_add_node                  <- GraphWatcher::on_add_node (src/routing/graphwatcher.rs:5,
+ *                                      impl src/render/reference.rs:117-120, make_node :98-113)
+ *   fr_on_del_node                  <- GraphWatcher::on_del_node (graphwatcher.rs:6, reference.rs:121-123)
+ *   fr_on_add_edge                  <- GraphWatcher::on_add_edge (graphwatcher.rs:7, reference.rs:124-126,141-153)
+ *   fr_on_del_edge                  <- GraphWatcher::on_del_edge (graphwatcher.rs:8, reference.rs:127-136)
+ *   fr_fill_buffer                  <- Renderer::fill_buffer (src/render/renderer.rs:16,
+ *                                      impl src/render/reference.rs:47-85), called from
+ *                                      src/dispatch.rs:150 only
+ *
+ * Plain pointers and sizes only: no C++/torch/Rust types cross this line.  A Rust host binds these
+ * with an `extern "C"` block; the C++ host mirror in libfriendship_amd/host/
+ * and the Python test harness bind the same symbols.
+ *
+ * Two shared libraries export this exact symbol set:
+ *   libfriendship_amd/libfriendship_hip.so  -- the product: HIP/gfx950 engine.  No CPU fallback.
+ *   oracle/_build/libfr_oracle.so           -- TEST INFRASTRUCTURE ONLY: CPU restatement of RefRenderer.
+ *
+ * Threading: one host thread per handle; calls on one handle are serialised by the caller
+ * (the reference's Dispatch is !Send, src/routing/routegraph.rs:27).  fr_fill_buffer is synchronous:
+ * when it returns, `out` is complete (src/dispatch.rs:150-151 hands the buffer on immediately).
+ *
+ * Errors: the reference's trait methods return () and panic on contract violations
+ * (reference.rs:69,71,131,145,186,199...).  Here every call returns an fr_status; a conforming shim
+ * turns non-zero into panic!.  Nothing in this library aborts the process.
+ */
+#ifndef FRIENDSHIP_RENDER_H
+#define FRIENDSHIP_RENDER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FR_ABI_VERSION 1u
+
+/* ---- status codes ------------------------------------------------------------------------- */
+typedef int32_t fr_status;
+enum {
+    FR_OK = 0,
+    FR_ERR_INVALID_ARG = 1,        /* null pointer, bad enum value, malformed effect description   */
+    FR_ERR_INPUT_TOO_LONG = 2,     /* input row extends past idx+n_times (reference.rs:71 assert)  */
+    FR_ERR_INPUT_HISTORY = 3,      /* row for a slot whose stored length != idx (reference.rs:69)  */
+    FR_ERR_NO_SUCH_NODE = 4,       /* edge to/from a node the renderer was never told about
+                                      (reference.rs:131,145,186 unwrap/expect/index panics)        */
+    FR_ERR_BAD_SLOT = 5,           /* non-constant primitive read through from_slot != 0
+                                      (reference.rs:199,223,230,237,244,251 asserts)               */
+    FR_ERR_CYCLE = 6,              /* dependency cycle reachable from a rendered output with no
+                                      way to terminate (the reference would recurse forever)      */
+    FR_ERR_DEVICE = 7,             /* HIP runtime failure; see fr_last_error                       */
+    FR_ERR_NO_DEVICE = 8,          /* no gfx950 device / HIP code object unusable                  */
+    FR_ERR_OUT_OF_MEMORY = 9,
+    FR_ERR_UNSUPPORTED = 10,       /* well-formed request the engine cannot evaluate (documented)  */
+    FR_ERR_COMM = 11               /* multi-GPU exchange failed                                    */
+};
+
+/* ---- graph data --------------------------------------------------------------------------- */
+
+/* routing::Edge (src/routing/routegraph.rs:20-24,38-44): 16 bytes.  Node handle 0 is the null
+ * handle = the graph's own inputs (as `from`) / outputs (as `to`), per NullableInt
+ * (src/routing/nullable_int.rs:65-72). */
+typedef struct fr_edge {
+    uint32_t from;
+    uint32_t to;
+    uint32_t from_slot;
+    uint32_t to_slot;
+} fr_edge;
+
+/* routing::effect::PrimitiveEffect in declaration order (src/routing/effect.rs:86-112). */
+enum {
+    FR_PRIM_DELAY = 0,
+    FR_PRIM_F32CONSTANT = 1,
+    FR_PRIM_SUM2 = 2,
+    FR_PRIM_MULTIPLY = 3,
+    FR_PRIM_DIVIDE = 4,
+    FR_PRIM_MODULO = 5,
+    FR_PRIM_MINIMUM = 6,
+    FR_EFFECT_GRAPH = 7            /* EffectData::RouteGraph (effect.rs:79-82): a composite effect */
+};
+
+/* What on_add_node receives in place of `&Rc<Effect>`: the part of `Effect` the renderer reads
+ * (EffectData, effect.rs:79-82).  For kind < 7 the arrays are ignored.  For FR_EFFECT_GRAPH the
+ * arrays are the effect's RouteGraph in AdjList shape (src/routing/adjlist.rs:11-15): nodes as
+ * (handle, effect) pairs, edges as 16-byte fr_edge.  The renderer copies everything it needs
+ * before returning (RefRenderer deep-copies too, reference.rs:98-113); pointers are borrowed for
+ * the duration of the call only. */
+typedef struct fr_effect {
+    int32_t kind;
+    uint32_t n_nodes;
+    const uint32_t *node_handles;                /* [n_nodes], none may be 0                      */
+    const struct fr_effect *const *node_effects; /* [n_nodes]                                     */
+    uint32_t n_edges;
+    const fr_edge *edges;                        /* [n_edges]                                     */
+} fr_effect;
+
+/* ---- renderer ----------------------------------------------------------------------------- */
+typedef struct fr_renderer fr_renderer;
+
+/* Execution strategy.  AUTO picks fused kernels where the lowered graph matches a known
+ * structure and the materialised evaluator elsewhere; the other values force one strategy and exist
+ * for parity tests and A/B measurements. */
+enum {
+    FR_MODE_AUTO = 0,
+    FR_MODE_PULL = 1,              /* per-(slot,t) pull interpreter: the reference's recursion    */
+    FR_MODE_STAGED = 2             /* materialised stage pipeline, no fused oscillator banks      */
+};
+
+typedef struct fr_config {
+    uint32_t abi_version;          /* FR_ABI_VERSION                                              */
+    int32_t device;                /* HIP device ordinal; -1 = current device                     */
+    int32_t mode;                  /* FR_MODE_*                                                   */
+    uint32_t flags;                /* reserved, 0                                                 */
+} fr_config;
+
+/* cfg may be NULL (device -1, FR_MODE_AUTO). */
+fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out);
+void fr_renderer_destroy(fr_renderer *r);
+
+fr_status fr_on_add_node(fr_renderer *r, uint32_t handle, const fr_effect *effect);
+fr_status fr_on_del_node(fr_renderer *r, uint32_t handle);
+fr_status fr_on_add_edge(fr_renderer *r, const fr_edge *edge);
+fr_status fr_on_del_edge(fr_renderer *r, const fr_edge *edge);
+
+/* Batch forms of the two calls above (same semantics as calling them in array order; stop at the
+ * first failure).  Not part of the reference surface: they exist so a host can hand over a
+ * multi-million-node tree without one FFI crossing per element. */
+fr_status fr_on_add_nodes(fr_renderer *r, const uint32_t *handles,
+                          const fr_effect *const *effects, size_t n);
+fr_status fr_on_add_edges(fr_renderer *r, const fr_edge *edges, size_t n);
+
+/* Renderer::fill_buffer.  `out` is the row-major [n_slots, n_times] f32 buffer (Array2, allocated
+ * by the caller, src/dispatch.rs:149); every element is overwritten.  `idx` is the absolute sample
+ * index of column 0; idx != previous idx+n_times is a seek (renderer.rs:12-15).  Inputs are the
+ * Jagged2<f32> in CSR form: row r (feeds input slot r) = in_data[in_row_offsets[r] ..
+ * in_row_offsets[r+1]); in_row_offsets has n_in_rows+1 entries.  n_in_rows == 0 allows NULLs. */
+fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t n_times,
+                         uint64_t idx, const float *in_data, const uint64_t *in_row_offsets,
+                         uint32_t n_in_rows);
+
+/* Same contract with every buffer already resident in device memory (out, in_data device pointers;
+ * in_row_offsets stays a host pointer -- it is control data).  Work is enqueued on `stream`
+ * (a hipStream_t; NULL = the default stream) and NOT synchronised: the caller owns ordering.
+ * The CPU oracle library returns FR_ERR_UNSUPPORTED. */
+fr_status fr_fill_buffer_device(fr_renderer *r, float *d_out, uint32_t n_slots, uint64_t n_times,
+                                uint64_t idx, const float *d_in_data,
+                                const uint64_t *in_row_offsets, uint32_t n_in_rows, void *stream);
+
+/* ---- introspection (host diagnostics, tests, bench) ---------------------------------------- */
+
+/* Text of the most recent failure on this handle ("" if none).  Valid until the next call. */
+const char *fr_last_error(const fr_renderer *r);
+const char *fr_status_string(fr_status s);
+
+/* "hip-gfx950" for the product library, "cpu-oracle" for the test oracle. */
+const char *fr_backend_name(void);
+uint32_t fr_abi_version(void);
+
+/* Description of the execution plan built by the last fill_buffer, as a JSON object in a
+ * NUL-terminated string owned by the handle (valid until the next call on it): stages, kernels,
+ * fused bank shapes, algorithmic bytes.  The oracle returns "{}". */
+const char *fr_plan_json(fr_renderer *r);
+
+/* Kernel time (milliseconds, HIP events on the engine's stream) accumulated by fill_buffer calls
+ * since the last reset, for the kernel class named (`"bank"`, `"stage"`, `"pull"`, `"all"`);
+ * *launches receives the launch count.  Enabled by fr_set_timing(r, 1); off by default. */
+fr_status fr_set_timing(fr_renderer *r, int32_t enabled);
+fr_status fr_get_timing(fr_renderer *r, const char *kernel_class, double *ms, uint64_t *launches);
+fr_status fr_reset_timing(fr_renderer *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRIENDSHIP_RENDER_H */
