@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the render hot path on MI355X.
+
+Metric (BASELINE.json): Msamples/sec at 4096 partials x 64 voices (one sample = one output frame of
+the whole tree, all 64 voice rows), 48 kHz synthetic tree, plus achieved rates against the roofline.
+
+A "step" is one `fill_buffer` call of T = 4800 frames (0.1 s of audio) over the full tree, through the
+C ABI's device-resident entry point: the time-ramp input and the output buffer are already in HBM when
+the timed region starts (PCIe-inclusive figures are in DESIGN.md, never in `value`).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the job is striped over time -- rank r
+renders its own contiguous stripe of frames of the same tree.  The evaluator is a pure function of
+(graph, input history, t) (reference src/render/reference.rs:178-266), so stripes are independent: no
+data-path collective, weak scaling, value = frames rendered by all ranks / max-over-ranks time.
+
+Prints ONE JSON line on stdout (rank 0); diagnostics go to stderr.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# MI355X ceilings (/opt/skills/guides/MI355X_MICROARCH.md: chip-level parameters, cycle constants)
+HBM_PEAK_GBS = 8000.0                       # spec; 6290 measured copy
+VALU_LANE_RATE = 256 * 4 * 32 * 2.4e9       # f32 VALU lane-ops/s: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12
+FMA_PEAK_TFLOPS = 157.3                     # the same rate counted as FMA (2 flops); unusable here, see DESIGN.md
+OPS_EXECUTED_PER_PF = 7                     # VALU ops the fused kernel issues per partial-frame (6 leaf + 1 tree add)
+OPS_GRAPH_PER_PF = 12                       # primitive nodes the reference evaluates per partial-frame (11 + Sum2)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(tree, V, P, frames_1t, frames_mt):
+    """The CPU path, timed on this box's host cores: the C++ restatement of RefRenderer (oracle/, kind
+    'port' -- the Rust reference cannot be built here).  Bounded sample of the same workload."""
+    from libfriendship_amd import synth
+    from libfriendship_amd.capi import Renderer, RendererLib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_tools
+    lib = RendererLib(os.path.join(ROOT, "oracle", "_build", "libfr_oracle.so"))
+    ncpu = os.cpu_count() or 1
+    with Renderer(lib) as r:
+        synth.install(r, tree)
+        t = synth.time_ramp(0, frames_1t)
+        t0 = time.perf_counter()
+        out1 = r.fill_buffer(V, 0, frames_1t, [t])
+        dt1 = time.perf_counter() - t0
+        nthreads = min(ncpu, V)
+        oracle_tools.set_threads(r, nthreads)
+        t = synth.time_ramp(frames_1t, frames_1t + frames_mt)
+        t0 = time.perf_counter()
+        r.fill_buffer(V, frames_1t, frames_1t + frames_mt, [t])
+        dtm = time.perf_counter() - t0
+    one = {"value": frames_1t / dt1 / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+           "sample": f"{frames_1t} frames of the same {P}x{V} tree, single thread (the reference renderer is "
+                     f"single-threaded); C++ restatement of RefRenderer, not the Rust binary",
+           "seconds": dt1}
+    many = {"value": frames_mt / dtm / 1e6, "unit": "Msamples/s", "cores": nthreads, "kind": "port",
+            "sample": f"{frames_mt} frames, output slots spread over {nthreads} threads", "seconds": dtm,
+            "host_cpus": ncpu}
+    return one, many, out1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--voices", type=int, default=64)
+    ap.add_argument("--partials", type=int, default=4096)
+    ap.add_argument("--frames", type=int, default=4800, help="frames per fill_buffer call (T)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "pull"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=48)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import libfriendship_amd
+    from libfriendship_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    V, P, T, K, W = args.voices, args.partials, args.frames, args.steps, args.warmup
+    t_build = time.perf_counter()
+    tree = synth.additive_tree(V, P)          # seeded synthetic tree, ~12 primitive nodes per partial
+    hip = libfriendship_amd.HipRenderer(mode=args.mode, device=local_rank)
+    synth.install(hip, tree)
+    log(f"[rank {rank}] graph: {len(tree['handles'])} nodes, {len(tree['edges'])} edges, "
+        f"installed in {time.perf_counter() - t_build:.1f}s")
+
+    # this rank's stripe of frames; every step's time-ramp row is already resident in HBM
+    n_calls = W + K
+    stripe0 = rank * n_calls * T
+    assert stripe0 + n_calls * T < (1 << 24), "f32 frame ramp is exact only below 2^24 frames"
+    d_time = torch.from_numpy(synth.time_ramp(stripe0, stripe0 + n_calls * T)).cuda()
+    d_out = torch.empty((V, T), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(k):
+        row = d_time[k * T:(k + 1) * T]
+        hip.fill_buffer_device(d_out.data_ptr(), V, T, stripe0 + k * T, row.data_ptr(), [0, T], stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    t0 = time.perf_counter()
+    for k in range(W):           # first call also lowers the graph and uploads the bank parameters
+        step(k)
+    torch.cuda.synchronize()
+    log(f"[rank {rank}] warmup ({W} steps incl. lowering): {time.perf_counter() - t0:.2f}s; plan: {hip.plan()}")
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        step(k)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    last = d_out.cpu().numpy()
+
+    # kernel-level timing for the roofline: same steps again with HIP events around every launch, recorded
+    # on the stream the kernels run on (engine-side, fr_set_timing); a seek back to the stripe start.
+    hip.set_timing(True)
+    hip.reset_timing()
+    for k in range(W, W + K):   # the first of these is a seek back to the stripe's first timed frame
+        step(k)
+    torch.cuda.synchronize()
+    bank_ms, bank_launches = hip.get_timing("bank")
+    all_ms, all_launches = hip.get_timing("all")
+    plan = hip.plan()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    frames_total = world * K * T
+    value = frames_total / elapsed / 1e6
+    pf_per_launch = float(V) * P * T
+    dom_ms, dom_n, dom_name = (bank_ms, bank_launches, "bank_kernel") if bank_launches else (all_ms, all_launches, "pull_kernel")
+    avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
+    # algorithmic HBM bytes per launch, closed-form model of SURVEY.md 8d: parameters read once + ramp in + samples out
+    bytes_per_launch = V * P * 8 + 4 * T + 4 * V * T
+    valu_rate = OPS_EXECUTED_PER_PF * pf_per_launch / avg_s if avg_s > 0 else 0.0
+    roofline = {
+        "bound": "valu",
+        "kernel": dom_name,
+        "achieved": valu_rate / 1e12,
+        "peak": VALU_LANE_RATE / 1e12,
+        "unit": "TFLOP/s",
+        "frac": valu_rate / VALU_LANE_RATE,
+        "traffic": None,
+        "avg_launch_ms": avg_s * 1e3,
+        "launches_timed": int(dom_n),
+        "flops_per_partial_frame": {"executed_by_kernel": OPS_EXECUTED_PER_PF, "primitive_nodes_in_graph": OPS_GRAPH_PER_PF},
+        "note": "f32 VALU issue bound: 256 CU x 4 SIMD-32 x 2.4 GHz lane-ops/s; parity forbids FMA contraction so "
+                "1 flop per lane-op (the 157.3 TFLOP/s FMA peak is unreachable by construction). MFMA not applicable.",
+        "hbm": {"achieved": bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (bytes_per_launch / avg_s / 1e9) / HBM_PEAK_GBS if avg_s > 0 else 0.0,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "note": "block rendering keeps partial state in registers/SGPRs for 4800 frames: HBM is not the bound"},
+    }
+
+    result = {
+        "metric": "Msamples/sec at 4096 partials x 64 voices; achieved HBM GB/s vs roofline",
+        "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"additive tree, {P} partials x {V} voices, 48 kHz, {T}-frame fill_buffer calls "
+                               f"(BASELINE.json configs[2])", "voices": V, "partials": P, "frames_per_call": T,
+                   "sharding": "time stripes, one per GPU, no collective" if world > 1 else "single GPU",
+                   "engine_mode": args.mode, "plan": plan},
+        "partial_frames_per_s": frames_total * float(V) * P / elapsed,
+        "roofline": roofline,
+    }
+
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            one, many, cpu_out = cpu_baseline(tree, V, P, args.cpu_frames, 4 * args.cpu_frames)
+            result["cpu_baseline"] = one
+            result["cpu_baseline_all_cores"] = many
+            # parity of the bench's own output against the CPU path on the sampled frames (stripe 0 only)
+            chk = libfriendship_amd.HipRenderer(mode=args.mode, device=local_rank)
+            synth.install(chk, tree)
+            got = chk.fill_buffer(V, 0, args.cpu_frames, [synth.time_ramp(0, args.cpu_frames)])
+            result["parity"] = {"frames_checked": args.cpu_frames, "voices": V,
+                                "bit_exact": bool(np.array_equal(got.view(np.uint32), cpu_out.view(np.uint32)))}
+            chk.close()
+        except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
+            result["cpu_baseline"] = {"error": repr(e)}
+    result["checksum"] = float(np.abs(last.astype(np.float64)).sum())
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,560 @@
+// engine.cpp -- the HIP render engine behind include/friendship_render.h.
+//
+// State contract (reference src/render/reference.rs:21-29): mirrored graph + per-slot input history +
+// `head`.  Everything else held here (lowered graph, device tables, bank parameters) is a cache of
+// that state, rebuilt when the mirror's version or the number of rendered slots changes.
+//
+// There is no CPU evaluation path in this file: if no gfx950 device is usable, creating a renderer
+// fails with FR_ERR_NO_DEVICE.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "graph.hpp"
+#include "kernels.hpp"
+#include "match.hpp"
+
+namespace fr {
+
+#define HIP_CHECK(expr)                                                                               \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            throw Error(_e == hipErrorOutOfMemory ? FR_ERR_OUT_OF_MEMORY : FR_ERR_DEVICE,             \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                           \
+    } while (0)
+
+// Device allocation owned by the engine.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    void ensure(size_t n) {   // contents are NOT preserved
+        if (n <= bytes) return;
+        release();
+        size_t want = std::max(n, (size_t)256);
+        HIP_CHECK(hipMalloc(&p, want));
+        bytes = want;
+    }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// One external input slot's history on the device (reference.rs:25 `inputs[slot]`).
+struct InSlot {
+    bool fed = false;        // ever received a row (otherwise implicit zeros)
+    uint64_t base = 0;       // zero prefix (seek / late creation), data[i] is time base+i
+    uint64_t len = 0;        // logical length (== base + stored samples)
+    DevBuf buf;
+    uint64_t cap = 0;        // capacity in floats
+};
+
+struct BankStage {
+    BankGroup grp;           // rows/params kept on the host for the plan description
+    DevBuf d_params, d_rows;
+};
+
+struct Plan {
+    bool valid = false;
+    uint64_t version = 0;
+    uint32_t n_slots = 0;
+    FlatGraph fg;
+    std::vector<BankStage> banks;
+    std::vector<uint32_t> pull_rows;     // output rows evaluated by the pull interpreter
+    DevBuf d_nodes, d_roots;             // pull: nodes (input slots remapped dense), roots per pull row
+    std::vector<uint32_t> input_slots;   // dense input index -> external slot
+    std::string json;
+};
+
+struct TimerClass {
+    double ms = 0;
+    uint64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace fr
+
+using namespace fr;
+
+struct fr_renderer {
+    int device = 0;
+    int mode = FR_MODE_AUTO;
+    hipStream_t stream = nullptr;
+    Mirror mirror;
+    // input history bookkeeping, same rules as reference.rs:47-75 (see oracle/ref_renderer.cpp)
+    std::vector<InSlot> slots;
+    uint64_t n_vecs = 0;
+    struct Seg { uint64_t first, last, len; };
+    std::vector<Seg> segs;
+    uint64_t head = 0;
+    Plan plan;
+    DevBuf d_out, d_in_table, d_stack_node, d_stack_time, d_stack_val, d_bank_ws;
+    std::vector<float> h_stage;
+    bool timing = false;
+    TimerClass t_bank, t_pull;
+    std::vector<hipEvent_t> event_pool;
+    std::string last_error;
+    std::string plan_json_cache;
+
+    ~fr_renderer() {
+        (void)hipSetDevice(device);
+        for (TimerClass *tc : {&t_bank, &t_pull})
+            for (auto &pr : tc->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    uint64_t implicit_len(uint64_t slot) const {
+        for (const Seg &s : segs) if (slot >= s.first && slot < s.last) return s.len;
+        return 0;
+    }
+
+    // ---- timing ------------------------------------------------------------------------------
+    hipEvent_t get_event() {
+        if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        return e;
+    }
+    struct Scope {
+        fr_renderer *r; TimerClass *tc; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+        Scope(fr_renderer *rr, TimerClass *t, hipStream_t st) : r(rr), tc(t), s(st) {
+            if (r->timing) { a = r->get_event(); b = r->get_event(); HIP_CHECK(hipEventRecord(a, s)); }
+        }
+        void done() {
+            if (a) { HIP_CHECK(hipEventRecord(b, s)); tc->pending.emplace_back(a, b); a = nullptr; }
+        }
+    };
+    void resolve(TimerClass &tc) {
+        for (auto &pr : tc.pending) {
+            HIP_CHECK(hipEventSynchronize(pr.second));
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
+            tc.ms += ms;
+            tc.launches += 1;
+            event_pool.push_back(pr.first);
+            event_pool.push_back(pr.second);
+        }
+        tc.pending.clear();
+    }
+
+    // ---- input store (reference.rs:47-75) -------------------------------------------------------
+    void grow(InSlot &s, uint64_t need_floats, hipStream_t st) {
+        if (need_floats <= s.cap) return;
+        uint64_t cap = std::max<uint64_t>(need_floats, std::max<uint64_t>(s.cap * 2, 4096));
+        DevBuf nb;
+        nb.ensure(cap * sizeof(float));
+        uint64_t stored = s.len - s.base;
+        if (stored) HIP_CHECK(hipMemcpyAsync(nb.p, s.buf.p, stored * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));   // old buffer is freed below
+        s.buf = std::move(nb);
+        s.cap = cap;
+    }
+
+    // `device_rows`: in_data is a device pointer (fr_fill_buffer_device).
+    void store_inputs(uint32_t n_slots, uint64_t n_times, uint64_t idx, const float *in_data,
+                      const uint64_t *offs, uint32_t n_rows, bool device_rows, hipStream_t st) {
+        if (idx != head) {   // seek: forget history, act as if inputs were 0 before idx (renderer.rs:12-15)
+            for (InSlot &s : slots) { s.base = idx; s.len = idx; }
+            segs.clear();
+            if (n_vecs) segs.push_back({0, n_vecs, idx});
+        }
+        uint64_t want = (uint64_t)n_slots * n_times;   // `buff.len()`, reference.rs:60 (element count, a quirk)
+        if (n_vecs < want) { segs.push_back({n_vecs, want, idx}); n_vecs = want; }
+        uint32_t rows = (uint32_t)std::min<uint64_t>(n_rows, n_vecs);   // zip stops at the shorter (:68)
+        // validate everything before mutating so a refused call leaves the history intact
+        for (uint32_t r = 0; r < rows; ++r) {
+            uint64_t cur = (r < slots.size() && slots[r].fed) ? slots[r].len : implicit_len(r);
+            if (cur != idx)
+                throw Error(FR_ERR_INPUT_HISTORY, "input slot " + std::to_string(r) + " holds " + std::to_string(cur) +
+                                                      " samples, expected idx=" + std::to_string(idx));
+            if (offs[r + 1] < offs[r] || offs[r + 1] - offs[r] > n_times)
+                throw Error(FR_ERR_INPUT_TOO_LONG, "input row " + std::to_string(r) + " longer than the range rendered");
+        }
+        if (rows > slots.size()) slots.resize(rows);
+        for (uint32_t r = 0; r < rows; ++r) {
+            InSlot &s = slots[r];
+            if (!s.fed) { s.fed = true; s.base = implicit_len(r); s.len = s.base; }
+            uint64_t rl = offs[r + 1] - offs[r];
+            uint64_t stored = s.len - s.base;
+            grow(s, stored + n_times, st);
+            float *dst = s.buf.as<float>() + stored;
+            if (device_rows) {
+                if (rl) HIP_CHECK(hipMemcpyAsync(dst, in_data + offs[r], rl * sizeof(float), hipMemcpyDeviceToDevice, st));
+                if (rl < n_times) {
+                    // pad with the last value now stored, or 0 (reference.rs:72-73)
+                    const float *last = (stored + rl) ? dst + rl - 1 : nullptr;
+                    HIP_CHECK(launch_pad(dst + rl, n_times - rl, last, st));
+                }
+            } else {
+                // host rows: build row + padding in a staging buffer, one H2D copy
+                float pad = 0.0f;
+                if (rl) pad = in_data[offs[r] + rl - 1];
+                else if (stored) {
+                    HIP_CHECK(hipMemcpyAsync(&pad, dst - 1, sizeof(float), hipMemcpyDeviceToHost, st));
+                    HIP_CHECK(hipStreamSynchronize(st));
+                }
+                h_stage.resize(n_times);
+                if (rl) std::memcpy(h_stage.data(), in_data + offs[r], rl * sizeof(float));
+                std::fill(h_stage.begin() + rl, h_stage.end(), pad);
+                HIP_CHECK(hipMemcpyAsync(dst, h_stage.data(), n_times * sizeof(float), hipMemcpyHostToDevice, st));
+                HIP_CHECK(hipStreamSynchronize(st));   // h_stage is reused by the next row
+            }
+            s.len += n_times;
+        }
+    }
+
+    DevInput dev_input(uint32_t slot) const {
+        DevInput d{nullptr, 0, 0};
+        if (slot < slots.size() && slots[slot].fed && slot < n_vecs) {
+            const InSlot &s = slots[slot];
+            d.data = s.buf.as<float>();
+            d.base = s.base;
+            d.len = s.len;
+        }
+        return d;
+    }
+
+    // ---- planning ---------------------------------------------------------------------------------
+    void build_plan(uint32_t n_slots, hipStream_t st) {
+        Plan p;
+        p.version = mirror.version;
+        p.n_slots = n_slots;
+        p.fg = lower(mirror, n_slots);
+        MatchResult mr;
+        if (mode == FR_MODE_AUTO) {
+            mr = match_banks(p.fg, 20);
+        } else {
+            for (uint32_t r = 0; r < n_slots; ++r) mr.other_rows.push_back(r);
+        }
+        for (BankGroup &bg : mr.banks) {
+            BankStage bs;
+            bs.grp = std::move(bg);
+            bs.d_params.ensure(bs.grp.params.size() * sizeof(float));
+            bs.d_rows.ensure(bs.grp.rows.size() * sizeof(uint32_t));
+            HIP_CHECK(hipMemcpyAsync(bs.d_params.p, bs.grp.params.data(), bs.grp.params.size() * sizeof(float), hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(bs.d_rows.p, bs.grp.rows.data(), bs.grp.rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            p.banks.push_back(std::move(bs));
+        }
+        p.pull_rows = std::move(mr.other_rows);
+        if (!p.pull_rows.empty()) {
+            // dense input table: OP_INPUT.a becomes an index into input_slots
+            std::vector<DevNode> dn(p.fg.nodes.size());
+            std::unordered_map<uint32_t, uint32_t> dense;
+            for (size_t i = 0; i < dn.size(); ++i) {
+                const FlatNode &n = p.fg.nodes[i];
+                dn[i] = DevNode{n.op, n.a, n.b, n.depth};
+                if (n.op == OP_INPUT) {
+                    auto it = dense.emplace(n.a, (uint32_t)p.input_slots.size());
+                    if (it.second) p.input_slots.push_back(n.a);
+                    dn[i].a = it.first->second;
+                }
+            }
+            std::vector<uint32_t> roots(n_slots);
+            for (uint32_t r = 0; r < n_slots; ++r) roots[r] = p.fg.outputs[r];
+            p.d_nodes.ensure(dn.size() * sizeof(DevNode));
+            p.d_roots.ensure(roots.size() * sizeof(uint32_t));
+            HIP_CHECK(hipMemcpyAsync(p.d_nodes.p, dn.data(), dn.size() * sizeof(DevNode), hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(p.d_roots.p, roots.data(), roots.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        }
+        HIP_CHECK(hipStreamSynchronize(st));   // host vectors above go out of scope
+        // description
+        std::ostringstream js;
+        js << "{\"backend\":\"hip-gfx950\",\"mode\":" << mode << ",\"n_slots\":" << n_slots
+           << ",\"lowered_nodes\":" << p.fg.nodes.size() << ",\"max_depth\":" << p.fg.max_depth << ",\"banks\":[";
+        for (size_t i = 0; i < p.banks.size(); ++i) {
+            const BankGroup &g = p.banks[i].grp;
+            js << (i ? "," : "") << "{\"voices\":" << g.rows.size() << ",\"partials\":" << (1u << g.log2_p)
+               << ",\"input_slot\":" << g.input_slot << ",\"fast_ok\":" << (g.fast_ok ? "true" : "false")
+               << ",\"param_bytes\":" << g.params.size() * sizeof(float) << "}";
+        }
+        js << "],\"pull_rows\":" << p.pull_rows.size() << "}";
+        p.json = js.str();
+        p.valid = true;
+        plan = std::move(p);
+    }
+
+    // ---- execution --------------------------------------------------------------------------------
+    void execute(float *d_dst, uint32_t n_slots, uint64_t n_times, uint64_t idx, hipStream_t st) {
+        if (!plan.valid || plan.version != mirror.version || plan.n_slots != n_slots) build_plan(n_slots, st);
+        if (n_slots == 0 || n_times == 0) return;
+        for (BankStage &bs : plan.banks) {
+            BankArgs a{};
+            a.params = bs.d_params.as<float2>();
+            DevInput di = dev_input(bs.grp.input_slot);
+            // frames [idx, idx+n_times) of the time row: idx >= base always holds after store_inputs
+            if (di.data && di.len > idx && idx >= di.base) {
+                a.time = di.data + (idx - di.base);
+                a.time_valid = std::min<uint64_t>(n_times, di.len - idx);
+            } else {
+                a.time = nullptr;
+                a.time_valid = 0;
+            }
+            a.out = d_dst;
+            a.rows = bs.d_rows.as<uint32_t>();
+            a.n_voices = (uint32_t)bs.grp.rows.size();
+            a.log2_p = bs.grp.log2_p;
+            a.n_times = n_times;
+            a.fast_ok = bs.grp.fast_ok ? 1u : 0u;
+            bank_shape(a.log2_p, a.n_voices, n_times, a.chunk_log2, a.frames_per_lane);
+            if (a.chunk_log2 != a.log2_p) {
+                d_bank_ws.ensure(((size_t)a.n_voices << (a.log2_p - a.chunk_log2)) * n_times * sizeof(float));
+                a.ws = d_bank_ws.as<float>();
+            }
+            Scope sc(this, &t_bank, st);
+            HIP_CHECK(launch_bank(a, st));
+            sc.done();
+        }
+        if (!plan.pull_rows.empty()) run_pull(d_dst, n_slots, n_times, idx, st);
+    }
+
+    void run_pull(float *d_dst, uint32_t n_slots, uint64_t n_times, uint64_t idx, hipStream_t st) {
+        // input table for this call
+        std::vector<DevInput> tab(plan.input_slots.size());
+        for (size_t i = 0; i < tab.size(); ++i) tab[i] = dev_input(plan.input_slots[i]);
+        d_in_table.ensure(std::max<size_t>(tab.size(), 1) * sizeof(DevInput));
+        if (!tab.empty()) {
+            HIP_CHECK(hipMemcpyAsync(d_in_table.p, tab.data(), tab.size() * sizeof(DevInput), hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        const uint64_t depth = std::max<uint32_t>(plan.fg.max_depth, 1);
+        // pull rows are processed as contiguous runs of rows; stack workspace bounded to ~1 GiB
+        const uint64_t budget = 1ull << 30;
+        uint64_t chunk = std::max<uint64_t>(budget / (depth * 16), 256);
+        size_t i = 0;
+        while (i < plan.pull_rows.size()) {
+            size_t j = i + 1;
+            while (j < plan.pull_rows.size() && plan.pull_rows[j] == plan.pull_rows[j - 1] + 1) ++j;
+            uint64_t first = (uint64_t)plan.pull_rows[i] * n_times;
+            uint64_t total = (uint64_t)(j - i) * n_times;
+            for (uint64_t off = 0; off < total; off += chunk) {
+                uint64_t cnt = std::min(chunk, total - off);
+                d_stack_node.ensure(depth * cnt * sizeof(uint32_t));
+                d_stack_time.ensure(depth * cnt * sizeof(uint64_t));
+                d_stack_val.ensure(depth * cnt * sizeof(float));
+                PullArgs a{};
+                a.nodes = plan.d_nodes.as<DevNode>();
+                a.outputs = plan.d_roots.as<uint32_t>();
+                a.inputs = d_in_table.as<DevInput>();
+                a.n_inputs = (uint32_t)tab.size();
+                a.out = d_dst;
+                a.n_slots = n_slots;
+                a.n_times = n_times;
+                a.idx = idx;
+                a.first = first + off;
+                a.count = cnt;
+                a.st_node = d_stack_node.as<uint32_t>();
+                a.st_time = d_stack_time.as<uint64_t>();
+                a.st_val = d_stack_val.as<float>();
+                Scope sc(this, &t_pull, st);
+                HIP_CHECK(launch_pull(a, st));
+                sc.done();
+            }
+            i = j;
+        }
+    }
+};
+
+namespace {
+
+template <class F>
+fr_status guarded(fr_renderer *r, F &&f) {
+    if (!r) return FR_ERR_INVALID_ARG;
+    try {
+        f();
+        r->last_error.clear();
+        return FR_OK;
+    } catch (const Error &e) {
+        r->last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        r->last_error = "host out of memory";
+        return FR_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception &e) {
+        r->last_error = e.what();
+        return FR_ERR_INVALID_ARG;
+    }
+}
+
+void check_fill_args(const void *out, uint32_t n_slots, uint64_t n_times, const float *in_data,
+                     const uint64_t *offs, uint32_t n_rows) {
+    if (!out && n_slots != 0 && n_times != 0) throw Error(FR_ERR_INVALID_ARG, "null output buffer");
+    if (n_rows && !offs) throw Error(FR_ERR_INVALID_ARG, "null row offsets");
+    if (n_rows && offs[n_rows] > offs[0] && !in_data) throw Error(FR_ERR_INVALID_ARG, "null input data");
+    if (n_slots && n_times > (1ull << 40) / n_slots) throw Error(FR_ERR_INVALID_ARG, "render range too large");
+}
+
+}  // namespace
+
+extern "C" {
+
+fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
+    if (!out) return FR_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg && cfg->abi_version != FR_ABI_VERSION) return FR_ERR_INVALID_ARG;
+    int mode = cfg ? cfg->mode : FR_MODE_AUTO;
+    if (mode < FR_MODE_AUTO || mode > FR_MODE_STAGED) return FR_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FR_ERR_NO_DEVICE;
+    int dev = cfg ? cfg->device : -1;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) return FR_ERR_NO_DEVICE;
+    }
+    if (dev >= ndev) return FR_ERR_INVALID_ARG;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return FR_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FR_ERR_NO_DEVICE;   // code objects are gfx950 only
+    if (hipSetDevice(dev) != hipSuccess) return FR_ERR_NO_DEVICE;
+    fr_renderer *r = new (std::nothrow) fr_renderer();
+    if (!r) return FR_ERR_OUT_OF_MEMORY;
+    r->device = dev;
+    r->mode = mode;
+    if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete r;
+        return FR_ERR_DEVICE;
+    }
+    *out = r;
+    return FR_OK;
+}
+
+void fr_renderer_destroy(fr_renderer *r) { delete r; }
+
+fr_status fr_on_add_node(fr_renderer *r, uint32_t handle, const fr_effect *effect) {
+    return guarded(r, [&] { r->mirror.add_node(handle, effect); });
+}
+fr_status fr_on_del_node(fr_renderer *r, uint32_t handle) {
+    return guarded(r, [&] { r->mirror.del_node(handle); });
+}
+fr_status fr_on_add_edge(fr_renderer *r, const fr_edge *edge) {
+    return guarded(r, [&] {
+        if (!edge) throw Error(FR_ERR_INVALID_ARG, "null edge");
+        r->mirror.add_edge(*edge);
+    });
+}
+fr_status fr_on_del_edge(fr_renderer *r, const fr_edge *edge) {
+    return guarded(r, [&] {
+        if (!edge) throw Error(FR_ERR_INVALID_ARG, "null edge");
+        r->mirror.del_edge(*edge);
+    });
+}
+fr_status fr_on_add_nodes(fr_renderer *r, const uint32_t *handles, const fr_effect *const *effects, size_t n) {
+    return guarded(r, [&] {
+        if (n && (!handles || !effects)) throw Error(FR_ERR_INVALID_ARG, "null array");
+        for (size_t i = 0; i < n; ++i) r->mirror.add_node(handles[i], effects[i]);
+    });
+}
+fr_status fr_on_add_edges(fr_renderer *r, const fr_edge *edges, size_t n) {
+    return guarded(r, [&] {
+        if (n && !edges) throw Error(FR_ERR_INVALID_ARG, "null array");
+        for (size_t i = 0; i < n; ++i) r->mirror.add_edge(edges[i]);
+    });
+}
+
+fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t n_times, uint64_t idx,
+                         const float *in_data, const uint64_t *in_row_offsets, uint32_t n_in_rows) {
+    return guarded(r, [&] {
+        check_fill_args(out, n_slots, n_times, in_data, in_row_offsets, n_in_rows);
+        HIP_CHECK(hipSetDevice(r->device));
+        hipStream_t st = r->stream;
+        r->store_inputs(n_slots, n_times, idx, in_data, in_row_offsets, n_in_rows, false, st);
+        size_t bytes = (size_t)n_slots * n_times * sizeof(float);
+        r->d_out.ensure(bytes);
+        r->execute(r->d_out.as<float>(), n_slots, n_times, idx, st);
+        if (bytes) HIP_CHECK(hipMemcpyAsync(out, r->d_out.p, bytes, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));   // synchronous contract: dispatch.rs:150-151
+        r->head = idx + n_times;               // reference.rs:84
+    });
+}
+
+fr_status fr_fill_buffer_device(fr_renderer *r, float *d_out, uint32_t n_slots, uint64_t n_times, uint64_t idx,
+                                const float *d_in_data, const uint64_t *in_row_offsets, uint32_t n_in_rows,
+                                void *stream) {
+    return guarded(r, [&] {
+        check_fill_args(d_out, n_slots, n_times, d_in_data, in_row_offsets, n_in_rows);
+        HIP_CHECK(hipSetDevice(r->device));
+        hipStream_t st = (hipStream_t)stream;
+        r->store_inputs(n_slots, n_times, idx, d_in_data, in_row_offsets, n_in_rows, true, st);
+        r->execute(d_out, n_slots, n_times, idx, st);
+        r->head = idx + n_times;
+    });
+}
+
+const char *fr_last_error(const fr_renderer *r) { return r ? r->last_error.c_str() : "null renderer"; }
+
+const char *fr_status_string(fr_status s) {
+    switch (s) {
+    case FR_OK: return "ok";
+    case FR_ERR_INVALID_ARG: return "invalid argument";
+    case FR_ERR_INPUT_TOO_LONG: return "input row extends past the rendered range";
+    case FR_ERR_INPUT_HISTORY: return "input row does not continue the slot's stored history";
+    case FR_ERR_NO_SUCH_NODE: return "no such node";
+    case FR_ERR_BAD_SLOT: return "primitive read through a non-zero output slot";
+    case FR_ERR_CYCLE: return "dependency cycle";
+    case FR_ERR_DEVICE: return "device error";
+    case FR_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case FR_ERR_OUT_OF_MEMORY: return "out of memory";
+    case FR_ERR_UNSUPPORTED: return "unsupported";
+    case FR_ERR_COMM: return "communication error";
+    default: return "unknown status";
+    }
+}
+
+const char *fr_backend_name(void) { return "hip-gfx950"; }
+uint32_t fr_abi_version(void) { return FR_ABI_VERSION; }
+
+const char *fr_plan_json(fr_renderer *r) {
+    if (!r) return "{}";
+    r->plan_json_cache = r->plan.valid ? r->plan.json : "{}";
+    return r->plan_json_cache.c_str();
+}
+
+fr_status fr_set_timing(fr_renderer *r, int32_t enabled) {
+    if (!r) return FR_ERR_INVALID_ARG;
+    r->timing = enabled != 0;
+    return FR_OK;
+}
+
+fr_status fr_get_timing(fr_renderer *r, const char *kernel_class, double *ms, uint64_t *launches) {
+    return guarded(r, [&] {
+        if (!kernel_class) throw Error(FR_ERR_INVALID_ARG, "null kernel class");
+        HIP_CHECK(hipSetDevice(r->device));
+        r->resolve(r->t_bank);
+        r->resolve(r->t_pull);
+        std::string k(kernel_class);
+        double m = 0;
+        uint64_t n = 0;
+        if (k == "bank" || k == "all") { m += r->t_bank.ms; n += r->t_bank.launches; }
+        if (k == "pull" || k == "all") { m += r->t_pull.ms; n += r->t_pull.launches; }
+        if (k != "bank" && k != "pull" && k != "all" && k != "stage") throw Error(FR_ERR_INVALID_ARG, "unknown kernel class " + k);
+        if (ms) *ms = m;
+        if (launches) *launches = n;
+    });
+}
+
+fr_status fr_reset_timing(fr_renderer *r) {
+    return guarded(r, [&] {
+        HIP_CHECK(hipSetDevice(r->device));
+        r->resolve(r->t_bank);
+        r->resolve(r->t_pull);
+        r->t_bank.ms = r->t_pull.ms = 0;
+        r->t_bank.launches = r->t_pull.launches = 0;
+    });
+}
+
+}  // extern "C"

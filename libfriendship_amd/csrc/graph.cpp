@@ -1,0 +1,399 @@
+// graph.cpp -- mirror maintenance (GraphWatcher side) and lowering to a flat primitive DAG.
+#include "graph.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace fr {
+
+float f32_from_bits(uint32_t b) {
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+uint32_t f32_to_bits(float f) {
+    uint32_t b;
+    std::memcpy(&b, &f, 4);
+    return b;
+}
+
+static inline uint64_t mix(uint64_t h, uint64_t v) {
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xBF58476D1CE4E5B9ull;
+    return h ^ (h >> 31);
+}
+
+// ---- Mirror ------------------------------------------------------------------------------------
+
+static void check_effect(const fr_effect *e) {
+    if (!e) throw Error(FR_ERR_INVALID_ARG, "null effect");
+    if (e->kind < 0 || e->kind > FR_EFFECT_GRAPH) throw Error(FR_ERR_INVALID_ARG, "bad effect kind");
+    if (e->kind == FR_EFFECT_GRAPH &&
+        ((e->n_nodes && (!e->node_handles || !e->node_effects)) || (e->n_edges && !e->edges)))
+        throw Error(FR_ERR_INVALID_ARG, "composite effect with null arrays");
+}
+
+static void set_slot(std::vector<EdgeRef> &v, uint32_t slot, const EdgeRef &r) {
+    if (v.size() <= slot) v.resize((size_t)slot + 1);
+    v[slot] = r;
+}
+
+bool SubGraph::equals(const SubGraph &o) const {
+    auto same_refs = [](const std::vector<EdgeRef> &a, const std::vector<EdgeRef> &b) {
+        if (a.size() != b.size()) return false;
+        for (size_t i = 0; i < a.size(); ++i)
+            if (a[i].present != b[i].present ||
+                (a[i].present && (a[i].from != b[i].from || a[i].from_slot != b[i].from_slot)))
+                return false;
+        return true;
+    };
+    if (hash != o.hash || handles != o.handles || !same_refs(outputs, o.outputs)) return false;
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        if (nodes[i].kind != o.nodes[i].kind || nodes[i].sub != o.nodes[i].sub ||
+            !same_refs(nodes[i].inbound, o.nodes[i].inbound))
+            return false;
+    }
+    return true;
+}
+
+// Builds (or finds) the immutable definition of a composite effect: the renderer-side copy that
+// RefRenderer::make_node produces (reference.rs:101-111), made once per distinct definition.
+std::shared_ptr<const SubGraph> Mirror::intern(const fr_effect *e, int depth) {
+    if (depth > 256) throw Error(FR_ERR_INVALID_ARG, "effect nesting too deep");
+    auto g = std::make_shared<SubGraph>();
+    uint64_t h = 0x5EEDull;
+    g->handles.reserve(e->n_nodes);
+    g->nodes.reserve(e->n_nodes);
+    for (uint32_t i = 0; i < e->n_nodes; ++i) {
+        uint32_t hnd = e->node_handles[i];
+        const fr_effect *ce = e->node_effects[i];
+        if (hnd == 0) throw Error(FR_ERR_INVALID_ARG, "node handle 0 is reserved for graph I/O");
+        check_effect(ce);
+        MNode n;
+        n.kind = ce->kind;
+        if (ce->kind == FR_EFFECT_GRAPH) n.sub = intern(ce, depth + 1);
+        auto ins = g->index.emplace(hnd, (uint32_t)g->nodes.size());
+        if (!ins.second) {  // HashMap::insert replaces an existing entry (reference.rs:105)
+            g->nodes[ins.first->second] = std::move(n);
+        } else {
+            g->handles.push_back(hnd);
+            g->nodes.push_back(std::move(n));
+        }
+        h = mix(h, hnd);
+        h = mix(h, (uint64_t)ce->kind);
+        if (ce->kind == FR_EFFECT_GRAPH) h = mix(h, g->nodes[g->index[hnd]].sub->hash);
+    }
+    for (uint32_t i = 0; i < e->n_edges; ++i) {
+        const fr_edge &ed = e->edges[i];
+        EdgeRef r{ed.from, ed.from_slot, true};
+        if (ed.to == 0) {
+            set_slot(g->outputs, ed.to_slot, r);
+        } else {
+            auto it = g->index.find(ed.to);
+            if (it == g->index.end())  // `.unwrap()` of reference.rs:145
+                throw Error(FR_ERR_NO_SUCH_NODE, "composite effect: edge into unknown node " + std::to_string(ed.to));
+            set_slot(g->nodes[it->second].inbound, ed.to_slot, r);
+        }
+        h = mix(h, ((uint64_t)ed.from << 32) | ed.to);
+        h = mix(h, ((uint64_t)ed.from_slot << 32) | ed.to_slot);
+    }
+    g->hash = h;
+    auto range = interned_.equal_range(h);
+    for (auto it = range.first; it != range.second;) {
+        if (auto sp = it->second.lock()) {
+            if (sp->equals(*g)) return sp;
+            ++it;
+        } else {
+            it = interned_.erase(it);
+        }
+    }
+    interned_.emplace(h, g);
+    return g;
+}
+
+void Mirror::add_node(uint32_t handle, const fr_effect *e) {  // reference.rs:117-120
+    if (handle == 0) throw Error(FR_ERR_INVALID_ARG, "node handle 0 is reserved for graph I/O");
+    check_effect(e);
+    MNode n;
+    n.kind = e->kind;
+    if (e->kind == FR_EFFECT_GRAPH) n.sub = intern(e, 0);
+    nodes[handle] = std::move(n);
+    ++version;
+}
+
+void Mirror::del_node(uint32_t handle) {  // reference.rs:121-123
+    nodes.erase(handle);
+    ++version;
+}
+
+void Mirror::add_edge(const fr_edge &e) {  // reference.rs:124-126,141-153
+    EdgeRef r{e.from, e.from_slot, true};
+    if (e.to == 0) {
+        set_slot(outputs, e.to_slot, r);
+    } else {
+        auto it = nodes.find(e.to);
+        if (it == nodes.end())
+            throw Error(FR_ERR_NO_SUCH_NODE, "add_edge: destination node " + std::to_string(e.to) + " unknown");
+        set_slot(it->second.inbound, e.to_slot, r);
+    }
+    ++version;
+}
+
+void Mirror::del_edge(const fr_edge &e) {  // reference.rs:127-136
+    std::vector<EdgeRef> *inbound;
+    if (e.to == 0) {
+        inbound = &outputs;
+    } else {
+        auto it = nodes.find(e.to);
+        if (it == nodes.end())
+            throw Error(FR_ERR_NO_SUCH_NODE, "Attempt to delete edge, but it was never created!");
+        inbound = &it->second.inbound;
+    }
+    if (e.to_slot < inbound->size()) (*inbound)[e.to_slot] = EdgeRef{};
+    ++version;
+}
+
+// ---- FlatGraph -----------------------------------------------------------------------------------
+
+// Same arithmetic as the device code and as reference.rs:221-262; this file is compiled with
+// -ffp-contract=off so every operation rounds once.
+float host_binop(FlatOp op, float a, float b) {
+    switch (op) {
+    case OP_SUM2: return a + b;
+    case OP_MUL: return a * b;
+    case OP_DIV: return a / b;
+    case OP_MOD: {
+        float rem = std::fmod(a, b);
+        return rem < 0.0f ? rem + b : rem;
+    }
+    case OP_MIN: return (a < b || b != b) ? a : b;  // Rust >= 1.20 f32::min
+    default: return 0.0f;
+    }
+}
+
+bool FlatGraph::is_const(uint32_t id, float v) const {
+    return nodes[id].op == OP_CONST && nodes[id].a == f32_to_bits(v);
+}
+float FlatGraph::const_val(uint32_t id) const { return f32_from_bits(nodes[id].a); }
+
+uint32_t FlatGraph::push(FlatOp op, uint32_t a, uint32_t b, uint32_t depth) {
+    if (nodes.size() >= 0x3FFFFFFFu) throw Error(FR_ERR_UNSUPPORTED, "lowered graph exceeds 2^30 nodes");
+    nodes.push_back(FlatNode{op, a, b, depth});
+    if (depth > max_depth) max_depth = depth;
+    return (uint32_t)nodes.size() - 1;
+}
+
+uint32_t FlatGraph::konst(uint32_t bits) {
+    auto it = cse_[OP_CONST].find(bits);
+    if (it != cse_[OP_CONST].end()) return it->second;
+    uint32_t id = push(OP_CONST, bits, 0, 0);
+    cse_[OP_CONST].emplace(bits, id);
+    return id;
+}
+
+uint32_t FlatGraph::input(uint32_t slot) {
+    auto it = cse_[OP_INPUT].find(slot);
+    if (it != cse_[OP_INPUT].end()) return it->second;
+    uint32_t id = push(OP_INPUT, slot, 0, 0);
+    cse_[OP_INPUT].emplace(slot, id);
+    if (!has_input || slot > max_input_slot) max_input_slot = slot;
+    has_input = true;
+    return id;
+}
+
+uint32_t FlatGraph::make(FlatOp op, uint32_t a, uint32_t b) {
+    if (op == OP_DELAY) {
+        // reference.rs:197-216 with a constant amount resolved now.
+        if (is_const(a, 0.0f)) return a;  // every branch of Delay yields +0.0 when the source is +0.0
+        if (is_const(b)) {
+            float d = const_val(b);
+            if (d >= 18446744073709551616.0f) return konst(0);
+            uint64_t di = (d < 0.0f || d != d) ? 0 : (uint64_t)d;
+            if (di == 0) return a;
+        }
+    } else {
+        if (is_const(a) && is_const(b)) return konst(f32_to_bits(host_binop(op, const_val(a), const_val(b))));
+        // a+b and a*b are bitwise commutative up to NaN payload, which is outside the contract.
+        if ((op == OP_SUM2 || op == OP_MUL) && a > b) std::swap(a, b);
+    }
+    uint64_t key = ((uint64_t)a << 32) | b;
+    auto it = cse_[op].find(key);
+    if (it != cse_[op].end()) return it->second;
+    uint32_t d = 1 + std::max(nodes[a].depth, nodes[b].depth);
+    uint32_t id = push(op, a, b, d);
+    cse_[op].emplace(key, id);
+    return id;
+}
+
+// ---- lowering --------------------------------------------------------------------------------------
+
+namespace {
+
+struct Ctx {
+    int parent;              // -1 for the root
+    const MNode *inst;       // the composite node (in the parent's graph) this context instantiates
+    const SubGraph *g;       // null for the root
+};
+
+struct Key {
+    int ctx;
+    const MNode *node;
+    bool operator==(const Key &o) const { return ctx == o.ctx && node == o.node; }
+};
+struct KeyHash {
+    size_t operator()(const Key &k) const {
+        return (size_t)mix((uint64_t)(uintptr_t)k.node, (uint64_t)(uint32_t)k.ctx);
+    }
+};
+
+struct Frame {
+    int ctx;
+    const MNode *node;
+    int next;           // operand being resolved (0, 1) or 2 = ready
+    uint32_t vals[2];
+};
+
+constexpr int64_t IN_PROGRESS = -1;
+
+struct Lowerer {
+    const Mirror &m;
+    FlatGraph fg;
+    std::vector<Ctx> ctxs;
+    std::unordered_map<Key, int, KeyHash> child_ctx;
+    std::unordered_map<Key, int64_t, KeyHash> memo;
+
+    explicit Lowerer(const Mirror &mm) : m(mm) { ctxs.push_back(Ctx{-1, nullptr, nullptr}); }
+
+    const MNode *find(int ctx, uint32_t handle) const {
+        const SubGraph *g = ctxs[ctx].g;
+        if (!g) {
+            auto it = m.nodes.find(handle);
+            return it == m.nodes.end() ? nullptr : &it->second;
+        }
+        auto it = g->index.find(handle);
+        return it == g->index.end() ? nullptr : &g->nodes[it->second];
+    }
+
+    // Follows an edge through graph inputs and composite outputs until it lands on a value that is
+    // already known (returns true, id in `out`) or on a primitive node still to be evaluated
+    // (returns false, `need` filled).  Mirrors the dispatch at reference.rs:178-195.
+    bool resolve(int ctx, EdgeRef ref, uint32_t &out, Frame &need) {
+        for (uint64_t hops = 0;; ++hops) {
+            if (hops > (1u << 20)) throw Error(FR_ERR_CYCLE, "edge chain through composite I/O never reaches a node");
+            if (!ref.present) {  // get_maybe_edge_value: missing edge is 0f32 (reference.rs:164-173)
+                out = fg.konst(0);
+                return true;
+            }
+            if (ref.from == 0) {  // reading this graph's input (reference.rs:181-183)
+                const Ctx &c = ctxs[ctx];
+                if (c.parent < 0) {
+                    out = fg.input(ref.from_slot);
+                    return true;
+                }
+                // closure of reference.rs:189-193: the instance's inbound[slot] in the parent graph
+                uint32_t slot = ref.from_slot;
+                ref = slot < c.inst->inbound.size() ? c.inst->inbound[slot] : EdgeRef{};
+                ctx = c.parent;
+                continue;
+            }
+            const MNode *n = find(ctx, ref.from);
+            if (!n) throw Error(FR_ERR_NO_SUCH_NODE, "edge reads from unknown node " + std::to_string(ref.from));
+            ++fg.n_mirror_nodes_visited;
+            if (n->kind == FR_EFFECT_GRAPH) {  // reference.rs:188-194
+                Key k{ctx, n};
+                auto it = child_ctx.find(k);
+                int cc;
+                if (it == child_ctx.end()) {
+                    cc = (int)ctxs.size();
+                    ctxs.push_back(Ctx{ctx, n, n->sub.get()});
+                    child_ctx.emplace(k, cc);
+                } else {
+                    cc = it->second;
+                }
+                uint32_t slot = ref.from_slot;
+                ref = slot < n->sub->outputs.size() ? n->sub->outputs[slot] : EdgeRef{};
+                ctx = cc;
+                continue;
+            }
+            if (n->kind == FR_PRIM_F32CONSTANT) {  // reference.rs:217-220
+                out = fg.konst(ref.from_slot);
+                return true;
+            }
+            if (ref.from_slot != 0)  // assert!(from_slot == 0), reference.rs:199,223,...
+                throw Error(FR_ERR_BAD_SLOT, "primitive node " + std::to_string(ref.from) + " read through output slot " +
+                                                 std::to_string(ref.from_slot));
+            Key k{ctx, n};
+            auto it = memo.find(k);
+            if (it != memo.end()) {
+                if (it->second == IN_PROGRESS)
+                    throw Error(FR_ERR_CYCLE, "dependency cycle through node " + std::to_string(ref.from) +
+                                                  " (feedback is not evaluable by this engine)");
+                out = (uint32_t)it->second;
+                return true;
+            }
+            need = Frame{ctx, n, 0, {0, 0}};
+            return false;
+        }
+    }
+
+    static FlatOp op_of(int kind) {
+        switch (kind) {
+        case FR_PRIM_DELAY: return OP_DELAY;
+        case FR_PRIM_SUM2: return OP_SUM2;
+        case FR_PRIM_MULTIPLY: return OP_MUL;
+        case FR_PRIM_DIVIDE: return OP_DIV;
+        case FR_PRIM_MODULO: return OP_MOD;
+        default: return OP_MIN;
+        }
+    }
+
+    uint32_t eval(int ctx0, EdgeRef root) {
+        uint32_t result = 0;
+        Frame need;
+        if (resolve(ctx0, root, result, need)) return result;
+        std::vector<Frame> stack;
+        stack.push_back(need);
+        memo[Key{need.ctx, need.node}] = IN_PROGRESS;
+        while (!stack.empty()) {
+            Frame &f = stack.back();
+            if (f.next < 2) {
+                const MNode *n = f.node;
+                EdgeRef ref = (size_t)f.next < n->inbound.size() ? n->inbound[f.next] : EdgeRef{};
+                uint32_t id;
+                Frame child;
+                if (resolve(f.ctx, ref, id, child)) {
+                    f.vals[f.next++] = id;
+                } else {
+                    memo[Key{child.ctx, child.node}] = IN_PROGRESS;
+                    stack.push_back(child);  // invalidates f; loop re-reads the top
+                }
+                continue;
+            }
+            uint32_t id = fg.make(op_of(f.node->kind), f.vals[0], f.vals[1]);
+            memo[Key{f.ctx, f.node}] = id;
+            stack.pop_back();
+            if (stack.empty()) {
+                result = id;
+            } else {
+                Frame &p = stack.back();
+                p.vals[p.next++] = id;
+            }
+        }
+        return result;
+    }
+};
+
+}  // namespace
+
+FlatGraph lower(const Mirror &m, uint32_t n_slots) {
+    Lowerer L(m);
+    L.fg.konst(0);  // node 0 is always +0.0
+    L.fg.outputs.resize(n_slots);
+    for (uint32_t s = 0; s < n_slots; ++s) {
+        EdgeRef ref = s < m.outputs.size() ? m.outputs[s] : EdgeRef{};  // reference.rs:158-161
+        L.fg.outputs[s] = L.eval(0, ref);
+    }
+    return std::move(L.fg);
+}
+
+}  // namespace fr

@@ -1,0 +1,399 @@
+// kernels.hip -- gfx950 (CDNA4) kernels of the render engine.  Written for 64-lane wavefronts,
+// 256 CUs x 4 SIMD-32; compiled with -ffp-contract=off: every f32 operation of the reference
+// evaluator (reference src/render/reference.rs:197-262) rounds exactly once and so must we.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace fr {
+
+// ---------------------------------------------------------------------------------------------------
+// Shared primitive arithmetic (bit-exact restatement of reference.rs:197-262)
+// ---------------------------------------------------------------------------------------------------
+enum : uint32_t { OP_CONST = 0, OP_INPUT = 1, OP_DELAY = 2, OP_SUM2 = 3, OP_MUL = 4, OP_DIV = 5, OP_MOD = 6, OP_MIN = 7 };
+
+__device__ __forceinline__ float prim_mod(float a, float b) {
+    // `dividend % divisor` is fmodf (exact, sign of the dividend); `if rem < 0 { rem + divisor }`
+    float rem = fmodf(a, b);
+    return rem < 0.0f ? rem + b : rem;
+}
+
+__device__ __forceinline__ float prim_min(float a, float b) {
+    // Rust >= 1.20 core f32::min: (a < b || b.is_nan()) ? a : b
+    return (a < b || b != b) ? a : b;
+}
+
+__device__ __forceinline__ float prim_binop(uint32_t op, float a, float b) {
+    switch (op) {
+    case OP_SUM2: return a + b;
+    case OP_MUL: return a * b;
+    case OP_DIV: return a / b;   // hipcc default: correctly rounded f32 divide
+    case OP_MOD: return prim_mod(a, b);
+    default: return prim_min(a, b);
+    }
+}
+
+// Delay's amount -> frames (reference.rs:200-211).  Returns false when the output is 0 because the
+// amount is >= 2^64.
+__device__ __forceinline__ bool delay_frames(float d, uint64_t &frames) {
+    if (d >= 18446744073709551616.0f) return false;
+    frames = (d < 0.0f || d != d) ? 0ull : (uint64_t)d;   // clamp negatives, NaN -> 0, floor
+    return true;
+}
+
+__device__ __forceinline__ float read_input(const DevInput *in, uint32_t n_in, uint32_t slot, uint64_t t) {
+    if (slot >= n_in) return 0.0f;
+    DevInput s = in[slot];
+    if (t < s.base || t >= s.len) return 0.0f;   // zero prefix after a seek; beyond stored -> 0 (reference.rs:92-94)
+    return s.data[t - s.base];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Pull interpreter: one thread per (output row, t), the reference's recursion with an explicit stack.
+// Universal (any DAG of the 7 primitives, signal-dependent delays) and bit-exact; cost grows with the
+// number of root-to-leaf paths exactly like the reference, so the planner uses it only for graphs
+// it cannot stage.  Stack frames live in global memory, [level][thread] so a wave's accesses coalesce.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pull_kernel(PullArgs a) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.count) return;
+    const uint64_t lin = a.first + e;
+    const uint32_t slot = (uint32_t)(lin / a.n_times);
+    const uint64_t ti = lin - (uint64_t)slot * a.n_times;
+
+    uint32_t sp = 0;
+    uint32_t cur = a.outputs[slot];
+    uint64_t cur_t = a.idx + ti;
+    float ret = 0.0f;
+    bool calling = true;
+    for (;;) {
+        if (calling) {
+            DevNode n = a.nodes[cur];
+            if (n.op == OP_CONST) {
+                ret = __uint_as_float(n.a);
+                calling = false;
+            } else if (n.op == OP_INPUT) {
+                ret = read_input(a.inputs, a.n_inputs, n.a, cur_t);
+                calling = false;
+            } else {
+                // frame {node, stage 0, t}; first operand: Delay evaluates its amount first (reference.rs:200)
+                uint64_t o = (uint64_t)sp * a.count + e;
+                a.st_node[o] = cur;
+                a.st_time[o] = cur_t;
+                ++sp;
+                cur = (n.op == OP_DELAY) ? n.b : n.a;
+            }
+        } else {
+            if (sp == 0) break;
+            uint64_t o = (uint64_t)(sp - 1) * a.count + e;
+            uint32_t ns = a.st_node[o];
+            uint32_t node = ns & 0x3FFFFFFFu;
+            DevNode n = a.nodes[node];
+            uint64_t t = a.st_time[o];
+            if ((ns >> 30) == 0) {
+                if (n.op == OP_DELAY) {
+                    uint64_t frames;
+                    --sp;   // tail call: the source's value is the Delay's value
+                    if (!delay_frames(ret, frames) || frames > t) {
+                        ret = 0.0f;   // >= 2^64 or t - frames underflows (reference.rs:202-205,213)
+                    } else {
+                        cur = n.a;
+                        cur_t = t - frames;
+                        calling = true;
+                    }
+                } else {
+                    a.st_val[o] = ret;
+                    a.st_node[o] = node | (1u << 30);
+                    cur = n.b;
+                    cur_t = t;
+                    calling = true;
+                }
+            } else {
+                ret = prim_binop(n.op, a.st_val[o], ret);
+                --sp;
+            }
+        }
+    }
+    a.out[lin] = ret;
+}
+
+hipError_t launch_pull(const PullArgs &a, hipStream_t s) {
+    if (a.count == 0) return hipSuccess;
+    uint64_t blocks = (a.count + 255) / 256;
+    hipLaunchKernelGGL(pull_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused oscillator bank.
+//
+// For each voice v (an output row) and frame t:
+//     out[v][t] = TREE_{k<P}  amp_k * parab(Modulo(time[t] * w_k, 1))
+// where TREE is the balanced binary Sum2 tree over consecutive leaves and parab is the parabolic sine
+//     u = phase + (-0.5);  y = (-16*u) * (0.5 + -(-(min(u, -u))))          (11 primitive nodes per partial)
+// Algebra that is exact in f32 (proved in DESIGN.md, checked bit-for-bit by tests/test_bank_parity.py):
+//     -(-min(u,-u)) == |u| up to the sign of zero, which 0.5 + (-x) discards;
+//     (-16*u)*q == -16*RN(u*q) because |u*q| is 0 or >= 2^-50 (no subnormal, no overflow);
+//     amp*(-16*z) == RN((-16*amp)*z) when -16*amp is exact (host checks) -> A = -16*amp.
+// So a leaf costs 6 VALU ops (mul, fract, sub, sub|abs|, mul, mul) and the tree 1 add: 7 per partial-frame.
+//
+// Mapping (time-major lanes): a lane owns F frames, a wave owns 64*F consecutive frames and a
+// contiguous quarter of the voice's partials, a 256-thread workgroup (4 waves) owns one
+// (voice, time-tile).  Partial parameters {w, A} are wave-uniform, so they arrive through the scalar
+// cache into SGPRs (s_load_dwordx16 = 8 partials) and feed the VALU as scalar operands: no LDS
+// traffic, no cross-lane reduction in the hot loop.  The Sum2 tree is evaluated in its own
+// association: 8 leaves in registers, then a binary-counter carry chain of named registers across
+// groups (wave-uniform branches), then the 4 waves' subtrees combine through LDS.
+// ---------------------------------------------------------------------------------------------------
+
+template <bool FAST>
+__device__ __forceinline__ float bank_leaf(float t, float w, float A) {
+    float x = t * w;
+    float r;
+    if (FAST) {
+        r = __builtin_amdgcn_fractf(x);   // x >= 0 finite: x - floor(x) == fmodf(x, 1) exactly
+    } else {
+        r = x - truncf(x);                // == fmodf(x, 1) for every finite x; inf -> NaN like fmodf
+        r = r < 0.0f ? r + 1.0f : r;      // `if rem < 0 { rem + divisor }`
+    }
+    float u = r - 0.5f;
+    float q = 0.5f - fabsf(u);
+    float z = u * q;
+    return A * z;
+}
+
+typedef float __attribute__((address_space(4))) const *const_f32_ptr;   // constant addrspace -> SMEM loads
+
+struct ParamGroup {   // 8 partials' {w, A}: one s_load_dwordx16, lives in SGPRs
+    float w[8], A[8];
+};
+
+__device__ __forceinline__ void load_group(ParamGroup &pg, const_f32_ptr p, uint32_t g) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        pg.w[j] = p[(size_t)g * 16 + 2 * j];
+        pg.A[j] = p[(size_t)g * 16 + 2 * j + 1];
+    }
+}
+
+// A wave sums at most 2^8 groups = 2048 partials (chunk <= 8192 per workgroup): 9 carry levels.
+// The levels are separate named arrays, not one 2-D array: hipcc otherwise merges the per-level
+// stores into one dynamically indexed store and the whole table drops to scratch memory.
+template <int I, int N, class Fn>
+__device__ __forceinline__ void static_for(Fn &&fn) {   // compile-time indices: nothing left to index dynamically
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(fn);
+    }
+}
+
+template <int F>
+using Lvl = float (&)[F];
+#define FR_LEVELS_DECL Lvl<F> s0, Lvl<F> s1, Lvl<F> s2, Lvl<F> s3, Lvl<F> s4, Lvl<F> s5, Lvl<F> s6, Lvl<F> s7, Lvl<F> s8
+#define FR_LEVELS_PASS s0, s1, s2, s3, s4, s5, s6, s7, s8
+
+template <int F, bool FAST>
+__device__ __forceinline__ void bank_group(const ParamGroup &pg, uint32_t g, uint32_t levels,
+                                           const float (&t)[F], FR_LEVELS_DECL) {
+    float v[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        float l0 = bank_leaf<FAST>(t[f], pg.w[0], pg.A[0]);
+        float l1 = bank_leaf<FAST>(t[f], pg.w[1], pg.A[1]);
+        float l2 = bank_leaf<FAST>(t[f], pg.w[2], pg.A[2]);
+        float l3 = bank_leaf<FAST>(t[f], pg.w[3], pg.A[3]);
+        float l4 = bank_leaf<FAST>(t[f], pg.w[4], pg.A[4]);
+        float l5 = bank_leaf<FAST>(t[f], pg.w[5], pg.A[5]);
+        float l6 = bank_leaf<FAST>(t[f], pg.w[6], pg.A[6]);
+        float l7 = bank_leaf<FAST>(t[f], pg.w[7], pg.A[7]);
+        v[f] = ((l0 + l1) + (l2 + l3)) + ((l4 + l5) + (l6 + l7));
+    }
+    // binary-counter carry: level k holds the finished left sibling of height k (wave-uniform branches)
+#define FR_CARRY(K, SK)                                                    \
+    if (levels == K || ((g >> K) & 1u) == 0u) {                            \
+        static_for<0, F>([&](auto f) { SK[f] = v[f]; });                   \
+        return;                                                            \
+    }                                                                      \
+    static_for<0, F>([&](auto f) { v[f] = SK[f] + v[f]; });
+    FR_CARRY(0u, s0) FR_CARRY(1u, s1) FR_CARRY(2u, s2) FR_CARRY(3u, s3) FR_CARRY(4u, s4)
+    FR_CARRY(5u, s5) FR_CARRY(6u, s6) FR_CARRY(7u, s7)
+#undef FR_CARRY
+#pragma unroll
+    for (int f = 0; f < F; ++f) s8[f] = v[f];
+}
+
+template <int F, bool FAST>
+__device__ __forceinline__ void bank_wave_sum(const float *params, uint32_t ngroups, uint32_t levels,
+                                              const float (&t)[F], float (&res)[F]) {
+    float s0[F], s1[F], s2[F], s3[F], s4[F], s5[F], s6[F], s7[F], s8[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+        s0[f] = s1[f] = s2[f] = s3[f] = s4[f] = s5[f] = s6[f] = s7[f] = s8[f] = 0.0f;
+
+    const_f32_ptr p = (const_f32_ptr)params;
+    // two parameter groups in flight: the scalar load of group g+1 is issued before group g's math
+    ParamGroup pa, pb;
+    load_group(pa, p, 0);
+    // (scalar loads return out of order, so the only usable wait is lgkmcnt(0): wait for the group
+    // about to be consumed FIRST, then issue the next load so it flies under this group's ~120 VALU ops)
+    for (uint32_t g = 0; g < ngroups; g += 2) {
+        const bool has_b = g + 1 < ngroups;
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): pa has landed
+        if (has_b) load_group(pb, p, g + 1);
+        bank_group<F, FAST>(pa, g, levels, t, FR_LEVELS_PASS);
+        if (has_b) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // pb has landed
+            if (g + 2 < ngroups) load_group(pa, p, g + 2);
+            bank_group<F, FAST>(pb, g + 1, levels, t, FR_LEVELS_PASS);
+        }
+    }
+    // after the last group (all ones) the carry chain stopped at level `levels`
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        float r = s8[f];
+        r = levels == 7u ? s7[f] : r;
+        r = levels == 6u ? s6[f] : r;
+        r = levels == 5u ? s5[f] : r;
+        r = levels == 4u ? s4[f] : r;
+        r = levels == 3u ? s3[f] : r;
+        r = levels == 2u ? s2[f] : r;
+        r = levels == 1u ? s1[f] : r;
+        r = levels == 0u ? s0[f] : r;
+        res[f] = r;
+    }
+}
+
+template <int F>
+__global__ void __launch_bounds__(256) bank_kernel(BankArgs a, uint32_t tiles, uint32_t nblocks) {
+    // XCD-aware order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
+    // contiguous range of (voice, chunk, tile) work: its L2 then sees 1/8 of the parameter streams.
+    uint32_t b = blockIdx.x;
+    uint32_t lid = (nblocks % 8u == 0u) ? (b % 8u) * (nblocks / 8u) + b / 8u : b;
+    const uint32_t nchunks = 1u << (a.log2_p - a.chunk_log2);
+    const uint32_t vc = lid / tiles;                  // voice * nchunks + chunk
+    const uint32_t tile = lid - vc * tiles;
+    const uint32_t voice = vc >> (a.log2_p - a.chunk_log2);
+    const uint32_t chunk = vc & (nchunks - 1u);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    const uint64_t t0 = (uint64_t)tile * (64u * F);
+    float t[F];
+    bool nonneg = true;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        uint64_t ti = t0 + (uint32_t)f * 64u + lane;
+        t[f] = ti < a.time_valid ? a.time[ti] : 0.0f;
+        nonneg = nonneg && (t[f] >= 0.0f) && (t[f] <= 4294967296.0f);
+    }
+    const bool fast = a.fast_ok && __all(nonneg);   // then every x = t*w is in [0, 2^64]: finite, >= 0
+
+    const uint32_t Pc = 1u << a.chunk_log2;           // partials per workgroup, 32 <= Pc <= 8192
+    const uint32_t Pw = Pc >> 2;                      // partials per wave
+    const float *params = (const float *)(a.params + ((size_t)voice << a.log2_p) + (size_t)chunk * Pc + (size_t)wave * Pw);
+    const uint32_t ngroups = Pw >> 3;
+    const uint32_t levels = a.chunk_log2 - 5u;        // log2(ngroups) <= 8
+
+    float res[F];
+    if (fast) bank_wave_sum<F, true>(params, ngroups, levels, t, res);
+    else bank_wave_sum<F, false>(params, ngroups, levels, t, res);
+
+    __shared__ float sm[4][F][64];
+#pragma unroll
+    for (int f = 0; f < F; ++f) sm[wave][f][lane] = res[f];
+    __syncthreads();
+    if (wave == 0) {
+        // one chunk: straight to the voice's output row; else to the workspace [chunk][voice][t]
+        float *orow = (nchunks == 1u) ? a.out + (size_t)a.rows[voice] * a.n_times
+                                      : a.ws + ((size_t)chunk * a.n_voices + voice) * a.n_times;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            uint64_t ti = t0 + (uint32_t)f * 64u + lane;
+            float r = (sm[0][f][lane] + sm[1][f][lane]) + (sm[2][f][lane] + sm[3][f][lane]);
+            if (ti < a.n_times) orow[ti] = r;
+        }
+    }
+}
+
+// Upper levels of the voice's Sum2 tree when a voice was split over several workgroups:
+// out[v][t] = TREE_c ws[c][v][t], same binary-counter association, one thread per (v, t).
+__global__ void __launch_bounds__(256) bank_combine_kernel(BankArgs a) {
+    const uint64_t total = (uint64_t)a.n_voices * a.n_times;
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const uint32_t voice = (uint32_t)(e / a.n_times);
+    const uint64_t ti = e - (uint64_t)voice * a.n_times;
+    const uint32_t levels = a.log2_p - a.chunk_log2;
+    const uint32_t nchunks = 1u << levels;
+    constexpr int MAXL = 20;
+    float s[MAXL];
+#pragma unroll
+    for (int k = 0; k < MAXL; ++k) s[k] = 0.0f;
+    float result = 0.0f;
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        float v = a.ws[e + (uint64_t)c * total];
+#pragma unroll
+        for (int k = 0; k < MAXL; ++k) {
+            if ((uint32_t)k == levels) { result = v; break; }
+            if (((c >> k) & 1u) == 0u) { s[k] = v; break; }
+            v = s[k] + v;
+        }
+    }
+    a.out[(size_t)a.rows[voice] * a.n_times + ti] = result;
+}
+
+template <int F>
+static hipError_t launch_bank_f(const BankArgs &a, hipStream_t s) {
+    uint64_t tiles64 = (a.n_times + 64 * F - 1) / (64 * F);
+    uint64_t nblocks64 = tiles64 * a.n_voices << (a.log2_p - a.chunk_log2);
+    if (nblocks64 == 0) return hipSuccess;
+    if (nblocks64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    uint32_t tiles = (uint32_t)tiles64, nblocks = (uint32_t)nblocks64;
+    hipLaunchKernelGGL((bank_kernel<F>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || a.chunk_log2 == a.log2_p) return e;
+    uint64_t total = (uint64_t)a.n_voices * a.n_times;
+    hipLaunchKernelGGL(bank_combine_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// Chooses how a voice's partials are split over workgroups for this call's shape: as few chunks as
+// possible (<= 8192 partials each) while still launching >= ~8 workgroups per CU.
+void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane) {
+    const uint64_t want_blocks = 2048;
+    chunk_log2 = log2_p < 13 ? log2_p : 13;
+    frames_per_lane = 2;
+    auto blocks = [&](uint32_t cl, uint32_t f) {
+        return ((n_times + 64 * f - 1) / (64 * f)) * n_voices << (log2_p - cl);
+    };
+    if (blocks(chunk_log2, 2) < want_blocks) frames_per_lane = 1;
+    while (chunk_log2 > 5 && blocks(chunk_log2, frames_per_lane) < want_blocks) --chunk_log2;
+}
+
+hipError_t launch_bank(const BankArgs &a, hipStream_t s) {
+    if (a.log2_p < 5 || a.log2_p > 24 || a.chunk_log2 < 5 || a.chunk_log2 > 13 || a.chunk_log2 > a.log2_p)
+        return hipErrorInvalidValue;
+    if (a.chunk_log2 != a.log2_p && !a.ws) return hipErrorInvalidValue;
+    if (a.frames_per_lane == 2) return launch_bank_f<2>(a, s);
+    return launch_bank_f<1>(a, s);
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void pad_kernel(float *dst, uint64_t n, const float *src_last) {
+    float v = src_last ? *src_last : 0.0f;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+
+hipError_t launch_pad(float *dst, uint64_t n, const float *src_last, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(pad_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, dst, n, src_last);
+    return hipGetLastError();
+}
+
+}  // namespace fr

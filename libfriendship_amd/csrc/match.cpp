@@ -1,0 +1,157 @@
+// match.cpp -- recognises oscillator banks in a lowered graph.
+//
+// The reference has no oscillator primitive: a partial is a sub-graph of the seven
+// primitives, a voice is a Sum2 tree over partials.  This matcher finds output slots whose lowered
+// expression is exactly
+//
+//   voice  := complete balanced Sum2 tree with P = 2^k >= 32 leaves
+//   leaf   := Multiply(C(amp), y)
+//   y      := Multiply(Multiply(C(-16), u), Sum2(C(0.5), Multiply(C(-1), absu)))
+//   absu   := Multiply(C(-1), Minimum(u, Multiply(C(-1), u)))          (= |u|)
+//   u      := Sum2(Modulo(Multiply(Input(s), C(w)), C(1.0)), C(-0.5))
+//
+// (operand order of the commutative Sum2/Multiply is free) and hands their
+// parameters to the fused bank kernel.  Anything else is left to the generic evaluators, so a
+// mismatch costs speed, never correctness.
+#include "match.hpp"
+
+#include <cmath>
+#include <unordered_map>
+
+namespace fr {
+namespace {
+
+struct Leaf {
+    float w, A;
+    uint32_t slot;
+    bool ok;
+};
+
+struct Matcher {
+    const FlatGraph &g;
+    std::unordered_map<uint32_t, Leaf> leaf_memo;
+    explicit Matcher(const FlatGraph &fg) : g(fg) {}
+
+    const FlatNode &n(uint32_t id) const { return g.nodes[id]; }
+
+    // id == op(C(c), other) for a commutative op: returns other.
+    bool bin_const(uint32_t id, FlatOp op, float c, uint32_t &other) const {
+        const FlatNode &x = n(id);
+        if (x.op != (uint32_t)op) return false;
+        if (g.is_const(x.a, c)) { other = x.b; return true; }
+        if (g.is_const(x.b, c)) { other = x.a; return true; }
+        return false;
+    }
+    // id == op(C(any), other): returns the constant and other.
+    bool bin_anyconst(uint32_t id, FlatOp op, float &c, uint32_t &other) const {
+        const FlatNode &x = n(id);
+        if (x.op != (uint32_t)op) return false;
+        if (g.is_const(x.a) && !g.is_const(x.b)) { c = g.const_val(x.a); other = x.b; return true; }
+        if (g.is_const(x.b) && !g.is_const(x.a)) { c = g.const_val(x.b); other = x.a; return true; }
+        return false;
+    }
+
+    bool match_q(uint32_t q, uint32_t u) const {
+        uint32_t n1, absu, m, nu_chk;
+        if (!bin_const(q, OP_SUM2, 0.5f, n1)) return false;
+        if (!bin_const(n1, OP_MUL, -1.0f, absu)) return false;
+        if (!bin_const(absu, OP_MUL, -1.0f, m)) return false;
+        const FlatNode &mn = n(m);
+        if (mn.op != OP_MIN) return false;
+        uint32_t nu = (mn.a == u) ? mn.b : (mn.b == u ? mn.a : 0xFFFFFFFFu);
+        if (nu == 0xFFFFFFFFu) return false;
+        return bin_const(nu, OP_MUL, -1.0f, nu_chk) && nu_chk == u;
+    }
+
+    Leaf match_leaf(uint32_t id) {
+        auto it = leaf_memo.find(id);
+        if (it != leaf_memo.end()) return it->second;
+        Leaf L{0, 0, 0, false};
+        float amp = 0, w = 0;
+        uint32_t y, p, q, u = 0, phase, x, in;
+        do {
+            if (!bin_anyconst(id, OP_MUL, amp, y)) break;
+            const FlatNode &yn = n(y);
+            if (yn.op != OP_MUL) break;
+            // y = p * q in either operand order
+            bool ok = false;
+            for (int swap = 0; swap < 2 && !ok; ++swap) {
+                p = swap ? yn.b : yn.a;
+                q = swap ? yn.a : yn.b;
+                ok = bin_const(p, OP_MUL, -16.0f, u) && match_q(q, u);
+            }
+            if (!ok) break;
+            if (!bin_const(u, OP_SUM2, -0.5f, phase)) break;
+            const FlatNode &ph = n(phase);
+            if (ph.op != OP_MOD || !g.is_const(ph.b, 1.0f)) break;
+            x = ph.a;
+            if (!bin_anyconst(x, OP_MUL, w, in)) break;
+            if (n(in).op != OP_INPUT) break;
+            // A = -16*amp must be exact for amp*(-16*z) == A*z (kernels.hip bank notes)
+            float A = -16.0f * amp;
+            if (!std::isfinite(A) || !std::isfinite(w) || A / -16.0f != amp) break;
+            L = Leaf{w, A, n(in).a, true};
+        } while (false);
+        leaf_memo.emplace(id, L);
+        return L;
+    }
+
+    // Collects the leaves of a complete Sum2 tree of the given height rooted at id.
+    bool collect(uint32_t id, uint32_t height, std::vector<float> &params, uint32_t &slot, bool &first, bool &fast_ok) {
+        if (height == 0) {
+            Leaf L = match_leaf(id);
+            if (!L.ok) return false;
+            if (first) { slot = L.slot; first = false; }
+            else if (slot != L.slot) return false;
+            params.push_back(L.w);
+            params.push_back(L.A);
+            if (!(L.w >= 0.0f && L.w <= 4294967296.0f)) fast_ok = false;
+            return true;
+        }
+        const FlatNode &x = n(id);
+        if (x.op != OP_SUM2) return false;
+        return collect(x.a, height - 1, params, slot, first, fast_ok) &&
+               collect(x.b, height - 1, params, slot, first, fast_ok);
+    }
+};
+
+}  // namespace
+
+MatchResult match_banks(const FlatGraph &g, uint32_t max_log2_p) {
+    MatchResult R;
+    Matcher M(g);
+    std::unordered_map<uint64_t, size_t> group_of;   // (log2_p, slot) -> index in R.banks
+    for (uint32_t row = 0; row < g.outputs.size(); ++row) {
+        uint32_t root = g.outputs[row];
+        // height = number of Sum2 nodes on the leftmost path
+        uint32_t h = 0, cur = root;
+        while (g.nodes[cur].op == OP_SUM2 && h <= max_log2_p) { cur = g.nodes[cur].a; ++h; }
+        bool matched = false;
+        if (h >= 5 && h <= max_log2_p) {
+            std::vector<float> params;
+            params.reserve((size_t)2 << h);
+            uint32_t slot = 0;
+            bool first = true, fast_ok = true;
+            if (M.collect(root, h, params, slot, first, fast_ok)) {
+                uint64_t key = ((uint64_t)h << 32) | slot;
+                auto it = group_of.find(key);
+                if (it == group_of.end()) {
+                    it = group_of.emplace(key, R.banks.size()).first;
+                    BankGroup bg;
+                    bg.log2_p = h;
+                    bg.input_slot = slot;
+                    R.banks.push_back(std::move(bg));
+                }
+                BankGroup &bg = R.banks[it->second];
+                bg.rows.push_back(row);
+                bg.params.insert(bg.params.end(), params.begin(), params.end());
+                bg.fast_ok = bg.fast_ok && fast_ok;
+                matched = true;
+            }
+        }
+        if (!matched) R.other_rows.push_back(row);
+    }
+    return R;
+}
+
+}  // namespace fr

@@ -1,0 +1,209 @@
+"""Synthetic additive-synthesis trees (BASELINE.json configs) as graphs of the
+reference's seven primitives.
+
+The reference has no oscillator/harmonics/detune/envelope effect: each is a sub-graph
+of Delay/F32Constant/Sum2/Multiply/Divide/Modulo/Minimum.  This module builds those graphs as plain
+arrays (node handles + primitive kinds, 16-byte edges) that any renderer behind the C ABI accepts --
+the HIP engine and, in tests, the CPU oracle receive byte-identical graphs.
+
+Definitions (t = external input slot 0, the f32 frame ramp; C(x) = F32Constant edge carrying x):
+  partial  : x = Multiply(t, C(w));  phase = Modulo(x, C(1));  u = Sum2(phase, C(-0.5))
+             absu = Multiply(C(-1), Minimum(u, Multiply(C(-1), u)))
+             y = Multiply(Multiply(C(-16), u), Sum2(C(0.5), Multiply(C(-1), absu)))     parabolic sine
+             leaf = Multiply(C(amp), y)                                                   11 nodes
+  voice    : balanced binary Sum2 tree over the voice's leaves (adjacent pairs, level by level)
+  harmonics: w_k = (f0 * (k+1) [* (1+detune_k)]) / sr, either folded on the host in f32 (default) or
+             carried as constant Multiply/Divide nodes (`constants_in_graph=True`) for the engine to fold
+  envelope : ADSR from Minimum/Sum2/Multiply/Divide of t, Multiply(env, mix)
+  delay    : K feed-forward taps y = Sum2(x, Multiply(C(g), Delay(x, C(d)))) in series (N6)
+"""
+import numpy as np
+
+from .capi import FR_PRIM, Effect, f32_bits
+
+K_DELAY, K_CONST, K_SUM2, K_MUL, K_DIV, K_MOD, K_MIN = (FR_PRIM[n] for n in
+                                                         ("Delay", "F32Constant", "Sum2", "Multiply", "Divide", "Modulo", "Minimum"))
+CONST_HANDLE = 1  # one F32Constant node serves every constant (the value rides on the edge)
+
+
+def splitmix64(seed, n):
+    """n outputs of SplitMix64 started at `seed` (vectorised)."""
+    with np.errstate(over="ignore"):
+        i = np.arange(1, n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + i * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed, n):
+    return (splitmix64(seed, n) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def bits(x):
+    return np.asarray(x, dtype=np.float32).view(np.uint32)
+
+
+class GraphArrays:
+    """Accumulates nodes and edges; handles are assigned sequentially from 2 (1 = the constant node)."""
+
+    def __init__(self):
+        self.handles = [np.array([CONST_HANDLE], dtype=np.uint32)]
+        self.kinds = [np.array([K_CONST], dtype=np.int32)]
+        self.edges = []
+        self.next = 2
+
+    def nodes(self, kind, n):
+        h = np.arange(self.next, self.next + n, dtype=np.uint32)
+        self.next += n
+        self.handles.append(h)
+        self.kinds.append(np.full(n, kind, dtype=np.int32))
+        return h
+
+    def edge(self, frm, to, from_slot, to_slot):
+        frm, to, from_slot, to_slot = np.broadcast_arrays(
+            np.asarray(frm, dtype=np.uint32), np.asarray(to, dtype=np.uint32),
+            np.asarray(from_slot, dtype=np.uint32), np.asarray(to_slot, dtype=np.uint32))
+        self.edges.append(np.stack([frm.ravel(), to.ravel(), from_slot.ravel(), to_slot.ravel()], axis=1))
+
+    def const(self, to, value, to_slot):
+        """C(value) -> to.to_slot"""
+        self.edge(CONST_HANDLE, to, bits(value), to_slot)
+
+    def binop(self, kind, a, b, n=None):
+        """New nodes kind(a, b); a/b are handle arrays or ('c', values) constants or ('in', slot)."""
+        n = n if n is not None else max(_len(a), _len(b))
+        h = self.nodes(kind, n)
+        for operand, slot in ((a, 0), (b, 1)):
+            if isinstance(operand, tuple) and operand[0] == "c":
+                self.const(h, operand[1], slot)
+            elif isinstance(operand, tuple) and operand[0] == "in":
+                self.edge(0, h, operand[1], slot)
+            else:
+                self.edge(operand, h, 0, slot)
+        return h
+
+    def finish(self, n_outputs):
+        return {"handles": np.concatenate(self.handles), "kinds": np.concatenate(self.kinds),
+                "edges": np.ascontiguousarray(np.concatenate(self.edges, axis=0), dtype=np.uint32),
+                "n_outputs": n_outputs}
+
+
+def _len(x):
+    if isinstance(x, tuple):
+        return _len(x[1]) if x[0] == "c" else 1
+    return int(np.size(x))
+
+
+def C(v):
+    return ("c", np.asarray(v, dtype=np.float32))
+
+
+def IN(slot):
+    return ("in", slot)
+
+
+def partial_leaves(g, w, amp, time_slot=0):
+    """The 11-node partial oscillator for every (w, amp); returns leaf handles (same shape, flattened)."""
+    w = np.asarray(w, dtype=np.float32).ravel()
+    amp = np.asarray(amp, dtype=np.float32).ravel()
+    n = len(w)
+    x = g.binop(K_MUL, IN(time_slot), C(w), n)
+    ph = g.binop(K_MOD, x, C(np.float32(1.0)), n)
+    u = g.binop(K_SUM2, ph, C(np.float32(-0.5)), n)
+    nu = g.binop(K_MUL, C(np.float32(-1.0)), u, n)
+    m = g.binop(K_MIN, u, nu, n)
+    ab = g.binop(K_MUL, C(np.float32(-1.0)), m, n)
+    n1 = g.binop(K_MUL, C(np.float32(-1.0)), ab, n)
+    q = g.binop(K_SUM2, C(np.float32(0.5)), n1, n)
+    p = g.binop(K_MUL, C(np.float32(-16.0)), u, n)
+    y = g.binop(K_MUL, p, q, n)
+    return g.binop(K_MUL, C(amp), y, n)
+
+
+def sum_tree(g, leaves):
+    """Balanced binary Sum2 tree per row of `leaves` [V, P]: adjacent pairs level by level (an odd
+    element is carried up unchanged).  Returns the root handle per row."""
+    cur = np.asarray(leaves, dtype=np.uint32)
+    while cur.shape[1] > 1:
+        npair = cur.shape[1] // 2
+        a = cur[:, 0:2 * npair:2]
+        b = cur[:, 1:2 * npair:2]
+        s = g.binop(K_SUM2, a.ravel(), b.ravel(), a.size).reshape(a.shape)
+        cur = np.concatenate([s, cur[:, 2 * npair:]], axis=1) if cur.shape[1] % 2 else s
+    return cur[:, 0]
+
+
+def voice_params(n_voices, n_partials, seed, detune=False, sr=48000.0):
+    """SURVEY.md 8d parameters, every step rounded to f32 like a graph of f32 primitives would:
+    f0_v = 55*2^(v/12); f = f0_v*(k+1) [*(1+delta)]; w = f/sr; amp = 1/(k+1)."""
+    v = np.arange(n_voices, dtype=np.float64)[:, None]
+    k1 = np.arange(1, n_partials + 1, dtype=np.float32)[None, :]
+    f0 = (55.0 * 2.0 ** (v / 12.0)).astype(np.float32)
+    f = (f0 * k1).astype(np.float32)
+    delta = None
+    if detune:
+        u = uniform01(seed, n_voices * n_partials).reshape(n_voices, n_partials)
+        delta = ((u - 0.5) * 0.01).astype(np.float32)
+        f = (f * (np.float32(1.0) + delta).astype(np.float32)).astype(np.float32)
+    w = (f / np.float32(sr)).astype(np.float32)
+    amp = (np.float32(1.0) / k1).astype(np.float32) * np.ones((n_voices, 1), dtype=np.float32)
+    return {"f0": f0, "k1": k1, "delta": delta, "w": w, "amp": amp.astype(np.float32), "sr": np.float32(sr)}
+
+
+def additive_tree(n_voices, n_partials, seed=0x5EED0002, detune=False, sr=48000.0, time_slot=0):
+    """configs B/C (and the oscillator part of D/E): V voices x P partials, one output slot per voice."""
+    p = voice_params(n_voices, n_partials, seed, detune, sr)
+    g = GraphArrays()
+    leaves = partial_leaves(g, p["w"], p["amp"], time_slot).reshape(n_voices, n_partials)
+    roots = sum_tree(g, leaves)
+    g.edge(roots, 0, 0, np.arange(n_voices, dtype=np.uint32))
+    t = g.finish(n_voices)
+    t["params"] = p
+    return t
+
+
+_PRIM_EFFECTS = None
+
+
+def install(renderer, tree):
+    """Feeds the graph to a renderer through the batch entry points (nodes grouped by kind, then edges)."""
+    global _PRIM_EFFECTS
+    if _PRIM_EFFECTS is None:
+        from .capi import PRIMITIVES
+        _PRIM_EFFECTS = [Effect.primitive(n) for n in PRIMITIVES]
+    handles, kinds = tree["handles"], tree["kinds"]
+    for k in np.unique(kinds):
+        renderer.on_add_nodes(handles[kinds == k], _PRIM_EFFECTS[int(k)])
+    renderer.on_add_edges(tree["edges"])
+    return renderer
+
+
+def time_ramp(start, end):
+    """The f32 frame ramp fed to the time slot (exact below 2^24 frames)."""
+    return np.arange(start, end, dtype=np.float64).astype(np.float32)
+
+
+def bank_reference_numpy(w, amp, t):
+    """numpy restatement of one voice (same op order and association as the graph), for test diagnostics.
+    w, amp: [P] f32; t: [T] f32 -> [T] f32.  Not used by any product path."""
+    w = np.asarray(w, np.float32)[:, None]
+    amp = np.asarray(amp, np.float32)[:, None]
+    t = np.asarray(t, np.float32)[None, :]
+    x = (t * w).astype(np.float32)
+    rem = np.fmod(x, np.float32(1.0)).astype(np.float32)
+    ph = np.where(rem < 0, (rem + np.float32(1.0)).astype(np.float32), rem)
+    u = (ph + np.float32(-0.5)).astype(np.float32)
+    nu = (np.float32(-1.0) * u).astype(np.float32)
+    m = np.where((u < nu) | np.isnan(nu), u, nu)
+    ab = (np.float32(-1.0) * m).astype(np.float32)
+    n1 = (np.float32(-1.0) * ab).astype(np.float32)
+    q = (np.float32(0.5) + n1).astype(np.float32)
+    pp = (np.float32(-16.0) * u).astype(np.float32)
+    y = (pp * q).astype(np.float32)
+    cur = (amp * y).astype(np.float32)
+    while cur.shape[0] > 1:
+        npair = cur.shape[0] // 2
+        s = (cur[0:2 * npair:2] + cur[1:2 * npair:2]).astype(np.float32)
+        cur = np.concatenate([s, cur[2 * npair:]], axis=0) if cur.shape[0] % 2 else s
+    return cur[0]

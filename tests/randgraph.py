@@ -1,0 +1,113 @@
+"""Seeded random graphs of the seven primitives (+ nested composites) for parity tests."""
+import numpy as np
+
+from libfriendship_amd.capi import Effect, f32_bits
+
+OPS = ["Delay", "Sum2", "Multiply", "Divide", "Modulo", "Minimum"]
+SPECIAL = [0.0, -0.0, 1.0, -1.0, 0.5, 2.0, 3.0, 1e-30, -3.5, 7.25, 1e20, float("inf"), float("nan"), 1.8446744e19, 4.0e19]
+
+
+def _const(rng):
+    r = rng.random()
+    if r < 0.25:
+        return float(SPECIAL[rng.integers(len(SPECIAL))])
+    if r < 0.6:
+        return float(rng.integers(-4, 9))
+    return float(np.float32(rng.normal() * 3))
+
+
+def random_effect(rng, depth=0, max_nodes=6):
+    """A random composite effect: 1-2 inputs, 1-2 outputs, a few primitive (or nested) nodes."""
+    n = int(rng.integers(1, max_nodes + 1))
+    n_in = int(rng.integers(1, 3))
+    nodes, edges = [], []
+    avail = []  # (handle, from_slot) producers inside the effect
+    const_h = 1000
+    nodes.append((const_h, Effect.primitive("F32Constant")))
+    for i in range(n):
+        h = i + 1
+        if depth < 1 and rng.random() < 0.2:
+            sub, sub_in, sub_out = random_effect(rng, depth + 1, 4)
+            nodes.append((h, sub))
+            arity, outs = sub_in, sub_out
+        else:
+            nodes.append((h, Effect.primitive(OPS[rng.integers(len(OPS))])))
+            arity, outs = 2, 1
+        for slot in range(arity):
+            r = rng.random()
+            if r < 0.15:
+                continue  # unconnected -> 0
+            if r < 0.45 or not avail:
+                if rng.random() < 0.5:
+                    edges.append((0, h, int(rng.integers(n_in)), slot))
+                else:
+                    edges.append((const_h, h, f32_bits(_const(rng)), slot))
+            else:
+                src = avail[rng.integers(len(avail))]
+                edges.append((src[0], h, src[1], slot))
+        for o in range(outs):
+            avail.append((h, o))
+    n_out = int(rng.integers(1, 3))
+    for o in range(n_out):
+        src = avail[rng.integers(len(avail))]
+        edges.append((src[0], 0, src[1], o))
+    return Effect.graph(nodes, edges), n_in, n_out
+
+
+def random_graph(seed, n_nodes=24, n_inputs=2, n_outputs=3, signal_delays=True, composites=True):
+    """Returns a list of steps [('node', h, effect) | ('edge', f, t, fs, ts)] and n_outputs."""
+    rng = np.random.default_rng(seed)
+    steps = [("node", 1, Effect.primitive("F32Constant"))]
+    avail = []
+    for i in range(n_nodes):
+        h = i + 2
+        if composites and rng.random() < 0.15:
+            eff, arity, outs = random_effect(rng)
+            kind = None
+        else:
+            kind = OPS[rng.integers(len(OPS))]
+            eff, arity, outs = Effect.primitive(kind), 2, 1
+        steps.append(("node", h, eff))
+        for slot in range(arity):
+            r = rng.random()
+            if r < 0.08:
+                continue
+            force_const = kind == "Delay" and slot == 1 and not (signal_delays and rng.random() < 0.4)
+            if force_const:
+                d = float(rng.integers(0, 9)) if rng.random() < 0.8 else _const(rng)
+                steps.append(("edge", 1, h, f32_bits(d), slot))
+            elif r < 0.3 or not avail:
+                if rng.random() < 0.6:
+                    steps.append(("edge", 0, h, int(rng.integers(n_inputs)), slot))
+                else:
+                    steps.append(("edge", 1, h, f32_bits(_const(rng)), slot))
+            else:
+                src = avail[rng.integers(len(avail))]
+                steps.append(("edge", src[0], h, src[1], slot))
+        for o in range(outs):
+            avail.append((h, o))
+    for o in range(n_outputs):
+        if rng.random() < 0.1:
+            continue  # unconnected output -> zeros
+        src = avail[rng.integers(max(0, len(avail) - 8), len(avail))]
+        steps.append(("edge", src[0], 0, src[1], o))
+    return steps, n_outputs
+
+
+def install_steps(r, steps):
+    for s in steps:
+        if s[0] == "node":
+            r.on_add_node(s[1], s[2])
+        else:
+            r.on_add_edge(*s[1:])
+
+
+def random_inputs(rng, n_inputs, n_times, kind="mixed"):
+    rows = []
+    for i in range(n_inputs):
+        L = n_times if rng.random() < 0.7 else int(rng.integers(0, n_times + 1))
+        if i == 0 and kind != "noise":
+            rows.append(None)  # filled by caller with the time ramp
+        else:
+            rows.append(np.float32(rng.normal(size=L) * 4).astype(np.float32))
+    return rows

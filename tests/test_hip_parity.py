@@ -1,0 +1,256 @@
+"""GPU parity tests proper: the HIP engine (through the C ABI) against the CPU oracle on the same
+seeded inputs, bit-exact (NaN == NaN).  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+import kat_replay
+import oracle_tools
+import randgraph
+from kat_replay import same_bits
+from libfriendship_amd import synth
+from libfriendship_amd.capi import (FR_ERR_CYCLE, FR_ERR_INPUT_HISTORY, FR_ERR_INPUT_TOO_LONG, FR_ERR_NO_SUCH_NODE,
+                                    RenderError, Renderer, f32_bits)
+
+pytestmark = pytest.mark.gpu
+
+
+def first_diff(a, b):
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    bad = ~((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b)))
+    idx = np.argwhere(bad)
+    if len(idx) == 0:
+        return "identical"
+    i = tuple(idx[0])
+    return f"{bad.sum()} of {bad.size} differ; first at {i}: got {a[i]!r} ({a.view(np.uint32)[i]:#x}) expected {b[i]!r} ({b.view(np.uint32)[i]:#x})"
+
+
+# ---- the reference's own known-answer tests, through the HIP engine -----------------------------
+@pytest.mark.parametrize("mode", ["auto", "pull"])
+@pytest.mark.parametrize("i", range(11))
+def test_reference_kat_on_hip(hip_lib, kat, i, mode):
+    kat_replay.check(hip_lib, kat["tests"][i], mode=mode)
+
+
+# ---- random graphs of all seven primitives ---------------------------------------------------------
+@pytest.mark.parametrize("mode", ["pull", "auto"])
+@pytest.mark.parametrize("seed", range(24))
+def test_random_graphs(hip_lib, oracle_lib, seed, mode):
+    rng = np.random.default_rng(1000 + seed)
+    steps, n_out = randgraph.random_graph(seed, n_nodes=int(rng.integers(4, 40)), n_inputs=2, n_outputs=3)
+    T = 96
+    with Renderer(hip_lib, mode=mode) as hip, Renderer(oracle_lib) as ref:
+        randgraph.install_steps(hip, steps)
+        randgraph.install_steps(ref, steps)
+
+        def both(start, end, rows):
+            try:
+                exp = ref.fill_buffer(n_out, start, end, rows)
+            except RenderError as e:
+                with pytest.raises(RenderError) as ei:
+                    hip.fill_buffer(n_out, start, end, rows)
+                assert ei.value.status == e.status
+                return False
+            got = hip.fill_buffer(n_out, start, end, rows)
+            assert same_bits(got, exp), f"seed {seed} [{start},{end}): " + first_diff(got, exp)
+            return True
+
+        noise = lambda n: (rng.normal(size=n) * 3).astype(np.float32)
+        if not both(0, T, [synth.time_ramp(0, T), noise(T)]):
+            return
+        both(T, 2 * T, [synth.time_ramp(T, 2 * T), noise(int(rng.integers(0, T)))])   # short row: last-value padding
+        both(5000, 5000 + T, [synth.time_ramp(5000, 5000 + T), noise(T)])               # seek
+        both(5000 + T, 5000 + T + 7, [synth.time_ramp(5000 + T, 5000 + T + 7)])          # slot 1 not fed
+
+
+def test_deep_chain_graph(hip_lib, oracle_lib):
+    """A 600-deep linear chain (depth stresses the pull stack) with a delay in the middle."""
+    N = 600
+    with Renderer(hip_lib, mode="pull") as hip, Renderer(oracle_lib) as ref:
+        for r in (hip, ref):
+            r.on_add_node(1, "F32Constant")
+            prev = (0, 0)
+            for i in range(N):
+                h = i + 2
+                r.on_add_node(h, "Delay" if i == N // 2 else ("Sum2" if i % 2 else "Multiply"))
+                r.on_add_edge(prev[0], h, prev[1], 0)
+                r.on_add_edge(1, h, f32_bits(3.0 if i == N // 2 else (0.001 if i % 2 else 1.0001)), 1)
+                prev = (h, 0)
+            r.on_add_edge(prev[0], 0, 0, 0)
+        t = synth.time_ramp(0, 128)
+        assert same_bits(hip.fill_buffer(1, 0, 128, [t]), ref.fill_buffer(1, 0, 128, [t]))
+
+
+# ---- fused oscillator bank ---------------------------------------------------------------------------
+BANK_CASES = [  # V, P, T, idx
+    (1, 32, 64, 0), (2, 64, 256, 0), (3, 128, 100, 0), (1, 256, 1000, 48000), (5, 512, 333, 7),
+    (2, 1024, 129, 1 << 20), (1, 4096, 64, 0), (64, 32, 4800, 0), (1, 8192, 200, 0), (1, 16384, 70, 123),
+    (2, 32768, 65, 0),
+]
+
+
+@pytest.mark.parametrize("V,P,T,idx", BANK_CASES)
+def test_bank_bit_exact(hip_lib, oracle_lib, V, P, T, idx):
+    tree = synth.additive_tree(V, P, seed=P + V, detune=bool(P % 3))
+    t = synth.time_ramp(idx, idx + T)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        got = hip.fill_buffer(V, idx, idx + T, [t])
+        plan = hip.plan()
+        assert plan["pull_rows"] == 0 and sum(b["voices"] for b in plan["banks"]) == V, plan
+        if P * T * V <= 1 << 21:
+            exp = ref.fill_buffer(V, idx, idx + T, [t])
+            assert same_bits(got, exp), first_diff(got, exp)
+        else:   # the oracle is random-access in time (a seek per sampled frame; the graph has no Delay)
+            rng = np.random.default_rng(P)
+            cols = np.unique(np.concatenate([[0, T - 1], rng.integers(0, T, 6)]))
+            for c in cols:
+                exp = ref.fill_buffer(V, idx + int(c), idx + int(c) + 1, [t[c:c + 1]])
+                assert same_bits(got[:, c:c + 1], exp), f"frame {c}: " + first_diff(got[:, c:c + 1], exp)
+
+
+def test_bank_matches_pull_interpreter(hip_lib):
+    """Fused kernel vs the generic interpreter on the same device (sizes the oracle would take minutes for)."""
+    tree = synth.additive_tree(4, 256, seed=3, detune=True)
+    t = synth.time_ramp(0, 1536)
+    with Renderer(hip_lib, mode="auto") as a, Renderer(hip_lib, mode="pull") as b:
+        synth.install(a, tree)
+        synth.install(b, tree)
+        assert same_bits(a.fill_buffer(4, 0, 1536, [t]), b.fill_buffer(4, 0, 1536, [t]))
+
+
+def test_bank_unusual_time_inputs(hip_lib, oracle_lib):
+    """The time slot is just an input signal: negative, fractional, huge, NaN/inf, short (padded) rows."""
+    tree = synth.additive_tree(2, 64, seed=11)
+    rng = np.random.default_rng(5)
+    rows = [
+        (-synth.time_ramp(0, 200)),                                   # negative times: slow (general) path
+        (rng.normal(size=200) * 1000).astype(np.float32),             # mixed sign, fractional
+        np.array([0, 1, 2, np.nan, np.inf, -np.inf, 1e30, 3e38, 1e-30, -0.0] * 20, dtype=np.float32),
+        synth.time_ramp(0, 50),                                       # short row: padded with 49.0
+        np.zeros(0, np.float32),                                      # empty row: padded with last value
+    ]
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        for i, row in enumerate(rows):
+            got = hip.fill_buffer(2, i * 200, (i + 1) * 200, [row])
+            exp = ref.fill_buffer(2, i * 200, (i + 1) * 200, [row])
+            assert same_bits(got, exp), f"row {i}: " + first_diff(got, exp)
+        # no time row at all after a seek: time reads as 0
+        assert same_bits(hip.fill_buffer(2, 0, 100), ref.fill_buffer(2, 0, 100))
+        assert hip.plan()["banks"]
+
+
+def test_bank_negative_frequency_and_mixed_outputs(hip_lib, oracle_lib):
+    """A voice with negative w (general path), plus an output that is not a bank (pull) next to banks."""
+    g = synth.GraphArrays()
+    w = np.linspace(-0.01, 0.02, 64).astype(np.float32)
+    amp = np.linspace(1.0, 0.1, 64).astype(np.float32)
+    leaves = synth.partial_leaves(g, w, amp).reshape(1, 64)
+    root = synth.sum_tree(g, leaves)
+    g.edge(root, 0, 0, 0)                       # out0: a bank
+    d = g.binop(synth.K_DELAY, root, synth.C(np.float32(5.0)), 1)
+    g.edge(d, 0, 0, 1)                          # out1: the bank delayed by 5 (not a bank: pull)
+    g.edge(0, 0, 0, 2)                          # out2: the time input itself
+    tree = g.finish(3)
+    t = synth.time_ramp(0, 300)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        got, exp = hip.fill_buffer(3, 0, 300, [t]), ref.fill_buffer(3, 0, 300, [t])
+        assert same_bits(got, exp), first_diff(got, exp)
+        plan = hip.plan()
+        assert len(plan["banks"]) == 1 and plan["pull_rows"] == 2 and not plan["banks"][0]["fast_ok"]
+
+
+def test_chunked_calls_equal_one_call(hip_lib):
+    """Size-independent property at BASELINE config C's full shape: rendering 4800 frames as one call,
+    as 10 x 480 and as ragged chunks gives identical bits (the evaluator is a pure function of t)."""
+    V, P, T = 64, 4096, 4800
+    tree = synth.additive_tree(V, P)
+    t = synth.time_ramp(0, T)
+    with Renderer(hip_lib) as a, Renderer(hip_lib) as b, Renderer(hip_lib) as c:
+        for r in (a, b, c):
+            synth.install(r, tree)
+        whole = a.fill_buffer(V, 0, T, [t])
+        parts = np.concatenate([b.fill_buffer(V, s, s + 480, [t[s:s + 480]]) for s in range(0, T, 480)], axis=1)
+        cuts = [0, 1, 65, 700, 701, 2049, 4799, 4800]
+        ragged = np.concatenate([c.fill_buffer(V, s, e, [t[s:e]]) for s, e in zip(cuts[:-1], cuts[1:])], axis=1)
+        assert same_bits(whole, parts) and same_bits(whole, ragged)
+        assert a.plan()["banks"][0]["partials"] == P
+
+
+def test_config_c_full_size_sampled_against_oracle(hip_lib, oracle_lib):
+    """BASELINE config C (4096 partials x 64 voices): the real oracle, random-access, on sampled frames of
+    every voice; the graph is the same 3.1 M-node primitive graph on both sides."""
+    V, P, T = 64, 4096, 4800
+    tree = synth.additive_tree(V, P)
+    t = synth.time_ramp(0, T)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        got = hip.fill_buffer(V, 0, T, [t])
+        rng = np.random.default_rng(0)
+        cols = np.unique(np.concatenate([[0, 1, T - 1], rng.integers(0, T, 5)]))
+        for c in cols:   # one oracle call per sampled frame (a seek each; this graph has no Delay)
+            exp = ref.fill_buffer(V, int(c), int(c) + 1, [t[c:c + 1]])
+            assert same_bits(got[:, c:c + 1], exp), f"frame {c}: " + first_diff(got[:, c:c + 1], exp)
+
+
+# ---- boundary behaviour on the HIP engine ---------------------------------------------------------------
+def test_hip_error_codes(hip_lib):
+    with Renderer(hip_lib) as r:
+        r.on_add_edge(0, 0, 0, 0)
+        with pytest.raises(RenderError) as ei:
+            r.fill_buffer(1, 0, 4, [[1, 2, 3, 4, 5]])
+        assert ei.value.status == FR_ERR_INPUT_TOO_LONG
+        assert r.fill_buffer(1, 0, 4, [[1, 2, 3, 4]]).tolist() == [[1, 2, 3, 4]]   # refused call left state intact
+    with Renderer(hip_lib) as r:
+        r.on_add_edge(0, 0, 0, 0)
+        r.on_add_edge(0, 0, 1, 1)
+        r.fill_buffer(2, 0, 4, [[1, 2, 3, 4]])
+        with pytest.raises(RenderError) as ei:
+            r.fill_buffer(2, 4, 8, [[1, 2, 3, 4], [9, 9, 9, 9]])
+        assert ei.value.status == FR_ERR_INPUT_HISTORY
+    with Renderer(hip_lib) as r:
+        with pytest.raises(RenderError) as ei:
+            r.on_add_edge(0, 42, 0, 0)
+        assert ei.value.status == FR_ERR_NO_SUCH_NODE
+    with Renderer(hip_lib) as r:   # a cycle the reference's RouteGraph would have rejected
+        r.on_add_node(1, "Sum2")
+        r.on_add_edge(1, 1, 0, 0)
+        r.on_add_edge(1, 0, 0, 0)
+        with pytest.raises(RenderError) as ei:
+            r.fill_buffer(1, 0, 4)
+        assert ei.value.status == FR_ERR_CYCLE
+
+
+def test_hip_rows_beyond_storage_are_dropped(hip_lib):
+    with Renderer(hip_lib) as r:
+        r.on_add_edge(0, 0, 1, 0)
+        assert r.fill_buffer(1, 0, 1, [[5.0], [7.0]]).tolist() == [[0.0]]
+    with Renderer(hip_lib) as r:
+        r.on_add_edge(0, 0, 1, 0)
+        assert r.fill_buffer(1, 0, 2, [[5.0, 5.0], [7.0, 8.0]]).tolist() == [[7.0, 8.0]]
+
+
+def test_device_resident_entry_point(hip_lib, oracle_lib):
+    """fr_fill_buffer_device: inputs and outputs already in HBM (what bench.py times)."""
+    import torch
+    tree = synth.additive_tree(3, 128, seed=2)
+    T = 700
+    t = synth.time_ramp(0, 2 * T)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        d_t = torch.from_numpy(t).cuda()
+        d_out = torch.empty((3, T), dtype=torch.float32, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        for k in range(2):
+            row = d_t[k * T:(k + 1) * T] if k == 0 else d_t[k * T:k * T + 100]   # second call: short row, padded on device
+            hip.fill_buffer_device(d_out.data_ptr(), 3, T, k * T, row.data_ptr(), [0, row.numel()], s)
+            torch.cuda.synchronize()
+            exp = ref.fill_buffer(3, k * T, (k + 1) * T, [row.cpu().numpy()])
+            assert same_bits(d_out.cpu().numpy(), exp), first_diff(d_out.cpu().numpy(), exp)
