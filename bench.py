@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0                       # spec; 6290 measured copy
 VALU_LANE_RATE = 256 * 4 * 32 * 2.4e9       # f32 VALU lane-ops/s: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12
 FMA_PEAK_TFLOPS = 157.3                     # the same rate counted as FMA (2 flops); unusable here, see DESIGN.md
-OPS_EXECUTED_PER_PF = 7                     # VALU ops the fused kernel issues per partial-frame (6 leaf + 1 tree add)
+OPS_EXECUTED_PER_PF = 6                     # VALU ops the fused kernel issues per partial-frame: mul, fract, fma, fma, mul + 1 tree add
+ISSUE_SLOTS_PER_PF = 7                      # v_fract_f32 issues at half rate on gfx950 (measured 4.07 vs 2.2 cyc, profiles/r01_valu_rate.txt)
 OPS_GRAPH_PER_PF = 12                       # primitive nodes the reference evaluates per partial-frame (11 + Sum2)
 
 
@@ -176,9 +177,14 @@ def main():
         "traffic": None,
         "avg_launch_ms": avg_s * 1e3,
         "launches_timed": int(dom_n),
-        "flops_per_partial_frame": {"executed_by_kernel": OPS_EXECUTED_PER_PF, "primitive_nodes_in_graph": OPS_GRAPH_PER_PF},
-        "note": "f32 VALU issue bound: 256 CU x 4 SIMD-32 x 2.4 GHz lane-ops/s; parity forbids FMA contraction so "
-                "1 flop per lane-op (the 157.3 TFLOP/s FMA peak is unreachable by construction). MFMA not applicable.",
+        "issue_frac": (ISSUE_SLOTS_PER_PF * pf_per_launch / avg_s) / VALU_LANE_RATE if avg_s > 0 else 0.0,
+        "flops_per_partial_frame": {"executed_by_kernel": OPS_EXECUTED_PER_PF, "issue_slots": ISSUE_SLOTS_PER_PF,
+                                    "primitive_nodes_in_graph": OPS_GRAPH_PER_PF},
+        "note": "f32 VALU issue bound; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz lane-ops/s (the 157.3 TFLOP/s spec counts "
+                "each FMA twice). achieved = executed VALU lane-ops/s (6 per partial-frame: exact algebra folds the graph's 12 "
+                "primitive ops; 2 of the 6 are FMAs whose single rounding is proved equal to the graph's two). issue_frac "
+                "counts v_fract_f32 as 2 slots (half rate on gfx950). The chip holds ~1.9-2.3 GHz under this load, not 2.4. "
+                "MFMA not applicable: a wide reduction, no dense contraction.",
         "hbm": {"achieved": bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (bytes_per_launch / avg_s / 1e9) / HBM_PEAK_GBS if avg_s > 0 else 0.0,
                 "algorithmic_bytes_per_launch": bytes_per_launch,

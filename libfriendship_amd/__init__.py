@@ -24,6 +24,13 @@ def hip_lib():
     """The product library.  Raises FileNotFoundError if it has not been built."""
     global _hip_lib
     if _hip_lib is None:
+        # torch's ROCm wheel bundles its own libamdhip64 under the same SONAME as /opt/rocm's.  Whichever
+        # is loaded first serves the whole process, and torch cannot see the GPU through the system copy.
+        # Device buffers and streams are shared with torch (bench.py, tests), so let torch load first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _hip_lib = RendererLib(HIP_LIB_PATH)
         if _hip_lib.backend != "hip-gfx950":
             raise RuntimeError(f"{HIP_LIB_PATH} reports backend {_hip_lib.backend!r}, expected 'hip-gfx950'")

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 #include <string>
@@ -107,6 +108,8 @@ struct fr_renderer {
     DevBuf d_out, d_in_table, d_stack_node, d_stack_time, d_stack_val, d_bank_ws;
     std::vector<float> h_stage;
     bool timing = false;
+    uint32_t bank_leaf_variant = 1;
+   // see kernels.hpp BankArgs::leaf_variant; FR_BANK_LEAF env overrides (A/B runs)
     TimerClass t_bank, t_pull;
     std::vector<hipEvent_t> event_pool;
     std::string last_error;
@@ -157,7 +160,8 @@ struct fr_renderer {
     // ---- input store (reference.rs:47-75) -------------------------------------------------------
     void grow(InSlot &s, uint64_t need_floats, hipStream_t st) {
         if (need_floats <= s.cap) return;
-        uint64_t cap = std::max<uint64_t>(need_floats, std::max<uint64_t>(s.cap * 2, 4096));
+        // growth stalls the stream (alloc + copy + sync): start at 4 MiB per fed slot and double from there
+        uint64_t cap = std::max<uint64_t>(need_floats, std::max<uint64_t>(s.cap * 2, 1u << 20));
         DevBuf nb;
         nb.ensure(cap * sizeof(float));
         uint64_t stored = s.len - s.base;
@@ -167,9 +171,20 @@ struct fr_renderer {
         s.cap = cap;
     }
 
+    // A full-length device-resident row feeding a bank's time slot is not copied here: the bank kernel reads
+    // the caller's row directly and appends it to the history itself (BankArgs::hist_dst).
+    struct Deferred { uint32_t slot; const float *src; float *dst; };
+    std::vector<Deferred> deferred;
+    bool bank_time_slot(uint32_t n_slots, uint32_t slot) const {
+        if (!plan.valid || plan.version != mirror.version || plan.n_slots != n_slots) return false;
+        for (const BankStage &bs : plan.banks) if (bs.grp.input_slot == slot) return true;
+        return false;
+    }
+
     // `device_rows`: in_data is a device pointer (fr_fill_buffer_device).
     void store_inputs(uint32_t n_slots, uint64_t n_times, uint64_t idx, const float *in_data,
                       const uint64_t *offs, uint32_t n_rows, bool device_rows, hipStream_t st) {
+        deferred.clear();
         if (idx != head) {   // seek: forget history, act as if inputs were 0 before idx (renderer.rs:12-15)
             for (InSlot &s : slots) { s.base = idx; s.len = idx; }
             segs.clear();
@@ -195,7 +210,9 @@ struct fr_renderer {
             uint64_t stored = s.len - s.base;
             grow(s, stored + n_times, st);
             float *dst = s.buf.as<float>() + stored;
-            if (device_rows) {
+            if (device_rows && rl == n_times && rl > 0 && bank_time_slot(n_slots, r)) {
+                deferred.push_back(Deferred{r, in_data + offs[r], dst});
+            } else if (device_rows) {
                 if (rl) HIP_CHECK(hipMemcpyAsync(dst, in_data + offs[r], rl * sizeof(float), hipMemcpyDeviceToDevice, st));
                 if (rl < n_times) {
                     // pad with the last value now stored, or 0 (reference.rs:72-73)
@@ -306,6 +323,13 @@ struct fr_renderer {
                 a.time = nullptr;
                 a.time_valid = 0;
             }
+            for (Deferred &d : deferred)
+                if (d.slot == bs.grp.input_slot) {   // read the caller's row; the first bank on this slot appends it
+                    a.time = d.src;
+                    a.time_valid = n_times;
+                    a.hist_dst = d.dst;
+                    d.dst = nullptr;
+                }
             a.out = d_dst;
             a.rows = bs.d_rows.as<uint32_t>();
             a.n_voices = (uint32_t)bs.grp.rows.size();
@@ -313,6 +337,7 @@ struct fr_renderer {
             a.n_times = n_times;
             a.fast_ok = bs.grp.fast_ok ? 1u : 0u;
             bank_shape(a.log2_p, a.n_voices, n_times, a.chunk_log2, a.frames_per_lane);
+            a.leaf_variant = bank_leaf_variant;
             if (a.chunk_log2 != a.log2_p) {
                 d_bank_ws.ensure(((size_t)a.n_voices << (a.log2_p - a.chunk_log2)) * n_times * sizeof(float));
                 a.ws = d_bank_ws.as<float>();
@@ -425,6 +450,7 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     if (!r) return FR_ERR_OUT_OF_MEMORY;
     r->device = dev;
     r->mode = mode;
+    if (const char *lv = std::getenv("FR_BANK_LEAF")) r->bank_leaf_variant = (lv[0] == '1') ? 1u : 0u;
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {
         delete r;
         return FR_ERR_DEVICE;

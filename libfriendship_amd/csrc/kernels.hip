@@ -139,7 +139,8 @@ hipError_t launch_pull(const PullArgs &a, hipStream_t s) {
 //     -(-min(u,-u)) == |u| up to the sign of zero, which 0.5 + (-x) discards;
 //     (-16*u)*q == -16*RN(u*q) because |u*q| is 0 or >= 2^-50 (no subnormal, no overflow);
 //     amp*(-16*z) == RN((-16*amp)*z) when -16*amp is exact (host checks) -> A = -16*amp.
-// So a leaf costs 6 VALU ops (mul, fract, sub, sub|abs|, mul, mul) and the tree 1 add: 7 per partial-frame.
+// So a leaf costs 6 VALU ops (mul, fract, sub, sub|abs|, mul, mul) -- and 5 with two FMAs, see bank_leaf --
+// and the tree 1 add: 6 VALU ops per partial-frame on the common path.
 //
 // Mapping (time-major lanes): a lane owns F frames, a wave owns 64*F consecutive frames and a
 // contiguous quarter of the voice's partials, a 256-thread workgroup (4 waves) owns one
@@ -150,8 +151,17 @@ hipError_t launch_pull(const PullArgs &a, hipStream_t s) {
 // groups (wave-uniform branches), then the 4 waves' subtrees combine through LDS.
 // ---------------------------------------------------------------------------------------------------
 
-template <bool FAST>
-__device__ __forceinline__ float bank_leaf(float t, float w, float A) {
+// EXACT = false is the 5-op leaf: with u2 = 2u = RN(2r - 1) (scaling by 2 commutes with rounding) and
+// q = 0.5 - |u| always exact (r is a multiple of 2^-25 wherever |u| < 0.25, Sterbenz elsewhere),
+//     u*q = RN(u*(0.5 - |u|)) = (1/4) * RN(u2 - u2*|u2|) = (1/4) * fma(-|u2|, u2, u2)
+// so leaf = A4 * fma(-|u2|, u2, u2) with A4 = -4*amp: mul, fract, fma, fma, mul.  It differs from the
+// graph's value only in the SIGN OF A ZERO leaf (r = 0: the fma's exact cancellation is +0, the
+// graph's product u*(+0) is -0).  A zero's sign cannot change a non-zero sum, so a wave's subtree sum
+// is exact whenever it is non-zero; when it is zero the wave recomputes its subtree with EXACT = true,
+// the 6-op product form, which is bit-identical to the graph including zero signs
+// (both claims brute-forced over 1.5e8 (t, w, amp) triples; parity-tested on device).
+template <bool FAST, bool EXACT>
+__device__ __forceinline__ float bank_leaf(float t, float w, float A4) {
     float x = t * w;
     float r;
     if (FAST) {
@@ -160,10 +170,15 @@ __device__ __forceinline__ float bank_leaf(float t, float w, float A) {
         r = x - truncf(x);                // == fmodf(x, 1) for every finite x; inf -> NaN like fmodf
         r = r < 0.0f ? r + 1.0f : r;      // `if rem < 0 { rem + divisor }`
     }
-    float u = r - 0.5f;
-    float q = 0.5f - fabsf(u);
-    float z = u * q;
-    return A * z;
+    if (EXACT) {
+        float u = r - 0.5f;
+        float q = 0.5f - fabsf(u);
+        float z = u * q;
+        return (4.0f * A4) * z;           // -16*amp, exact scaling
+    }
+    float u2 = __builtin_fmaf(r, 2.0f, -1.0f);
+    float z4 = __builtin_fmaf(-fabsf(u2), u2, u2);
+    return A4 * z4;
 }
 
 typedef float __attribute__((address_space(4))) const *const_f32_ptr;   // constant addrspace -> SMEM loads
@@ -196,25 +211,26 @@ using Lvl = float (&)[F];
 #define FR_LEVELS_DECL Lvl<F> s0, Lvl<F> s1, Lvl<F> s2, Lvl<F> s3, Lvl<F> s4, Lvl<F> s5, Lvl<F> s6, Lvl<F> s7, Lvl<F> s8
 #define FR_LEVELS_PASS s0, s1, s2, s3, s4, s5, s6, s7, s8
 
-template <int F, bool FAST>
-__device__ __forceinline__ void bank_group(const ParamGroup &pg, uint32_t g, uint32_t levels,
+template <int F, bool FAST, bool EXACT>
+__device__ __forceinline__ void bank_group(const ParamGroup &pg, uint32_t g,
                                            const float (&t)[F], FR_LEVELS_DECL) {
     float v[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-        float l0 = bank_leaf<FAST>(t[f], pg.w[0], pg.A[0]);
-        float l1 = bank_leaf<FAST>(t[f], pg.w[1], pg.A[1]);
-        float l2 = bank_leaf<FAST>(t[f], pg.w[2], pg.A[2]);
-        float l3 = bank_leaf<FAST>(t[f], pg.w[3], pg.A[3]);
-        float l4 = bank_leaf<FAST>(t[f], pg.w[4], pg.A[4]);
-        float l5 = bank_leaf<FAST>(t[f], pg.w[5], pg.A[5]);
-        float l6 = bank_leaf<FAST>(t[f], pg.w[6], pg.A[6]);
-        float l7 = bank_leaf<FAST>(t[f], pg.w[7], pg.A[7]);
+        float l0 = bank_leaf<FAST, EXACT>(t[f], pg.w[0], pg.A[0]);
+        float l1 = bank_leaf<FAST, EXACT>(t[f], pg.w[1], pg.A[1]);
+        float l2 = bank_leaf<FAST, EXACT>(t[f], pg.w[2], pg.A[2]);
+        float l3 = bank_leaf<FAST, EXACT>(t[f], pg.w[3], pg.A[3]);
+        float l4 = bank_leaf<FAST, EXACT>(t[f], pg.w[4], pg.A[4]);
+        float l5 = bank_leaf<FAST, EXACT>(t[f], pg.w[5], pg.A[5]);
+        float l6 = bank_leaf<FAST, EXACT>(t[f], pg.w[6], pg.A[6]);
+        float l7 = bank_leaf<FAST, EXACT>(t[f], pg.w[7], pg.A[7]);
         v[f] = ((l0 + l1) + (l2 + l3)) + ((l4 + l5) + (l6 + l7));
     }
-    // binary-counter carry: level k holds the finished left sibling of height k (wave-uniform branches)
+    // binary-counter carry: level k holds the finished left sibling of height k (wave-uniform branches);
+    // the chain always stops at level `levels` at the latest because g < ngroups = 2^levels
 #define FR_CARRY(K, SK)                                                    \
-    if (levels == K || ((g >> K) & 1u) == 0u) {                            \
+    if (((g >> K) & 1u) == 0u) {   /* g < 2^levels: bit `levels` is 0 */    \
         static_for<0, F>([&](auto f) { SK[f] = v[f]; });                   \
         return;                                                            \
     }                                                                      \
@@ -226,7 +242,7 @@ __device__ __forceinline__ void bank_group(const ParamGroup &pg, uint32_t g, uin
     for (int f = 0; f < F; ++f) s8[f] = v[f];
 }
 
-template <int F, bool FAST>
+template <int F, bool FAST, bool EXACT>
 __device__ __forceinline__ void bank_wave_sum(const float *params, uint32_t ngroups, uint32_t levels,
                                               const float (&t)[F], float (&res)[F]) {
     float s0[F], s1[F], s2[F], s3[F], s4[F], s5[F], s6[F], s7[F], s8[F];
@@ -244,11 +260,11 @@ __device__ __forceinline__ void bank_wave_sum(const float *params, uint32_t ngro
         const bool has_b = g + 1 < ngroups;
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): pa has landed
         if (has_b) load_group(pb, p, g + 1);
-        bank_group<F, FAST>(pa, g, levels, t, FR_LEVELS_PASS);
+        bank_group<F, FAST, EXACT>(pa, g, t, FR_LEVELS_PASS);
         if (has_b) {
             __builtin_amdgcn_s_waitcnt(0xC07F);   // pb has landed
             if (g + 2 < ngroups) load_group(pa, p, g + 2);
-            bank_group<F, FAST>(pb, g + 1, levels, t, FR_LEVELS_PASS);
+            bank_group<F, FAST, EXACT>(pb, g + 1, t, FR_LEVELS_PASS);
         }
     }
     // after the last group (all ones) the carry chain stopped at level `levels`
@@ -267,7 +283,28 @@ __device__ __forceinline__ void bank_wave_sum(const float *params, uint32_t ngro
     }
 }
 
-template <int F>
+// The sign of a zero sum.  An RN sum tree yields -0 iff every leaf is -0 (x + (-x) and (+0) + (-0) are +0), so
+// when a workgroup's result holds a zero only that AND over its leaves is needed, never a recomputation.
+// The AND is order-free, so here lanes run over PARTIALS (coalesced float2 loads), unlike the hot loop.
+// Returns, for this thread's share of partials [0, n), whether all leaves at time t are exactly -0.0 in the
+// graph's arithmetic (product-form leaf, general fract: bit-identical to the graph for every input).
+__device__ __forceinline__ bool leaves_all_negzero(const float2 *params, uint32_t n, float t, uint32_t tid) {
+    bool ok = true;
+    for (uint32_t k = tid; k < n && ok; k += 256u) {
+        float2 p = params[k];
+        ok = __float_as_uint(bank_leaf<false, true>(t, p.x, p.y)) == 0x80000000u;
+    }
+    return ok;
+}
+
+// MODE 0: every leaf in the product form (always exact).
+// MODE 1: FMA-form leaves (5 ops + 1 add per partial-frame); where the workgroup's combined result is a
+//         zero, its sign is settled by leaves_all_negzero (rare: t*w integral for every partial, e.g. t = 0).
+// MODE 2: FMA-form leaves without the sign repair -- diagnostic only (tools/bank_bench.hip).
+// (Recomputing flagged tiles with the product-form loop inside the same kernel was tried first: with a second
+//  copy of the hot loop inlined, register allocation degrades and the kernel runs 1.6x slower;
+//  profiles/r01_bank_variants.txt.)
+template <int F, int MODE>
 __global__ void __launch_bounds__(256) bank_kernel(BankArgs a, uint32_t tiles, uint32_t nblocks) {
     // XCD-aware order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
     // contiguous range of (voice, chunk, tile) work: its L2 then sees 1/8 of the parameter streams.
@@ -289,32 +326,58 @@ __global__ void __launch_bounds__(256) bank_kernel(BankArgs a, uint32_t tiles, u
         uint64_t ti = t0 + (uint32_t)f * 64u + lane;
         t[f] = ti < a.time_valid ? a.time[ti] : 0.0f;
         nonneg = nonneg && (t[f] >= 0.0f) && (t[f] <= 4294967296.0f);
+        // the call's time row doubles as this slot's input history (reference.rs:70): one workgroup
+        // column appends it, which saves a separate copy kernel on the stream
+        if (a.hist_dst && vc == 0u && wave == 0u && ti < a.time_valid) a.hist_dst[ti] = t[f];
     }
     const bool fast = a.fast_ok && __all(nonneg);   // then every x = t*w is in [0, 2^64]: finite, >= 0
 
     const uint32_t Pc = 1u << a.chunk_log2;           // partials per workgroup, 32 <= Pc <= 8192
     const uint32_t Pw = Pc >> 2;                      // partials per wave
-    const float *params = (const float *)(a.params + ((size_t)voice << a.log2_p) + (size_t)chunk * Pc + (size_t)wave * Pw);
+    const float2 *cparams = a.params + ((size_t)voice << a.log2_p) + (size_t)chunk * Pc;
+    const float *params = (const float *)(cparams + (size_t)wave * Pw);
     const uint32_t ngroups = Pw >> 3;
     const uint32_t levels = a.chunk_log2 - 5u;        // log2(ngroups) <= 8
 
     float res[F];
-    if (fast) bank_wave_sum<F, true>(params, ngroups, levels, t, res);
-    else bank_wave_sum<F, false>(params, ngroups, levels, t, res);
+    constexpr bool EXACT = (MODE == 0);
+    if (fast) bank_wave_sum<F, true, EXACT>(params, ngroups, levels, t, res);
+    else bank_wave_sum<F, false, EXACT>(params, ngroups, levels, t, res);
 
     __shared__ float sm[4][F][64];
+    __shared__ unsigned long long zmask[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) sm[wave][f][lane] = res[f];
     __syncthreads();
+    // one chunk: straight to the voice's output row; else to the workspace [chunk][voice][t]
+    float *orow = (nchunks == 1u) ? a.out + (size_t)a.rows[voice] * a.n_times
+                                  : a.ws + ((size_t)chunk * a.n_voices + voice) * a.n_times;
     if (wave == 0) {
-        // one chunk: straight to the voice's output row; else to the workspace [chunk][voice][t]
-        float *orow = (nchunks == 1u) ? a.out + (size_t)a.rows[voice] * a.n_times
-                                      : a.ws + ((size_t)chunk * a.n_voices + voice) * a.n_times;
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             uint64_t ti = t0 + (uint32_t)f * 64u + lane;
             float r = (sm[0][f][lane] + sm[1][f][lane]) + (sm[2][f][lane] + sm[3][f][lane]);
-            if (ti < a.n_times) orow[ti] = r;
+            bool live = ti < a.n_times;
+            if (live) orow[ti] = r;
+            if (MODE == 1) {
+                unsigned long long m = __ballot(live && r == 0.0f);
+                if (lane == 0) zmask[f] = m;
+            }
+        }
+    }
+    if (MODE == 1) {
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            unsigned long long m = zmask[f];          // workgroup-uniform
+            while (m) {
+                uint32_t l = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                uint64_t ti = t0 + (uint32_t)f * 64u + l;
+                float tz = ti < a.time_valid ? a.time[ti] : 0.0f;
+                int all = __syncthreads_and(leaves_all_negzero(cparams, Pc, tz, threadIdx.x) ? 1 : 0);
+                if (threadIdx.x == 0) orow[ti] = all ? -0.0f : 0.0f;
+            }
         }
     }
 }
@@ -346,14 +409,21 @@ __global__ void __launch_bounds__(256) bank_combine_kernel(BankArgs a) {
     a.out[(size_t)a.rows[voice] * a.n_times + ti] = result;
 }
 
+// Workgroups launch_bank uses for this shape.
+uint64_t bank_blocks(const BankArgs &a) {
+    uint64_t f = a.frames_per_lane;
+    return ((a.n_times + 64 * f - 1) / (64 * f)) * a.n_voices << (a.log2_p - a.chunk_log2);
+}
+
 template <int F>
 static hipError_t launch_bank_f(const BankArgs &a, hipStream_t s) {
-    uint64_t tiles64 = (a.n_times + 64 * F - 1) / (64 * F);
-    uint64_t nblocks64 = tiles64 * a.n_voices << (a.log2_p - a.chunk_log2);
+    uint64_t nblocks64 = bank_blocks(a);
     if (nblocks64 == 0) return hipSuccess;
     if (nblocks64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    uint32_t tiles = (uint32_t)tiles64, nblocks = (uint32_t)nblocks64;
-    hipLaunchKernelGGL((bank_kernel<F>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
+    uint32_t tiles = (uint32_t)((a.n_times + 64 * F - 1) / (64 * F)), nblocks = (uint32_t)nblocks64;
+    if (a.leaf_variant == 0) hipLaunchKernelGGL((bank_kernel<F, 0>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
+    else if (a.leaf_variant == 1) hipLaunchKernelGGL((bank_kernel<F, 1>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
+    else hipLaunchKernelGGL((bank_kernel<F, 2>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || a.chunk_log2 == a.log2_p) return e;
     uint64_t total = (uint64_t)a.n_voices * a.n_times;
@@ -361,25 +431,28 @@ static hipError_t launch_bank_f(const BankArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Chooses how a voice's partials are split over workgroups for this call's shape: as few chunks as
-// possible (<= 8192 partials each) while still launching >= ~8 workgroups per CU.
+// Chooses how a voice's partials are split over workgroups for this call's shape.  Measured on MI355X
+// (tools/bank_bench.hip, profiles/r01_bank_variants.txt): one 64-frame tile per wave (F = 1) is never
+// slower than 2 or 4; whole voices per workgroup (<= 8192 partials) win as soon as that yields ~512
+// workgroups (2 per CU); below that, splitting partials into chunks (+ one combine pass) pays.
 void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane) {
-    const uint64_t want_blocks = 2048;
+    const uint64_t want_blocks = 512;
     chunk_log2 = log2_p < 13 ? log2_p : 13;
-    frames_per_lane = 2;
-    auto blocks = [&](uint32_t cl, uint32_t f) {
-        return ((n_times + 64 * f - 1) / (64 * f)) * n_voices << (log2_p - cl);
-    };
-    if (blocks(chunk_log2, 2) < want_blocks) frames_per_lane = 1;
-    while (chunk_log2 > 5 && blocks(chunk_log2, frames_per_lane) < want_blocks) --chunk_log2;
+    frames_per_lane = 1;
+    auto blocks = [&](uint32_t cl) { return ((n_times + 63) / 64) * n_voices << (log2_p - cl); };
+    while (chunk_log2 > 5 && blocks(chunk_log2) < want_blocks) --chunk_log2;
 }
 
 hipError_t launch_bank(const BankArgs &a, hipStream_t s) {
     if (a.log2_p < 5 || a.log2_p > 24 || a.chunk_log2 < 5 || a.chunk_log2 > 13 || a.chunk_log2 > a.log2_p)
         return hipErrorInvalidValue;
     if (a.chunk_log2 != a.log2_p && !a.ws) return hipErrorInvalidValue;
-    if (a.frames_per_lane == 2) return launch_bank_f<2>(a, s);
-    return launch_bank_f<1>(a, s);
+    switch (a.frames_per_lane) {
+    case 1: return launch_bank_f<1>(a, s);
+    case 2: return launch_bank_f<2>(a, s);
+    case 4: return launch_bank_f<4>(a, s);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -87,10 +87,10 @@ struct Matcher {
             x = ph.a;
             if (!bin_anyconst(x, OP_MUL, w, in)) break;
             if (n(in).op != OP_INPUT) break;
-            // A = -16*amp must be exact for amp*(-16*z) == A*z (kernels.hip bank notes)
-            float A = -16.0f * amp;
-            if (!std::isfinite(A) || !std::isfinite(w) || A / -16.0f != amp) break;
-            L = Leaf{w, A, n(in).a, true};
+            // the kernel multiplies by A4 = -4*amp (and 4*A4 = -16*amp): both must be exact scalings
+            float A16 = -16.0f * amp, A4 = -4.0f * amp;
+            if (!std::isfinite(A16) || !std::isfinite(w) || A16 / -16.0f != amp || A4 * 4.0f != A16) break;
+            L = Leaf{w, A4, n(in).a, true};
         } while (false);
         leaf_memo.emplace(id, L);
         return L;

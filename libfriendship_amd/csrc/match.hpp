@@ -14,7 +14,7 @@ struct BankGroup {
     uint32_t input_slot = 0;        // external input slot read as `t`
     bool fast_ok = true;            // every w in [0, 2^32]
     std::vector<uint32_t> rows;     // output row of each voice
-    std::vector<float> params;      // [rows][P]{w, -16*amp}
+    std::vector<float> params;      // [rows][P]{w, -4*amp}
 };
 
 struct MatchResult {

@@ -1,0 +1,261 @@
+// render_tests.cpp -- the reference's integration tests, written against the C++ host mirror.
+//
+// Same structure as the reference's tests/render_prim.rs, tests/ext_input.rs and tests/load_effect.rs:
+// a MyClient that forwards rendered audio, test_setup() building Dispatch::new(renderer, client), graphs
+// built by dispatching OscRouteGraph messages, one RenderRange, exact comparison with an array literal.
+// Where the reference constructs `SparkleRenderer::default()`, this constructs the renderer plugin named
+// by $FRIENDSHIP_RENDERER_LIB (the HIP engine on a GPU box; the CPU oracle in the CPU-only test run).
+//
+// Build: g++ -std=c++17 -O1 -o render_tests render_tests.cpp -ldl      Run: ./render_tests [test-name]
+#include <cstdio>
+#include <cstdlib>
+#include <deque>
+#include <functional>
+#include <iostream>
+#include <memory>
+
+#include "../../libfriendship_amd/host/friendship.hpp"
+
+using namespace friendship;
+using namespace friendship::routing;
+using friendship::dispatch::OscRenderer;
+using friendship::dispatch::OscResMan;
+using friendship::dispatch::OscRouteGraph;
+
+// `struct MyClient { tx: Sender<Array2<f32>> }`: the channel is a queue shared with the test body.
+using Channel = std::shared_ptr<std::deque<Array2>>;
+struct MyClient : Client {
+    Channel tx;
+    explicit MyClient(Channel c) : tx(std::move(c)) {}
+    void audio_rendered(Array2 buffer, uint64_t) override { tx->push_back(std::move(buffer)); }
+};
+
+using TestDispatch = Dispatch<std::unique_ptr<render::Renderer>, MyClient>;
+
+static std::pair<TestDispatch, Channel> test_setup() {
+    const char *lib = std::getenv("FRIENDSHIP_RENDERER_LIB");
+    if (!lib) throw std::runtime_error("set FRIENDSHIP_RENDERER_LIB to the renderer plugin (.so) under test");
+    Channel rx = std::make_shared<std::deque<Array2>>();
+    std::unique_ptr<render::Renderer> r = std::make_unique<render::PluginRenderer>(lib);
+    return {TestDispatch(std::move(r), MyClient(rx)), rx};
+}
+
+static Array2 recv(const Channel &rx) {
+    if (rx->empty()) throw std::runtime_error("nothing was rendered");
+    Array2 a = std::move(rx->front());
+    rx->pop_front();
+    return a;
+}
+
+static Array2 array(std::initializer_list<float> row) { return Array2{1, row.size(), std::vector<float>(row)}; }
+
+#define ASSERT_EQ_ARR(got, want)                                                                  \
+    do {                                                                                          \
+        Array2 g_ = (got), w_ = (want);                                                           \
+        if (!(g_ == w_)) {                                                                        \
+            std::cerr << __FILE__ << ":" << __LINE__ << ": assertion failed: got [";             \
+            for (float v : g_.data) std::cerr << v << " ";                                        \
+            std::cerr << "] expected [";                                                          \
+            for (float v : w_.data) std::cerr << v << " ";                                        \
+            std::cerr << "]\n";                                                                   \
+            throw std::runtime_error("assert_eq failed");                                         \
+        }                                                                                         \
+    } while (0)
+
+static EffectId prim_id(const char *name, const char *url) { return EffectId::make(name, std::nullopt, {url}); }
+static EffectId delay_id() { return prim_id("Delay", "primitive:///Delay"); }
+static EffectId sum2_id() { return prim_id("Sum2", "primitive:///Sum2"); }
+static EffectId const_id() { return prim_id("F32Constant", "primitive:///F32Constant"); }
+static EffectId mult_id() { return prim_id("Multiply", "primitive:///Multiply"); }
+static EffectId div_id() { return prim_id("Divide", "primitive:///Divide"); }
+static EffectId mod_id() { return prim_id("Modulo", "primitive:///Modulo"); }
+static EffectId min_id() { return prim_id("Minimum", "primitive:///Minimum"); }
+
+static OscRenderer::RenderRange render_range(uint64_t start, uint64_t end, uint32_t slots, Jagged2 inputs = {}) {
+    return OscRenderer::RenderRange{start, end, slots, std::move(inputs)};
+}
+
+// ---- tests/render_prim.rs ------------------------------------------------------------------------
+static void render_zeros() {
+    auto [dispatch, rx] = test_setup();
+    dispatch.dispatch(render_range(0, 4, 1));
+    ASSERT_EQ_ARR(recv(rx), array({0.f, 0.f, 0.f, 0.f}));
+}
+
+static void render_const() {
+    auto [dispatch, rx] = test_setup();
+    auto handle = NodeHandle::make(1);
+    dispatch.dispatch(OscRouteGraph::AddNode{handle, const_id()});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::new_to_null(handle, EdgeWeight::make(f32_to_bits(0.5f), 0))});
+    dispatch.dispatch(render_range(0, 4, 1));
+    ASSERT_EQ_ARR(recv(rx), array({0.5f, 0.5f, 0.5f, 0.5f}));
+}
+
+static void render_delay() {
+    auto [dispatch, rx] = test_setup();
+    auto delay_hnd = NodeHandle::make(1);
+    dispatch.dispatch(OscRouteGraph::AddNode{delay_hnd, delay_id()});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::new_to_null(delay_hnd, EdgeWeight::make(0, 0))});
+    auto const_hnd = NodeHandle::make(2);
+    dispatch.dispatch(OscRouteGraph::AddNode{const_hnd, const_id()});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(const_hnd, delay_hnd, EdgeWeight::make(f32_to_bits(0.5f), 0))});
+    const_hnd = NodeHandle::make(3);
+    dispatch.dispatch(OscRouteGraph::AddNode{const_hnd, const_id()});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(const_hnd, delay_hnd, EdgeWeight::make(f32_to_bits(2.f), 1))});
+    dispatch.dispatch(render_range(0, 4, 1));
+    ASSERT_EQ_ARR(recv(rx), array({0.f, 0.f, 0.5f, 0.5f}));
+}
+
+static void binop(EffectId id, float a, float b, float exp) {
+    auto [dispatch, rx] = test_setup();
+    auto op_hnd = NodeHandle::make(1);
+    dispatch.dispatch(OscRouteGraph::AddNode{op_hnd, id});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::new_to_null(op_hnd, EdgeWeight::make(0, 0))});
+    auto const_hnd = NodeHandle::make(2);
+    dispatch.dispatch(OscRouteGraph::AddNode{const_hnd, const_id()});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(const_hnd, op_hnd, EdgeWeight::make(f32_to_bits(a), 0))});
+    const_hnd = NodeHandle::make(3);
+    dispatch.dispatch(OscRouteGraph::AddNode{const_hnd, const_id()});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(const_hnd, op_hnd, EdgeWeight::make(f32_to_bits(b), 1))});
+    dispatch.dispatch(render_range(0, 4, 1));
+    ASSERT_EQ_ARR(recv(rx), array({exp, exp, exp, exp}));
+}
+static void render_mult() { binop(mult_id(), 0.5f, -3.f, -1.5f); }
+static void render_sum2() { binop(sum2_id(), 0.5f, -3.f, -2.5f); }
+static void render_div() { binop(div_id(), 0.5f, -3.f, 0.5f / -3.0f); }
+static void render_mod() { binop(mod_id(), -3.5f, 2.f, 0.5f); }
+static void render_min() { binop(min_id(), -3.5f, 2.f, -3.5f); }
+
+// ---- tests/ext_input.rs --------------------------------------------------------------------------
+static void ext_render_passthrough() {
+    auto [dispatch, rx] = test_setup();
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::new_to_null(NodeHandle::toplevel(), EdgeWeight::make(0, 0))});
+    Jagged2 builder;
+    builder.extend({1.f, 2.f, 3.f, 4.f});
+    dispatch.dispatch(render_range(0, 4, 1, builder));
+    ASSERT_EQ_ARR(recv(rx), array({1.f, 2.f, 3.f, 4.f}));
+    builder = Jagged2();
+    builder.extend({0.f, 1.f, 2.f});
+    dispatch.dispatch(render_range(4, 8, 1, builder));
+    ASSERT_EQ_ARR(recv(rx), array({0.f, 1.f, 2.f, 2.f}));   // empty inputs take on their last known value
+    dispatch.dispatch(render_range(0, 4, 1));
+    ASSERT_EQ_ARR(recv(rx), array({0.f, 0.f, 0.f, 0.f}));   // seeking implicitly zeros the inputs
+}
+
+static void ext_render_delay() {
+    auto [dispatch, rx] = test_setup();
+    auto delay_hnd = NodeHandle::make(1);
+    dispatch.dispatch(OscRouteGraph::AddNode{delay_hnd, delay_id()});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::new_to_null(delay_hnd, EdgeWeight::make(0, 0))});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::new_from_null(delay_hnd, EdgeWeight::make(0, 0))});
+    Jagged2 builder;
+    builder.extend({1.f, 2.f, 3.f, 4.f});
+    dispatch.dispatch(render_range(0, 4, 1, builder));
+    ASSERT_EQ_ARR(recv(rx), array({1.f, 2.f, 3.f, 4.f}));
+    auto const_hnd = NodeHandle::make(2);
+    dispatch.dispatch(OscRouteGraph::AddNode{const_hnd, const_id()});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(const_hnd, delay_hnd, EdgeWeight::make(f32_to_bits(1.f), 1))});
+    builder = Jagged2();
+    builder.extend({1.f, 2.f, 3.f, 4.f});
+    dispatch.dispatch(render_range(4, 8, 1, builder));
+    ASSERT_EQ_ARR(recv(rx), array({4.f, 1.f, 2.f, 3.f}));
+}
+
+// ---- tests/load_effect.rs ------------------------------------------------------------------------
+static EffectDesc create_multby2() {
+    auto mult_hnd = NodeHandle::make(1);
+    auto mult_data = EffectId::make("Multiply", std::nullopt, {"primitive:///Multiply"});
+    auto const_hnd = NodeHandle::make(2);
+    auto const_data = EffectId::make("Constant", std::nullopt, {"primitive:///F32Constant"});
+    AdjList list;
+    list.nodes = {{mult_hnd, mult_data}, {const_hnd, const_data}};
+    list.edges = {Edge::new_from_null(mult_hnd, EdgeWeight::make(0, 0)),                            // input -> multiply (A)
+                  Edge::new_to_null(mult_hnd, EdgeWeight::make(0, 0)),                              // multiply -> effect out
+                  Edge::make(const_hnd, mult_hnd, EdgeWeight::make(f32_to_bits(5.0f), 1))};         // const -> multiply (B)
+    auto meta = EffectMeta::make("MulBy2", {}, {EffectInput::make("source", 0)}, {EffectOutput::make("result", 0)});
+    return EffectDesc::make(meta, list);
+}
+
+static void load_multby2() {
+    auto [dispatch, rx] = test_setup();
+    // The reference writes the description to a temp dir as JSON and finds it by sha256; the on-disk
+    // loader is a later row, so the description is registered with the ResMan directly.
+    dispatch.dispatch(OscResMan::AddDir{"/nonexistent-libfriendship-test-dir"});
+    dispatch.resman().add_desc(create_multby2());
+    auto mul_hnd = NodeHandle::make(1);
+    dispatch.dispatch(OscRouteGraph::AddNode{mul_hnd, EffectId::make("MulBy2", std::nullopt, {})});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::new_to_null(mul_hnd, EdgeWeight::make(0, 0))});
+    auto const_hnd = NodeHandle::make(2);
+    dispatch.dispatch(OscRouteGraph::AddNode{const_hnd, EffectId::make("Constant", std::nullopt, {"primitive:///F32Constant"})});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(const_hnd, mul_hnd, EdgeWeight::make(f32_to_bits(0.5f), 0))});
+    dispatch.dispatch(render_range(0, 4, 1));
+    ASSERT_EQ_ARR(recv(rx), array({2.5f, 2.5f, 2.5f, 2.5f}));
+}
+
+// ---- RouteGraph validation (src/routing/routegraph.rs:165-208): host-side, no renderer compute ----
+template <class F>
+static void expect_rg_error(routegraph::ErrorKind want, F &&f) {
+    try {
+        f();
+    } catch (const dispatch::Error &e) {
+        if (e.kind == dispatch::Error::RouteGraphError && e.routegraph_kind && *e.routegraph_kind == want) return;
+        throw std::runtime_error(std::string("wrong error: ") + e.what());
+    }
+    throw std::runtime_error(std::string("expected ") + routegraph::Error::name(want));
+}
+
+static void routegraph_validation() {
+    auto [dispatch, rx] = test_setup();
+    (void)rx;
+    auto a = NodeHandle::make(1), b = NodeHandle::make(2), c = NodeHandle::make(3);
+    dispatch.dispatch(OscRouteGraph::AddNode{a, sum2_id()});
+    dispatch.dispatch(OscRouteGraph::AddNode{b, mult_id()});
+    dispatch.dispatch(OscRouteGraph::AddNode{c, const_id()});
+    expect_rg_error(routegraph::ErrorKind::NodeExists, [&] { dispatch.dispatch(OscRouteGraph::AddNode{a, sum2_id()}); });
+    expect_rg_error(routegraph::ErrorKind::NoSuchNode, [&] {
+        dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(a, NodeHandle::make(9), EdgeWeight::make(0, 0))});
+    });
+    expect_rg_error(routegraph::ErrorKind::NoSuchSlot, [&] {   // Sum2 has inputs 0 and 1 only
+        dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(c, a, EdgeWeight::make(f32_to_bits(1.f), 2))});
+    });
+    expect_rg_error(routegraph::ErrorKind::NoSuchSlot, [&] {   // Sum2 has one output
+        dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(a, b, EdgeWeight::make(1, 0))});
+    });
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(a, b, EdgeWeight::make(0, 0))});
+    expect_rg_error(routegraph::ErrorKind::SlotAlreadyConnected, [&] {
+        dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(c, b, EdgeWeight::make(f32_to_bits(1.f), 0))});
+    });
+    expect_rg_error(routegraph::ErrorKind::WouldCycle, [&] {
+        dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(b, a, EdgeWeight::make(0, 0))});
+    });
+    expect_rg_error(routegraph::ErrorKind::WouldCycle, [&] {
+        dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(b, b, EdgeWeight::make(0, 1))});
+    });
+    expect_rg_error(routegraph::ErrorKind::NodeInUse, [&] { dispatch.dispatch(OscRouteGraph::DelNode{a}); });
+    dispatch.dispatch(OscRouteGraph::DelEdge{Edge::make(a, b, EdgeWeight::make(0, 0))});
+    dispatch.dispatch(OscRouteGraph::DelNode{a});
+    dispatch.dispatch(OscRouteGraph::DelNode{a});   // already deleted: Ok(())
+}
+
+int main(int argc, char **argv) {
+    std::vector<std::pair<const char *, std::function<void()>>> tests = {
+        {"render_zeros", render_zeros}, {"render_const", render_const}, {"render_delay", render_delay},
+        {"render_mult", render_mult}, {"render_sum2", render_sum2}, {"render_div", render_div},
+        {"render_mod", render_mod}, {"render_min", render_min},
+        {"ext_render_passthrough", ext_render_passthrough}, {"ext_render_delay", ext_render_delay},
+        {"load_multby2", load_multby2}, {"routegraph_validation", routegraph_validation}};
+    int failed = 0, ran = 0;
+    for (auto &t : tests) {
+        if (argc > 1 && std::string(argv[1]) != t.first) continue;
+        ++ran;
+        try {
+            t.second();
+            std::printf("test %s ... ok\n", t.first);
+        } catch (const std::exception &e) {
+            std::printf("test %s ... FAILED: %s\n", t.first, e.what());
+            ++failed;
+        }
+    }
+    std::printf("test result: %s. %d passed; %d failed\n", failed ? "FAILED" : "ok", ran - failed, failed);
+    return failed ? 1 : 0;
+}

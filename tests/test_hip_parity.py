@@ -254,3 +254,32 @@ def test_device_resident_entry_point(hip_lib, oracle_lib):
             torch.cuda.synchronize()
             exp = ref.fill_buffer(3, k * T, (k + 1) * T, [row.cpu().numpy()])
             assert same_bits(d_out.cpu().numpy(), exp), first_diff(d_out.cpu().numpy(), exp)
+
+
+def test_device_calls_keep_input_history(hip_lib, oracle_lib):
+    """With device-resident full rows the bank kernel itself appends the time row to the slot's history;
+    a Delay on the same input must still see earlier calls' samples (tests/ext_input.rs:108-121 semantics)."""
+    import torch
+    g = synth.GraphArrays()
+    p = synth.voice_params(2, 64, seed=9)
+    leaves = synth.partial_leaves(g, p["w"], p["amp"]).reshape(2, 64)
+    roots = synth.sum_tree(g, leaves)
+    g.edge(roots, 0, 0, np.arange(2, dtype=np.uint32))
+    d = g.binop(synth.K_DELAY, synth.IN(0), synth.C(np.float32(300.0)), 1)   # out2 = time input delayed 300 frames
+    g.edge(d, 0, 0, 2)
+    tree = g.finish(3)
+    T = 256
+    t = (synth.time_ramp(0, 4 * T) * np.float32(0.5)).astype(np.float32)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        d_t = torch.from_numpy(t).cuda()
+        d_out = torch.empty((3, T), dtype=torch.float32, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        for k in range(4):
+            row = d_t[k * T:(k + 1) * T]
+            hip.fill_buffer_device(d_out.data_ptr(), 3, T, k * T, row.data_ptr(), [0, T], s)
+            torch.cuda.synchronize()
+            exp = ref.fill_buffer(3, k * T, (k + 1) * T, [t[k * T:(k + 1) * T]])
+            assert same_bits(d_out.cpu().numpy(), exp), f"call {k}: " + first_diff(d_out.cpu().numpy(), exp)
+        assert hip.plan()["banks"] and hip.plan()["pull_rows"] == 1
