@@ -153,6 +153,18 @@ def main():
     bank_ms, bank_launches = hip.get_timing("bank")
     all_ms, all_launches = hip.get_timing("all")
     plan = hip.plan()
+    hip.set_timing(False)
+
+    # the drop-in entry point (host buffers in, host buffer out: H2D of the ramp, D2H of [V,T] f32, sync per call);
+    # reported as an extra, never as `value`
+    host_rate = None
+    if rank == 0:
+        ramp = synth.time_ramp(stripe0, stripe0 + 6 * T)
+        hip.fill_buffer(V, stripe0, stripe0 + T, [ramp[:T]])
+        th = time.perf_counter()
+        for k in range(1, 6):
+            hip.fill_buffer(V, stripe0 + k * T, stripe0 + (k + 1) * T, [ramp[k * T:(k + 1) * T]])
+        host_rate = 5 * T / (time.perf_counter() - th) / 1e6
 
     if rank != 0:
         if world > 1:
@@ -202,7 +214,19 @@ def main():
                    "engine_mode": args.mode, "plan": plan},
         "partial_frames_per_s": frames_total * float(V) * P / elapsed,
         "roofline": roofline,
+        "host_buffer_api_msamples_per_s": host_rate,
     }
+    # HBM traffic per launch from PMC counters: rocprofv3 cannot wrap a process from inside it, so the figure is
+    # read from the committed summary of the separate --pmc passes of this same command (profiles/).
+    pmc_path = os.path.join(ROOT, "profiles", "r01_bank_pmc_summary.json")
+    if (V, P, T) == (64, 4096, 4800) and os.path.exists(pmc_path):
+        try:
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            roofline["traffic"] = pmc["derived"]["hbm_traffic_bytes"]
+            roofline["traffic_source"] = "profiles/r01_bank_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        except Exception:
+            pass
 
     if not args.no_cpu_baseline and world == 1:
         try:

@@ -1,0 +1,34 @@
+"""The C++ host mirror (libfriendship_amd/host/friendship.hpp) running the reference's own integration tests
+(tests/cpp/render_tests.cpp transcribes tests/render_prim.rs, tests/ext_input.rs, tests/load_effect.rs)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "render_tests.cpp")
+BIN = os.path.join(ROOT, "tests", "cpp", "_build", "render_tests")
+HDR = os.path.join(ROOT, "libfriendship_amd", "host", "friendship.hpp")
+
+
+def build():
+    if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        os.makedirs(os.path.dirname(BIN), exist_ok=True)
+        subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-o", BIN, SRC, "-ldl"], check=True)
+    return BIN
+
+
+def run(lib):
+    env = dict(os.environ, FRIENDSHIP_RENDERER_LIB=lib)
+    p = subprocess.run([build()], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "12 passed; 0 failed" in p.stdout, p.stdout
+
+
+def test_reference_tests_through_cpp_dispatch_on_oracle(oracle_lib):
+    run(oracle_lib.path)
+
+
+@pytest.mark.gpu
+def test_reference_tests_through_cpp_dispatch_on_hip(hip_lib):
+    run(hip_lib.path)
