@@ -79,6 +79,10 @@ def main():
     ap.add_argument("--partials", type=int, default=4096)
     ap.add_argument("--frames", type=int, default=4800, help="frames per fill_buffer call (T)")
     ap.add_argument("--mode", default="auto", choices=["auto", "pull"])
+    ap.add_argument("--shard", default="time", choices=["time", "voices", "partials"],
+                    help="how N > 1 ranks split the job (libfriendship_amd/shard.py): time stripes (weak scaling, no exchange; "
+                         "default), voices (strong, no exchange), partial blocks (strong, RCCL all-gather + tree-order sum)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl is RCCL on ROCm (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=48)
     args = ap.parse_args()
@@ -93,14 +97,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    # (rehearsals on a one-GPU box: several ranks may share device 0 with --backend gloo)
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     V, P, T, K, W = args.voices, args.partials, args.frames, args.steps, args.warmup
     t_build = time.perf_counter()
-    tree = synth.additive_tree(V, P)          # seeded synthetic tree, ~12 primitive nodes per partial
+    from libfriendship_amd import shard
+    shard_mode = args.shard if world > 1 else "time"
+    # seeded synthetic tree, ~12 primitive nodes per partial; under voices/partials sharding each rank
+    # holds only its sub-graph
+    tree, shard_info = shard.additive_tree_shard(V, P, rank, world, shard_mode)
+    full_tree = tree if shard_mode == "time" else None
+    V_local = tree["n_outputs"]
     hip = libfriendship_amd.HipRenderer(mode=args.mode, device=local_rank)
     synth.install(hip, tree)
     log(f"[rank {rank}] graph: {len(tree['handles'])} nodes, {len(tree['edges'])} edges, "
@@ -108,15 +123,26 @@ def main():
 
     # this rank's stripe of frames; every step's time-ramp row is already resident in HBM
     n_calls = W + K
-    stripe0 = rank * n_calls * T
+    stripe0 = rank * n_calls * T if shard_mode == "time" else 0
     assert stripe0 + n_calls * T < (1 << 24), "f32 frame ramp is exact only below 2^24 frames"
     d_time = torch.from_numpy(synth.time_ramp(stripe0, stripe0 + n_calls * T)).cuda()
-    d_out = torch.empty((V, T), dtype=torch.float32, device="cuda")
+    d_out = torch.empty((max(V_local, 1), T), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    d_mixes = [torch.empty_like(d_out) for _ in range(world)] if shard_mode == "partials" else None
 
     def step(k):
         row = d_time[k * T:(k + 1) * T]
-        hip.fill_buffer_device(d_out.data_ptr(), V, T, stripe0 + k * T, row.data_ptr(), [0, T], stream)
+        hip.fill_buffer_device(d_out.data_ptr(), V_local, T, stripe0 + k * T, row.data_ptr(), [0, T], stream)
+        if shard_mode == "partials":
+            # the one exchange step of the path: every rank's partial mix to every rank (RCCL over xGMI), then the
+            # top log2(N) levels of the voices' Sum2 trees, pairwise in the graph's own order (bit-exact)
+            if args.backend == "nccl":
+                dist.all_gather(d_mixes, d_out)
+                return shard.combine_partial_mixes(d_mixes)
+            host = [torch.empty(d_out.shape, dtype=torch.float32) for _ in range(world)]   # gloo rehearsal: via host
+            dist.all_gather(host, d_out.cpu())
+            return shard.combine_partial_mixes(host)
+        return d_out
 
     def barrier():
         if world > 1:
@@ -137,7 +163,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
@@ -160,10 +186,10 @@ def main():
     host_rate = None
     if rank == 0:
         ramp = synth.time_ramp(stripe0, stripe0 + 6 * T)
-        hip.fill_buffer(V, stripe0, stripe0 + T, [ramp[:T]])
+        hip.fill_buffer(V_local, stripe0, stripe0 + T, [ramp[:T]])
         th = time.perf_counter()
         for k in range(1, 6):
-            hip.fill_buffer(V, stripe0 + k * T, stripe0 + (k + 1) * T, [ramp[k * T:(k + 1) * T]])
+            hip.fill_buffer(V_local, stripe0 + k * T, stripe0 + (k + 1) * T, [ramp[k * T:(k + 1) * T]])
         host_rate = 5 * T / (time.perf_counter() - th) / 1e6
 
     if rank != 0:
@@ -171,13 +197,14 @@ def main():
             dist.destroy_process_group()
         return
 
-    frames_total = world * K * T
+    frames_total = (world if shard_mode == "time" else 1) * K * T
     value = frames_total / elapsed / 1e6
-    pf_per_launch = float(V) * P * T
+    k_lo, k_hi = shard_info["partials"]
+    pf_per_launch = float(V_local) * (k_hi - k_lo) * T
     dom_ms, dom_n, dom_name = (bank_ms, bank_launches, "bank_kernel") if bank_launches else (all_ms, all_launches, "pull_kernel")
     avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
     # algorithmic HBM bytes per launch, closed-form model of SURVEY.md 8d: parameters read once + ramp in + samples out
-    bytes_per_launch = V * P * 8 + 4 * T + 4 * V * T
+    bytes_per_launch = V_local * (k_hi - k_lo) * 8 + 4 * T + 4 * V_local * T
     valu_rate = OPS_EXECUTED_PER_PF * pf_per_launch / avg_s if avg_s > 0 else 0.0
     roofline = {
         "bound": "valu",
@@ -206,13 +233,17 @@ def main():
     result = {
         "metric": "Msamples/sec at 4096 partials x 64 voices; achieved HBM GB/s vs roofline",
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+        "scaling": "weak" if shard_mode == "time" else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"additive tree, {P} partials x {V} voices, 48 kHz, {T}-frame fill_buffer calls "
                                f"(BASELINE.json configs[2])", "voices": V, "partials": P, "frames_per_call": T,
-                   "sharding": "time stripes, one per GPU, no collective" if world > 1 else "single GPU",
+                   "sharding": {"time": "time stripes, one per GPU, no collective",
+                                "voices": "voices split over GPUs, no collective",
+                                "partials": "partial blocks of every voice split over GPUs; RCCL all-gather of [V,T] partial "
+                                            "mixes + tree-order f32 sum"}[shard_mode] if world > 1 else "single GPU",
                    "engine_mode": args.mode, "plan": plan},
-        "partial_frames_per_s": frames_total * float(V) * P / elapsed,
+        "partial_frames_per_s": K * T * float(V) * P * (world if shard_mode == "time" else 1) / elapsed,
         "roofline": roofline,
         "host_buffer_api_msamples_per_s": host_rate,
     }
@@ -230,12 +261,12 @@ def main():
 
     if not args.no_cpu_baseline and world == 1:
         try:
-            one, many, cpu_out = cpu_baseline(tree, V, P, args.cpu_frames, 4 * args.cpu_frames)
+            one, many, cpu_out = cpu_baseline(full_tree, V, P, args.cpu_frames, 4 * args.cpu_frames)
             result["cpu_baseline"] = one
             result["cpu_baseline_all_cores"] = many
             # parity of the bench's own output against the CPU path on the sampled frames (stripe 0 only)
             chk = libfriendship_amd.HipRenderer(mode=args.mode, device=local_rank)
-            synth.install(chk, tree)
+            synth.install(chk, full_tree)
             got = chk.fill_buffer(V, 0, args.cpu_frames, [synth.time_ramp(0, args.cpu_frames)])
             result["parity"] = {"frames_checked": args.cpu_frames, "voices": V,
                                 "bit_exact": bool(np.array_equal(got.view(np.uint32), cpu_out.view(np.uint32)))}
