@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--shard", default="time", choices=["time", "voices", "partials"],
                     help="how N > 1 ranks split the job (libfriendship_amd/shard.py): time stripes (weak scaling, no exchange; "
                          "default), voices (strong, no exchange), partial blocks (strong, RCCL all-gather + tree-order sum)")
+    ap.add_argument("--tree", default="additive", choices=["additive", "effects"],
+                    help="additive = BASELINE configs[2] shape (the headline); effects = configs[3] shape (detune + ADSR + "
+                         "4-tap delay chain), a diagnostic run: use with --voices 128 --partials 1024 --no-cpu-baseline")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl is RCCL on ROCm (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=48)
@@ -113,7 +116,11 @@ def main():
     shard_mode = args.shard if world > 1 else "time"
     # seeded synthetic tree, ~12 primitive nodes per partial; under voices/partials sharding each rank
     # holds only its sub-graph
-    tree, shard_info = shard.additive_tree_shard(V, P, rank, world, shard_mode)
+    if args.tree == "effects":
+        assert world == 1, "the effects tree is a single-GPU diagnostic"
+        tree, shard_info = synth.effects_tree(V, P), {"partials": (0, P), "voices": (0, V), "mode": "time"}
+    else:
+        tree, shard_info = shard.additive_tree_shard(V, P, rank, world, shard_mode)
     full_tree = tree if shard_mode == "time" else None
     V_local = tree["n_outputs"]
     hip = libfriendship_amd.HipRenderer(mode=args.mode, device=local_rank)
@@ -236,8 +243,10 @@ def main():
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
         "scaling": "weak" if shard_mode == "time" else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"additive tree, {P} partials x {V} voices, 48 kHz, {T}-frame fill_buffer calls "
-                               f"(BASELINE.json configs[2])", "voices": V, "partials": P, "frames_per_call": T,
+        "config": {"workload": (f"additive tree, {P} partials x {V} voices, 48 kHz, {T}-frame fill_buffer calls "
+                                f"(BASELINE.json configs[2])" if args.tree == "additive" else
+                                f"harmonics + detune + ADSR + 4-tap delay chain, {P} partials x {V} voices (BASELINE.json configs[3] shape)"),
+                   "voices": V, "partials": P, "frames_per_call": T,
                    "sharding": {"time": "time stripes, one per GPU, no collective",
                                 "voices": "voices split over GPUs, no collective",
                                 "partials": "partial blocks of every voice split over GPUs; RCCL all-gather of [V,T] partial "

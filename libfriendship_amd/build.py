@@ -12,8 +12,8 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 OUT = os.path.join(PKG_DIR, "libfriendship_hip.so")
-SOURCES = ["engine.cpp", "graph.cpp", "match.cpp", "kernels.hip"]
-HEADERS = ["graph.hpp", "kernels.hpp", "match.hpp", os.path.join("..", "..", "include", "friendship_render.h")]
+SOURCES = ["engine.cpp", "graph.cpp", "match.cpp", "stage.cpp", "kernels.hip"]
+HEADERS = ["graph.hpp", "kernels.hpp", "match.hpp", "stage.hpp", os.path.join("..", "..", "include", "friendship_render.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-slp-vectorize", "-mllvm", "-simplifycfg-sink-common=false", "-Wall", "-Wextra"]
 

@@ -18,6 +18,7 @@
 #include "graph.hpp"
 #include "kernels.hpp"
 #include "match.hpp"
+#include "stage.hpp"
 
 namespace fr {
 
@@ -67,7 +68,7 @@ struct InSlot {
 };
 
 struct BankStage {
-    BankGroup grp;           // rows/params kept on the host for the plan description
+    BankLaunch grp;          // rows/params kept on the host for the plan description
     DevBuf d_params, d_rows;
 };
 
@@ -77,6 +78,10 @@ struct Plan {
     uint32_t n_slots = 0;
     FlatGraph fg;
     std::vector<BankStage> banks;
+    StagedPlan sp;                       // programs / levels / rings (banks moved into `banks`)
+    DevBuf d_instrs, d_progs;
+    bool stage_valid = false;            // rings hold [stage_end - lmax, stage_end) of the current graph + history
+    uint64_t stage_end = 0;
     std::vector<uint32_t> pull_rows;     // output rows evaluated by the pull interpreter
     DevBuf d_nodes, d_roots;             // pull: nodes (input slots remapped dense), roots per pull row
     std::vector<uint32_t> input_slots;   // dense input index -> external slot
@@ -110,14 +115,16 @@ struct fr_renderer {
     bool timing = false;
     uint32_t bank_leaf_variant = 1;
    // see kernels.hpp BankArgs::leaf_variant; FR_BANK_LEAF env overrides (A/B runs)
-    TimerClass t_bank, t_pull;
+    TimerClass t_bank, t_pull, t_stage;
+    DevBuf d_rings, d_in_table_stage;
+    uint64_t ring_cap = 0;               // floats per ring (power of two)
     std::vector<hipEvent_t> event_pool;
     std::string last_error;
     std::string plan_json_cache;
 
     ~fr_renderer() {
         (void)hipSetDevice(device);
-        for (TimerClass *tc : {&t_bank, &t_pull})
+        for (TimerClass *tc : {&t_bank, &t_pull, &t_stage})
             for (auto &pr : tc->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -177,6 +184,7 @@ struct fr_renderer {
     std::vector<Deferred> deferred;
     bool bank_time_slot(uint32_t n_slots, uint32_t slot) const {
         if (!plan.valid || plan.version != mirror.version || plan.n_slots != n_slots) return false;
+        if (plan.sp.uses_rings() || !plan.sp.progs.empty()) return false;   // windows with look-back read the stored history
         for (const BankStage &bs : plan.banks) if (bs.grp.input_slot == slot) return true;
         return false;
     }
@@ -254,13 +262,8 @@ struct fr_renderer {
         p.version = mirror.version;
         p.n_slots = n_slots;
         p.fg = lower(mirror, n_slots);
-        MatchResult mr;
-        if (mode == FR_MODE_AUTO) {
-            mr = match_banks(p.fg, 20);
-        } else {
-            for (uint32_t r = 0; r < n_slots; ++r) mr.other_rows.push_back(r);
-        }
-        for (BankGroup &bg : mr.banks) {
+        p.sp = plan_stages(p.fg, mode == FR_MODE_AUTO, mode != FR_MODE_PULL, 20);
+        for (BankLaunch &bg : p.sp.banks) {
             BankStage bs;
             bs.grp = std::move(bg);
             bs.d_params.ensure(bs.grp.params.size() * sizeof(float));
@@ -269,7 +272,14 @@ struct fr_renderer {
             HIP_CHECK(hipMemcpyAsync(bs.d_rows.p, bs.grp.rows.data(), bs.grp.rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             p.banks.push_back(std::move(bs));
         }
-        p.pull_rows = std::move(mr.other_rows);
+        p.sp.banks.clear();
+        if (!p.sp.progs.empty()) {
+            p.d_instrs.ensure(p.sp.instrs.size() * sizeof(StageInstr));
+            p.d_progs.ensure(p.sp.progs.size() * sizeof(StageProg));
+            HIP_CHECK(hipMemcpyAsync(p.d_instrs.p, p.sp.instrs.data(), p.sp.instrs.size() * sizeof(StageInstr), hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(p.d_progs.p, p.sp.progs.data(), p.sp.progs.size() * sizeof(StageProg), hipMemcpyHostToDevice, st));
+        }
+        p.pull_rows = p.sp.pull_rows;
         if (!p.pull_rows.empty()) {
             // dense input table: OP_INPUT.a becomes an index into input_slots
             std::vector<DevNode> dn(p.fg.nodes.size());
@@ -296,12 +306,16 @@ struct fr_renderer {
         js << "{\"backend\":\"hip-gfx950\",\"mode\":" << mode << ",\"n_slots\":" << n_slots
            << ",\"lowered_nodes\":" << p.fg.nodes.size() << ",\"max_depth\":" << p.fg.max_depth << ",\"banks\":[";
         for (size_t i = 0; i < p.banks.size(); ++i) {
-            const BankGroup &g = p.banks[i].grp;
+            const BankLaunch &g = p.banks[i].grp;
             js << (i ? "," : "") << "{\"voices\":" << g.rows.size() << ",\"partials\":" << (1u << g.log2_p)
                << ",\"input_slot\":" << g.input_slot << ",\"fast_ok\":" << (g.fast_ok ? "true" : "false")
+               << ",\"to_ring\":" << (g.to_ring ? "true" : "false")
                << ",\"param_bytes\":" << g.params.size() * sizeof(float) << "}";
         }
-        js << "],\"pull_rows\":" << p.pull_rows.size() << "}";
+        js << "],\"stage_programs\":" << p.sp.progs.size() << ",\"stage_instrs\":" << p.sp.instrs.size()
+           << ",\"stage_levels\":" << (p.sp.level_first.empty() ? 0 : p.sp.level_first.size() - 1)
+           << ",\"rings\":" << p.sp.n_rings << ",\"max_lookback\":" << p.sp.lmax
+           << ",\"pull_rows\":" << p.pull_rows.size() << "}";
         p.json = js.str();
         p.valid = true;
         plan = std::move(p);
@@ -311,40 +325,107 @@ struct fr_renderer {
     void execute(float *d_dst, uint32_t n_slots, uint64_t n_times, uint64_t idx, hipStream_t st) {
         if (!plan.valid || plan.version != mirror.version || plan.n_slots != n_slots) build_plan(n_slots, st);
         if (n_slots == 0 || n_times == 0) return;
+        const StagedPlan &sp = plan.sp;
+
+        // Window of the staged part.  Contiguous with what the rings already hold: just this call's frames.
+        // Otherwise (first call, seek, graph edit, larger call): rebuild the look-back from the input history.
+        uint64_t w0 = idx;
+        if (sp.uses_rings()) {
+            uint64_t need = sp.lmax + n_times;
+            uint64_t cap = 1024;
+            while (cap < need) cap <<= 1;
+            if (cap > ring_cap) {
+                d_rings.ensure((size_t)sp.n_rings * cap * sizeof(float));
+                ring_cap = cap;
+                plan.stage_valid = false;
+            } else if ((size_t)sp.n_rings * ring_cap * sizeof(float) > d_rings.bytes) {
+                d_rings.ensure((size_t)sp.n_rings * ring_cap * sizeof(float));
+                plan.stage_valid = false;
+            }
+            if (!(plan.stage_valid && plan.stage_end == idx)) w0 = idx > sp.lmax ? idx - sp.lmax : 0;
+        }
+        const uint64_t w_len = idx + n_times - w0;
+
         for (BankStage &bs : plan.banks) {
+            const bool ring = bs.grp.to_ring;
+            const uint64_t b0 = ring ? w0 : idx, blen = ring ? w_len : n_times;
             BankArgs a{};
             a.params = bs.d_params.as<float2>();
+            // time-slot history for window [b0, b0 + blen): zero before the stored history (seek), zero beyond it
             DevInput di = dev_input(bs.grp.input_slot);
-            // frames [idx, idx+n_times) of the time row: idx >= base always holds after store_inputs
-            if (di.data && di.len > idx && idx >= di.base) {
-                a.time = di.data + (idx - di.base);
-                a.time_valid = std::min<uint64_t>(n_times, di.len - idx);
-            } else {
-                a.time = nullptr;
-                a.time_valid = 0;
+            if (di.data && di.len > di.base) {
+                uint64_t start = std::max(b0, di.base);
+                a.time_skip = std::min(start - b0, blen);
+                a.time = di.data + (start - di.base);
+                a.time_valid = di.len > start ? di.len - start : 0;
             }
-            for (Deferred &d : deferred)
-                if (d.slot == bs.grp.input_slot) {   // read the caller's row; the first bank on this slot appends it
-                    a.time = d.src;
-                    a.time_valid = n_times;
-                    a.hist_dst = d.dst;
-                    d.dst = nullptr;
-                }
-            a.out = d_dst;
+            if (!ring)
+                for (Deferred &d : deferred)
+                    if (d.slot == bs.grp.input_slot) {   // read the caller's row; the first bank on this slot appends it
+                        a.time = d.src;
+                        a.time_skip = 0;
+                        a.time_valid = n_times;
+                        a.hist_dst = d.dst;
+                        d.dst = nullptr;
+                    }
             a.rows = bs.d_rows.as<uint32_t>();
+            if (ring) {
+                a.out = d_rings.as<float>();
+                a.out_stride = ring_cap;
+                a.ring_mask = ring_cap - 1;
+                a.ring_t0 = b0;
+            } else {
+                a.out = d_dst;
+                a.out_stride = n_times;
+            }
             a.n_voices = (uint32_t)bs.grp.rows.size();
             a.log2_p = bs.grp.log2_p;
-            a.n_times = n_times;
+            a.n_times = blen;
             a.fast_ok = bs.grp.fast_ok ? 1u : 0u;
-            bank_shape(a.log2_p, a.n_voices, n_times, a.chunk_log2, a.frames_per_lane);
+            bank_shape(a.log2_p, a.n_voices, blen, a.chunk_log2, a.frames_per_lane);
             a.leaf_variant = bank_leaf_variant;
             if (a.chunk_log2 != a.log2_p) {
-                d_bank_ws.ensure(((size_t)a.n_voices << (a.log2_p - a.chunk_log2)) * n_times * sizeof(float));
+                d_bank_ws.ensure(((size_t)a.n_voices << (a.log2_p - a.chunk_log2)) * blen * sizeof(float));
                 a.ws = d_bank_ws.as<float>();
             }
             Scope sc(this, &t_bank, st);
             HIP_CHECK(launch_bank(a, st));
             sc.done();
+        }
+
+        if (!sp.progs.empty()) {
+            std::vector<DevInput> tab(sp.input_slots.size());
+            for (size_t i = 0; i < tab.size(); ++i) tab[i] = dev_input(sp.input_slots[i]);
+            d_in_table_stage.ensure(std::max<size_t>(tab.size(), 1) * sizeof(DevInput));
+            if (!tab.empty()) {
+                HIP_CHECK(hipMemcpyAsync(d_in_table_stage.p, tab.data(), tab.size() * sizeof(DevInput), hipMemcpyHostToDevice, st));
+                HIP_CHECK(hipStreamSynchronize(st));   // `tab` is a stack object
+            }
+            for (size_t l = 0; l + 1 < sp.level_first.size(); ++l) {
+                uint32_t first = sp.level_first[l], count = sp.level_first[l + 1] - first;
+                for (uint32_t off = 0; off < count; off += 65535u) {   // grid.y limit
+                    StageArgs a{};
+                    a.instrs = plan.d_instrs.as<StageInstr>();
+                    a.progs = plan.d_progs.as<StageProg>() + first + off;
+                    a.n_progs = std::min<uint32_t>(count - off, 65535u);
+                    a.rings = d_rings.as<float>();
+                    a.ring_mask = ring_cap ? ring_cap - 1 : 0;
+                    a.inputs = d_in_table_stage.as<DevInput>();
+                    a.n_inputs = (uint32_t)tab.size();
+                    a.out = d_dst;
+                    a.n_times = n_times;
+                    a.idx = idx;
+                    a.w0 = w0;
+                    a.w_len = w_len;
+                    Scope sc(this, &t_stage, st);
+                    HIP_CHECK(launch_stage(a, st));
+                    sc.done();
+                }
+            }
+        }
+        if (sp.uses_rings()) {
+            plan.stage_valid = true;
+            plan.stage_end = idx + n_times;
         }
         if (!plan.pull_rows.empty()) run_pull(d_dst, n_slots, n_times, idx, st);
     }
@@ -562,11 +643,13 @@ fr_status fr_get_timing(fr_renderer *r, const char *kernel_class, double *ms, ui
         HIP_CHECK(hipSetDevice(r->device));
         r->resolve(r->t_bank);
         r->resolve(r->t_pull);
+        r->resolve(r->t_stage);
         std::string k(kernel_class);
         double m = 0;
         uint64_t n = 0;
         if (k == "bank" || k == "all") { m += r->t_bank.ms; n += r->t_bank.launches; }
         if (k == "pull" || k == "all") { m += r->t_pull.ms; n += r->t_pull.launches; }
+        if (k == "stage" || k == "all") { m += r->t_stage.ms; n += r->t_stage.launches; }
         if (k != "bank" && k != "pull" && k != "all" && k != "stage") throw Error(FR_ERR_INVALID_ARG, "unknown kernel class " + k);
         if (ms) *ms = m;
         if (launches) *launches = n;
@@ -578,8 +661,9 @@ fr_status fr_reset_timing(fr_renderer *r) {
         HIP_CHECK(hipSetDevice(r->device));
         r->resolve(r->t_bank);
         r->resolve(r->t_pull);
-        r->t_bank.ms = r->t_pull.ms = 0;
-        r->t_bank.launches = r->t_pull.launches = 0;
+        r->resolve(r->t_stage);
+        r->t_bank.ms = r->t_pull.ms = r->t_stage.ms = 0;
+        r->t_bank.launches = r->t_pull.launches = r->t_stage.launches = 0;
     });
 }
 

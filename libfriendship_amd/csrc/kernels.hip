@@ -297,6 +297,13 @@ __device__ __forceinline__ bool leaves_all_negzero(const float2 *params, uint32_
     return ok;
 }
 
+__device__ __forceinline__ float bank_time(const BankArgs &a, uint64_t ti) {
+    return (ti >= a.time_skip && ti - a.time_skip < a.time_valid) ? a.time[ti - a.time_skip] : 0.0f;
+}
+__device__ __forceinline__ uint64_t bank_out_index(const BankArgs &a, uint64_t ti) {
+    return a.ring_mask ? ((a.ring_t0 + ti) & a.ring_mask) : ti;
+}
+
 // MODE 0: every leaf in the product form (always exact).
 // MODE 1: FMA-form leaves (5 ops + 1 add per partial-frame); where the workgroup's combined result is a
 //         zero, its sign is settled by leaves_all_negzero (rare: t*w integral for every partial, e.g. t = 0).
@@ -324,10 +331,10 @@ __global__ void __launch_bounds__(256) bank_kernel(BankArgs a, uint32_t tiles, u
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         uint64_t ti = t0 + (uint32_t)f * 64u + lane;
-        t[f] = ti < a.time_valid ? a.time[ti] : 0.0f;
+        t[f] = bank_time(a, ti);
         nonneg = nonneg && (t[f] >= 0.0f) && (t[f] <= 4294967296.0f);
         // the call's time row doubles as this slot's input history (reference.rs:70): one workgroup
-        // column appends it, which saves a separate copy kernel on the stream
+        // column appends it, which saves a separate copy kernel on the stream (only with time_skip == 0)
         if (a.hist_dst && vc == 0u && wave == 0u && ti < a.time_valid) a.hist_dst[ti] = t[f];
     }
     const bool fast = a.fast_ok && __all(nonneg);   // then every x = t*w is in [0, 2^64]: finite, >= 0
@@ -350,15 +357,16 @@ __global__ void __launch_bounds__(256) bank_kernel(BankArgs a, uint32_t tiles, u
     for (int f = 0; f < F; ++f) sm[wave][f][lane] = res[f];
     __syncthreads();
     // one chunk: straight to the voice's output row; else to the workspace [chunk][voice][t]
-    float *orow = (nchunks == 1u) ? a.out + (size_t)a.rows[voice] * a.n_times
-                                  : a.ws + ((size_t)chunk * a.n_voices + voice) * a.n_times;
+    const bool direct = nchunks == 1u;
+    float *orow = direct ? a.out + (size_t)a.rows[voice] * a.out_stride
+                         : a.ws + ((size_t)chunk * a.n_voices + voice) * a.n_times;
     if (wave == 0) {
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             uint64_t ti = t0 + (uint32_t)f * 64u + lane;
             float r = (sm[0][f][lane] + sm[1][f][lane]) + (sm[2][f][lane] + sm[3][f][lane]);
             bool live = ti < a.n_times;
-            if (live) orow[ti] = r;
+            if (live) orow[direct ? bank_out_index(a, ti) : ti] = r;
             if (MODE == 1) {
                 unsigned long long m = __ballot(live && r == 0.0f);
                 if (lane == 0) zmask[f] = m;
@@ -374,9 +382,9 @@ __global__ void __launch_bounds__(256) bank_kernel(BankArgs a, uint32_t tiles, u
                 uint32_t l = (uint32_t)__builtin_ctzll(m);
                 m &= m - 1;
                 uint64_t ti = t0 + (uint32_t)f * 64u + l;
-                float tz = ti < a.time_valid ? a.time[ti] : 0.0f;
+                float tz = bank_time(a, ti);
                 int all = __syncthreads_and(leaves_all_negzero(cparams, Pc, tz, threadIdx.x) ? 1 : 0);
-                if (threadIdx.x == 0) orow[ti] = all ? -0.0f : 0.0f;
+                if (threadIdx.x == 0) orow[direct ? bank_out_index(a, ti) : ti] = all ? -0.0f : 0.0f;
             }
         }
     }
@@ -406,7 +414,7 @@ __global__ void __launch_bounds__(256) bank_combine_kernel(BankArgs a) {
             v = s[k] + v;
         }
     }
-    a.out[(size_t)a.rows[voice] * a.n_times + ti] = result;
+    a.out[(size_t)a.rows[voice] * a.out_stride + bank_out_index(a, ti)] = result;
 }
 
 // Workgroups launch_bank uses for this shape.
@@ -453,6 +461,50 @@ hipError_t launch_bank(const BankArgs &a, hipStream_t s) {
     case 4: return launch_bank_f<4>(a, s);
     default: return hipErrorInvalidValue;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Staged evaluator: one thread per (program, frame).  Temporaries live in LDS as [register][thread] columns
+// (conflict-free, no barriers: a thread only touches its own column).  Ring reads are the materialised
+// form of the reference's "re-evaluate the source at t - d" (reference.rs:213-215): the ring holds exactly the
+// values that re-evaluation would produce, because it was filled by the same graph from the same input history.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
+    __shared__ float tmp[STAGE_REGS][256];
+    const uint64_t wi = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (wi >= a.w_len) return;
+    const uint64_t t = a.w0 + wi;
+    const StageProg pg = a.progs[blockIdx.y];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = 0; i < pg.n_instr; ++i) {
+        const StageInstr in = a.instrs[pg.first_instr + i];
+        float v;
+        switch (in.op) {
+        case S_CONST: v = __uint_as_float(in.imm); break;
+        case S_INPUT: v = read_input(a.inputs, a.n_inputs, in.imm, t); break;
+        case S_READ: v = t >= in.d_lo ? a.rings[(size_t)in.buf * (a.ring_mask + 1) + ((t - in.d_lo) & a.ring_mask)] : 0.0f; break;
+        case S_READ_INPUT: v = t >= in.d_lo ? read_input(a.inputs, a.n_inputs, in.imm, t - in.d_lo) : 0.0f; break;
+        case S_STEP: v = t >= in.d_lo ? __uint_as_float(in.imm) : 0.0f; break;
+        case S_SUM2: v = tmp[in.a][tid] + tmp[in.b][tid]; break;
+        case S_MUL: v = tmp[in.a][tid] * tmp[in.b][tid]; break;
+        case S_DIV: v = tmp[in.a][tid] / tmp[in.b][tid]; break;
+        case S_MOD: v = prim_mod(tmp[in.a][tid], tmp[in.b][tid]); break;
+        default: v = prim_min(tmp[in.a][tid], tmp[in.b][tid]); break;
+        }
+        tmp[in.dst][tid] = v;
+    }
+    const float r = tmp[pg.result_reg][tid];
+    if (pg.dst_ring != 0xFFFFFFFFu) a.rings[(size_t)pg.dst_ring * (a.ring_mask + 1) + (t & a.ring_mask)] = r;
+    if (pg.out_row >= 0 && t >= a.idx) a.out[(size_t)pg.out_row * a.n_times + (t - a.idx)] = r;
+}
+
+hipError_t launch_stage(const StageArgs &a, hipStream_t s) {
+    if (a.n_progs == 0 || a.w_len == 0) return hipSuccess;
+    if (a.n_progs > 65535u) return hipErrorInvalidValue;
+    uint64_t bx = (a.w_len + 255) / 256;
+    if (bx > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(stage_kernel, dim3((uint32_t)bx, a.n_progs), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -41,13 +41,20 @@ hipError_t launch_pull(const PullArgs &a, hipStream_t s);
 // amp * parabolic_sine(Modulo(time[t] * w, 1)).
 struct BankArgs {
     const float2 *params;      // [n_voices][P] {w, -4*amp}
-    const float *time;         // the time-carrying input row, already offset to frame idx (may be null)
-    uint64_t time_valid;       // frames of `time` that are stored; beyond -> 0
-    float *out;                // [n_voices rows of out], row stride n_times
-    const uint32_t *rows;      // [n_voices] output row of each voice
+    // Window frame ti (0 <= ti < n_times) reads the time-carrying input as
+    //   ti < time_skip ? 0 : (ti - time_skip < time_valid ? time[ti - time_skip] : 0)
+    const float *time;         // stored history of the time slot, starting at window frame time_skip (may be null)
+    uint64_t time_skip;        // leading window frames that precede the stored history (zero after a seek)
+    uint64_t time_valid;       // stored frames available from `time`; beyond -> 0
+    // Voice v writes window frame ti to out[rows[v] * out_stride + (ring_mask ? (ring_t0 + ti) & ring_mask : ti)]
+    float *out;
+    const uint32_t *rows;      // [n_voices] destination row of each voice
+    uint64_t out_stride;       // floats between destination rows
+    uint64_t ring_mask;        // 0: rows are linear windows; else rows are rings of ring_mask + 1 floats
+    uint64_t ring_t0;          // absolute frame of window frame 0 (ring addressing)
     uint32_t n_voices;
     uint32_t log2_p;           // P = 1 << log2_p
-    uint64_t n_times;
+    uint64_t n_times;          // window length in frames
     uint32_t fast_ok;          // every w in [0, 2^32]: the non-negative fast path may be used
     uint32_t chunk_log2;       // partials per workgroup = 1 << chunk_log2 (5..13, <= log2_p); from bank_shape
     uint32_t frames_per_lane;  // 1, 2 or 4; from bank_shape
@@ -58,6 +65,47 @@ struct BankArgs {
 void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane);
 uint64_t bank_blocks(const BankArgs &a);
 hipError_t launch_bank(const BankArgs &a, hipStream_t s);
+
+// ---- staged evaluator -------------------------------------------------------------------------------
+// A cut node (a value some Delay reads back in time, or an output) is computed per frame by a small
+// register program over: constants, inputs at t, and ring reads of other cut nodes at t - d.
+enum StageOp : uint8_t {
+    S_CONST = 0,       // dst = bits(imm)
+    S_INPUT = 1,       // dst = input[imm] at t
+    S_READ = 2,        // dst = t >= d ? ring[buf][(t - d) & mask] : 0          d = {lo, hi}
+    S_READ_INPUT = 3,  // dst = t >= d ? input[imm] at t - d : 0
+    S_STEP = 4,        // dst = t >= d ? bits(imm) : 0                           Delay of a constant
+    S_SUM2 = 5, S_MUL = 6, S_DIV = 7, S_MOD = 8, S_MIN = 9,   // dst = a op b
+};
+struct StageInstr {    // 16 bytes
+    uint8_t op, dst, a, b;
+    uint32_t imm;
+    uint32_t buf;      // ring index (S_READ)
+    uint32_t d_lo;     // delay frames, low 32 bits (delays >= 2^32 frames are not staged)
+};
+struct StageProg {
+    uint32_t first_instr, n_instr;
+    uint32_t result_reg;
+    uint32_t dst_ring;     // ring to store into, or 0xFFFFFFFF
+    int32_t out_row;       // output row to store into (frames >= idx), or -1
+    uint32_t pad[3];
+};
+constexpr int STAGE_REGS = 48;
+struct StageArgs {
+    const StageInstr *instrs;
+    const StageProg *progs;    // programs of this level
+    uint32_t n_progs;
+    float *rings;              // [n_rings][ring_mask + 1]
+    uint64_t ring_mask;
+    const DevInput *inputs;
+    uint32_t n_inputs;
+    float *out;                // [n_slots, n_times] of the call
+    uint64_t n_times;
+    uint64_t idx;              // first frame of the call
+    uint64_t w0;               // first frame of the window computed now (<= idx)
+    uint64_t w_len;            // window length
+};
+hipError_t launch_stage(const StageArgs &a, hipStream_t s);
 
 // Fills dst[0..n) with *src_last (or 0 when src_last is null): last-value padding of a short input
 // row (reference.rs:72-73) for the device-resident entry point.

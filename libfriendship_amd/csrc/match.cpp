@@ -117,41 +117,38 @@ struct Matcher {
 
 }  // namespace
 
-MatchResult match_banks(const FlatGraph &g, uint32_t max_log2_p) {
-    MatchResult R;
-    Matcher M(g);
-    std::unordered_map<uint64_t, size_t> group_of;   // (log2_p, slot) -> index in R.banks
-    for (uint32_t row = 0; row < g.outputs.size(); ++row) {
-        uint32_t root = g.outputs[row];
-        // height = number of Sum2 nodes on the leftmost path
-        uint32_t h = 0, cur = root;
-        while (g.nodes[cur].op == OP_SUM2 && h <= max_log2_p) { cur = g.nodes[cur].a; ++h; }
-        bool matched = false;
-        if (h >= 5 && h <= max_log2_p) {
-            std::vector<float> params;
-            params.reserve((size_t)2 << h);
-            uint32_t slot = 0;
-            bool first = true, fast_ok = true;
-            if (M.collect(root, h, params, slot, first, fast_ok)) {
-                uint64_t key = ((uint64_t)h << 32) | slot;
-                auto it = group_of.find(key);
-                if (it == group_of.end()) {
-                    it = group_of.emplace(key, R.banks.size()).first;
-                    BankGroup bg;
-                    bg.log2_p = h;
-                    bg.input_slot = slot;
-                    R.banks.push_back(std::move(bg));
-                }
-                BankGroup &bg = R.banks[it->second];
-                bg.rows.push_back(row);
-                bg.params.insert(bg.params.end(), params.begin(), params.end());
-                bg.fast_ok = bg.fast_ok && fast_ok;
-                matched = true;
-            }
-        }
-        if (!matched) R.other_rows.push_back(row);
+struct BankMatcher::Impl : Matcher {
+    using Matcher::Matcher;
+};
+
+BankMatcher::BankMatcher(const FlatGraph &g, uint32_t max_log2_p) : impl_(new Impl(g)), g_(g), max_log2_p_(max_log2_p) {}
+BankMatcher::~BankMatcher() { delete impl_; }
+
+bool BankMatcher::try_voice(uint32_t root, VoiceMatch &out) {
+    auto it = memo_.find(root);
+    if (it != memo_.end()) {
+        if (it->second < 0) return false;
+        out = found_[(size_t)it->second];
+        return true;
     }
-    return R;
+    // height = number of Sum2 nodes on the leftmost path
+    uint32_t h = 0, cur = root;
+    while (g_.nodes[cur].op == OP_SUM2 && h <= max_log2_p_) { cur = g_.nodes[cur].a; ++h; }
+    if (h >= 5 && h <= max_log2_p_) {
+        VoiceMatch vm;
+        vm.log2_p = h;
+        vm.params.reserve((size_t)2 << h);
+        bool first = true;
+        vm.fast_ok = true;
+        if (impl_->collect(root, h, vm.params, vm.input_slot, first, vm.fast_ok)) {
+            memo_.emplace(root, (int64_t)found_.size());
+            found_.push_back(vm);
+            out = found_.back();
+            return true;
+        }
+    }
+    memo_.emplace(root, -1);
+    return false;
 }
 
 }  // namespace fr

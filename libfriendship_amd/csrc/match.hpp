@@ -2,26 +2,37 @@
 #pragma once
 
 #include <cstdint>
+#include <unordered_map>
 #include <vector>
 
 #include "graph.hpp"
 
 namespace fr {
 
-// Voices (output rows) that share a partial count and a time-carrying input slot: one fused launch.
-struct BankGroup {
-    uint32_t log2_p = 0;            // partials per voice = 1 << log2_p
+// One recognised voice: a complete balanced Sum2 tree over 2^log2_p partial leaves.
+struct VoiceMatch {
+    uint32_t log2_p = 0;
     uint32_t input_slot = 0;        // external input slot read as `t`
     bool fast_ok = true;            // every w in [0, 2^32]
-    std::vector<uint32_t> rows;     // output row of each voice
-    std::vector<float> params;      // [rows][P]{w, -4*amp}
+    std::vector<float> params;      // [P]{w, -4*amp}
 };
 
-struct MatchResult {
-    std::vector<BankGroup> banks;
-    std::vector<uint32_t> other_rows;   // output rows no fused kernel covers
-};
+class BankMatcher {
+public:
+    BankMatcher(const FlatGraph &g, uint32_t max_log2_p);
+    ~BankMatcher();
+    BankMatcher(const BankMatcher &) = delete;
+    BankMatcher &operator=(const BankMatcher &) = delete;
+    // Is the expression rooted at `root` a voice?  Results (including failures) are memoised per node.
+    bool try_voice(uint32_t root, VoiceMatch &out);
 
-MatchResult match_banks(const FlatGraph &g, uint32_t max_log2_p);
+private:
+    struct Impl;
+    Impl *impl_;
+    const FlatGraph &g_;
+    uint32_t max_log2_p_;
+    std::unordered_map<uint32_t, int64_t> memo_;
+    std::vector<VoiceMatch> found_;
+};
 
 }  // namespace fr

@@ -1,0 +1,336 @@
+// stage.cpp -- plans the staged (materialised) evaluation of a lowered graph.
+//
+// The reference implements Delay by re-evaluating the whole upstream sub-graph at t - d
+// (reference src/render/reference.rs:197-216), so K chained delays cost 2^K upstream evaluations.  On the
+// GPU the upstream value is materialised once per frame instead: every node some constant Delay reads back
+// in time becomes a *cut node* with a ring buffer in HBM, computed level by level per call; rings persist
+// across contiguous calls (that is the delay line) and are recomputed from the input history after a seek
+// or a graph edit -- exactly the reference's "recompute from input history with the current graph".
+// This is equivalent only because the evaluator is a pure function of (graph, input history, t).
+//
+// Not staged (left to the pull interpreter, which handles everything): signal-dependent delay amounts,
+// delays of 2^31 frames or more, programs that outgrow the register/instruction budget.
+#include "stage.hpp"
+
+#include <algorithm>
+#include <memory>
+#include <unordered_map>
+#include <unordered_set>
+
+namespace fr {
+namespace {
+
+constexpr uint32_t NO_RING = 0xFFFFFFFFu;
+constexpr size_t MAX_PROG_INSTR = 4096;
+
+struct Planner {
+    const FlatGraph &g;
+    BankMatcher *matcher;   // null: no fused banks
+    std::unordered_map<uint32_t, int8_t> supported_memo;
+    std::unordered_map<uint32_t, VoiceMatch> bank_of;     // node -> voice
+    std::unordered_set<uint32_t> cut;                     // program cut nodes (non-bank)
+    std::unordered_set<uint32_t> visited;
+
+    Planner(const FlatGraph &fg, BankMatcher *m) : g(fg), matcher(m) {}
+
+    static bool delay_frames_ok(const FlatGraph &g, const FlatNode &n, uint64_t &frames) {
+        if (!g.is_const(n.b)) return false;
+        float d = g.const_val(n.b);
+        if (!(d >= 1.0f) || d >= 2147483648.0f) return false;   // 0 / negative / NaN / >= 2^64 were folded at lowering
+        frames = (uint64_t)d;
+        return true;
+    }
+
+    // iterative post-order "is everything under n stageable"
+    bool supported(uint32_t root) {
+        std::vector<uint32_t> st{root};
+        while (!st.empty()) {
+            uint32_t n = st.back();
+            if (supported_memo.count(n)) { st.pop_back(); continue; }
+            const FlatNode &x = g.nodes[n];
+            if (x.op == OP_CONST || x.op == OP_INPUT) { supported_memo[n] = 1; st.pop_back(); continue; }
+            uint64_t fr_;
+            if (x.op == OP_DELAY && !delay_frames_ok(g, x, fr_)) { supported_memo[n] = 0; st.pop_back(); continue; }
+            bool need_a = !supported_memo.count(x.a);
+            bool need_b = x.op != OP_DELAY && !supported_memo.count(x.b);
+            if (need_a) st.push_back(x.a);
+            if (need_b) st.push_back(x.b);
+            if (need_a || need_b) continue;
+            supported_memo[n] = supported_memo[x.a] && (x.op == OP_DELAY || supported_memo[x.b]);
+            st.pop_back();
+        }
+        return supported_memo[root] != 0;
+    }
+
+    bool is_leaf(uint32_t n) const { return g.nodes[n].op == OP_CONST || g.nodes[n].op == OP_INPUT; }
+
+    // marks banks and cut nodes under a root
+    void explore(uint32_t root) {
+        std::vector<uint32_t> st{root};
+        while (!st.empty()) {
+            uint32_t n = st.back();
+            st.pop_back();
+            if (is_leaf(n) || !visited.insert(n).second) continue;
+            const FlatNode &x = g.nodes[n];
+            if (matcher && x.op == OP_SUM2) {
+                VoiceMatch vm;
+                if (matcher->try_voice(n, vm)) { bank_of.emplace(n, std::move(vm)); continue; }
+            }
+            if (x.op == OP_DELAY) {
+                if (!is_leaf(x.a)) cut.insert(x.a);
+                st.push_back(x.a);
+            } else {
+                st.push_back(x.a);
+                st.push_back(x.b);
+            }
+        }
+    }
+};
+
+struct ProgBuild {
+    std::vector<StageInstr> instrs;   // `buf` holds the cut NODE id until rings are assigned
+    uint32_t result_reg = 0;
+    std::vector<std::pair<uint32_t, uint64_t>> reads;   // (cut node, delay)
+};
+
+// Emits the program computing cut node `m`.  Returns false if it does not fit the budgets.
+bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unordered_map<uint32_t, uint32_t> &dense_input,
+                   std::vector<uint32_t> &input_slots, ProgBuild &out) {
+    auto is_boundary = [&](uint32_t n) { return n != m && (P.cut.count(n) || P.bank_of.count(n)); };
+    // post-order over the expression DAG inside this stage
+    std::vector<uint32_t> order;
+    std::unordered_map<uint32_t, uint32_t> uses;
+    {
+        std::unordered_set<uint32_t> seen;
+        std::vector<std::pair<uint32_t, int>> st{{m, 0}};
+        while (!st.empty()) {
+            auto [n, state] = st.back();
+            st.pop_back();
+            if (state == 1) { order.push_back(n); continue; }
+            if (!seen.insert(n).second) continue;
+            st.push_back({n, 1});
+            const FlatNode &x = g.nodes[n];
+            if (is_boundary(n) || x.op == OP_CONST || x.op == OP_INPUT || x.op == OP_DELAY) continue;   // leaves of the program
+            ++uses[x.a];
+            ++uses[x.b];
+            st.push_back({x.b, 0});
+            st.push_back({x.a, 0});
+        }
+    }
+    std::vector<uint8_t> free_regs;
+    for (int r = STAGE_REGS - 1; r >= 0; --r) free_regs.push_back((uint8_t)r);
+    std::unordered_map<uint32_t, uint8_t> reg_of;
+    auto dense = [&](uint32_t slot) {
+        auto it = dense_input.emplace(slot, (uint32_t)input_slots.size());
+        if (it.second) input_slots.push_back(slot);
+        return it.first->second;
+    };
+    for (uint32_t n : order) {
+        if (out.instrs.size() >= MAX_PROG_INSTR || free_regs.empty()) return false;
+        const FlatNode &x = g.nodes[n];
+        StageInstr in{};
+        if (is_boundary(n)) {
+            in.op = S_READ; in.buf = n; in.d_lo = 0;
+            out.reads.push_back({n, 0});
+        } else if (x.op == OP_CONST) {
+            in.op = S_CONST; in.imm = x.a;
+        } else if (x.op == OP_INPUT) {
+            in.op = S_INPUT; in.imm = dense(x.a);
+        } else if (x.op == OP_DELAY) {
+            uint64_t d;
+            Planner::delay_frames_ok(g, x, d);
+            const FlatNode &src = g.nodes[x.a];
+            in.d_lo = (uint32_t)d;
+            if (src.op == OP_CONST) { in.op = S_STEP; in.imm = src.a; }
+            else if (src.op == OP_INPUT) { in.op = S_READ_INPUT; in.imm = dense(src.a); }
+            else { in.op = S_READ; in.buf = x.a; out.reads.push_back({x.a, d}); }
+        } else {
+            switch (x.op) {
+            case OP_SUM2: in.op = S_SUM2; break;
+            case OP_MUL: in.op = S_MUL; break;
+            case OP_DIV: in.op = S_DIV; break;
+            case OP_MOD: in.op = S_MOD; break;
+            default: in.op = S_MIN; break;
+            }
+            in.a = reg_of.at(x.a);
+            in.b = reg_of.at(x.b);
+            // operands die after their last use inside this program
+            if (--uses[x.a] == 0) free_regs.push_back(reg_of.at(x.a));
+            if (--uses[x.b] == 0) free_regs.push_back(reg_of.at(x.b));   // x.a == x.b: counted twice, freed once
+        }
+        in.dst = free_regs.back();
+        free_regs.pop_back();
+        reg_of[n] = in.dst;
+        out.instrs.push_back(in);
+    }
+    out.result_reg = reg_of.at(m);
+    return true;
+}
+
+}  // namespace
+
+StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p) {
+    StagedPlan sp;
+    const uint32_t n_rows = (uint32_t)g.outputs.size();
+    std::unique_ptr<BankMatcher> matcher;
+    if (allow_banks) matcher.reset(new BankMatcher(g, max_log2_p));
+    Planner P(g, matcher.get());
+
+    std::vector<uint32_t> staged_rows;
+    for (uint32_t row = 0; row < n_rows; ++row) {
+        uint32_t root = g.outputs[row];
+        VoiceMatch vm;
+        bool root_is_bank = matcher && g.nodes[root].op == OP_SUM2 && matcher->try_voice(root, vm);
+        if (root_is_bank || (allow_programs && P.supported(root))) staged_rows.push_back(row);
+        else sp.pull_rows.push_back(row);
+    }
+    for (uint32_t row : staged_rows) P.explore(g.outputs[row]);
+    for (auto &kv : P.bank_of) P.cut.erase(kv.first);   // a Delay's source that is a voice is computed by the bank kernel
+
+    // output rows per root
+    std::unordered_map<uint32_t, std::vector<uint32_t>> rows_of;
+    for (uint32_t row : staged_rows) rows_of[g.outputs[row]].push_back(row);
+    for (auto &kv : rows_of)
+        if (!P.bank_of.count(kv.first)) P.cut.insert(kv.first);   // a root that is a leaf gets a trivial program too
+
+    // programs (cut node ids ascending == topological)
+    std::vector<uint32_t> cuts(P.cut.begin(), P.cut.end());
+    std::sort(cuts.begin(), cuts.end());
+    std::unordered_map<uint32_t, uint32_t> dense_input;
+    std::unordered_map<uint32_t, ProgBuild> built;
+    bool ok = true;
+    for (uint32_t m : cuts) {
+        ProgBuild pb;
+        if (!allow_programs || !build_program(g, P, m, dense_input, sp.input_slots, pb)) { ok = false; break; }
+        built.emplace(m, std::move(pb));
+    }
+    if (!ok) {
+        // budget exceeded somewhere: keep only rows whose root is itself a bank (direct launches), pull the rest
+        StagedPlan fb;
+        fb.pull_rows = sp.pull_rows;
+        std::unordered_map<uint64_t, size_t> grp;
+        for (uint32_t row : staged_rows) {
+            auto it = P.bank_of.find(g.outputs[row]);
+            if (it == P.bank_of.end()) { fb.pull_rows.push_back(row); continue; }
+            const VoiceMatch &vm = it->second;
+            uint64_t key = ((uint64_t)vm.log2_p << 32) | vm.input_slot;
+            auto gi = grp.find(key);
+            if (gi == grp.end()) {
+                gi = grp.emplace(key, fb.banks.size()).first;
+                BankLaunch bl;
+                bl.log2_p = vm.log2_p; bl.input_slot = vm.input_slot; bl.to_ring = false;
+                fb.banks.push_back(std::move(bl));
+            }
+            BankLaunch &bl = fb.banks[gi->second];
+            bl.rows.push_back(row);
+            bl.params.insert(bl.params.end(), vm.params.begin(), vm.params.end());
+            bl.fast_ok = bl.fast_ok && vm.fast_ok;
+        }
+        std::sort(fb.pull_rows.begin(), fb.pull_rows.end());
+        return fb;
+    }
+
+    // who needs a ring: anything read by a program, or feeding more than one output row
+    std::unordered_set<uint32_t> needs_ring;
+    for (auto &kv : built)
+        for (auto &rd : kv.second.reads) needs_ring.insert(rd.first);
+    for (auto &kv : rows_of)
+        if (kv.second.size() > 1) needs_ring.insert(kv.first);
+
+    // look-back and levels, consumers before producers (descending node id)
+    std::unordered_map<uint32_t, uint64_t> L;
+    std::unordered_map<uint32_t, uint32_t> level;
+    for (auto it = cuts.rbegin(); it != cuts.rend(); ++it) {
+        uint64_t lm = L[*it];
+        for (auto &rd : built[*it].reads) L[rd.first] = std::max(L[rd.first], lm + rd.second);
+    }
+    for (uint32_t m : cuts) {   // ascending: producers first
+        uint32_t lv = 1;
+        for (auto &rd : built[m].reads) lv = std::max(lv, (P.bank_of.count(rd.first) ? 0u : level[rd.first]) + 1);
+        level[m] = lv;
+    }
+
+    // rings
+    std::unordered_map<uint32_t, uint32_t> ring_of;
+    std::vector<uint32_t> ring_nodes(needs_ring.begin(), needs_ring.end());
+    std::sort(ring_nodes.begin(), ring_nodes.end());
+    for (uint32_t n : ring_nodes) {
+        ring_of[n] = sp.n_rings++;
+        sp.lmax = std::max(sp.lmax, L[n]);
+    }
+
+    // bank launches: voices that go straight to one output row, and voices that fill rings
+    {
+        std::unordered_map<uint64_t, size_t> grp;
+        std::vector<uint32_t> bank_nodes;
+        for (auto &kv : P.bank_of) bank_nodes.push_back(kv.first);
+        std::sort(bank_nodes.begin(), bank_nodes.end());
+        for (uint32_t n : bank_nodes) {
+            const VoiceMatch &vm = P.bank_of[n];
+            bool ring = needs_ring.count(n) != 0;
+            auto ro = rows_of.find(n);
+            if (!ring && ro == rows_of.end()) continue;   // unreachable
+            uint64_t key = ((uint64_t)vm.log2_p << 33) | ((uint64_t)vm.input_slot << 1) | (ring ? 1u : 0u);
+            auto gi = grp.find(key);
+            if (gi == grp.end()) {
+                gi = grp.emplace(key, sp.banks.size()).first;
+                BankLaunch bl;
+                bl.log2_p = vm.log2_p; bl.input_slot = vm.input_slot; bl.to_ring = ring;
+                sp.banks.push_back(std::move(bl));
+            }
+            BankLaunch &bl = sp.banks[gi->second];
+            bl.rows.push_back(ring ? ring_of[n] : ro->second[0]);
+            bl.params.insert(bl.params.end(), vm.params.begin(), vm.params.end());
+            bl.fast_ok = bl.fast_ok && vm.fast_ok;
+        }
+    }
+
+    // programs, ordered by level
+    struct Pending { uint32_t level; uint32_t node; ProgBuild *pb; uint32_t dst_ring; int32_t out_row; };
+    std::vector<Pending> pend;
+    std::vector<ProgBuild> extra;   // trivial copies ring -> additional output rows
+    extra.reserve(n_rows);
+    uint32_t max_level = 0;
+    for (uint32_t m : cuts) {
+        auto ro = rows_of.find(m);
+        int32_t row0 = ro != rows_of.end() ? (int32_t)ro->second[0] : -1;
+        pend.push_back({level[m], m, &built[m], needs_ring.count(m) ? ring_of[m] : NO_RING, row0});
+        max_level = std::max(max_level, level[m]);
+    }
+    for (auto &kv : rows_of) {
+        bool bank = P.bank_of.count(kv.first) != 0;
+        size_t first_extra = (bank && !needs_ring.count(kv.first)) ? kv.second.size() : (bank ? 0 : 1);
+        for (size_t i = first_extra; i < kv.second.size(); ++i) {
+            ProgBuild pb;
+            StageInstr in{};
+            in.op = S_READ; in.buf = kv.first; in.dst = 0;
+            pb.instrs.push_back(in);
+            pb.result_reg = 0;
+            extra.push_back(std::move(pb));
+            uint32_t lv = (bank ? 0u : level[kv.first]) + 1;
+            pend.push_back({lv, kv.first, &extra.back(), NO_RING, (int32_t)kv.second[i]});
+            max_level = std::max(max_level, lv);
+        }
+    }
+    std::stable_sort(pend.begin(), pend.end(), [](const Pending &a, const Pending &b) { return a.level < b.level; });
+    sp.level_first.assign((size_t)max_level + 2, 0);
+    for (const Pending &pd : pend) {
+        StageProg pg{};
+        pg.first_instr = (uint32_t)sp.instrs.size();
+        pg.n_instr = (uint32_t)pd.pb->instrs.size();
+        pg.result_reg = pd.pb->result_reg;
+        pg.dst_ring = pd.dst_ring;
+        pg.out_row = pd.out_row;
+        for (StageInstr in : pd.pb->instrs) {
+            if (in.op == S_READ) in.buf = ring_of.at(in.buf);
+            sp.instrs.push_back(in);
+        }
+        sp.progs.push_back(pg);
+        ++sp.level_first[pd.level + 1];
+    }
+    for (size_t l = 1; l < sp.level_first.size(); ++l) sp.level_first[l] += sp.level_first[l - 1];
+    std::sort(sp.pull_rows.begin(), sp.pull_rows.end());
+    return sp;
+}
+
+}  // namespace fr

@@ -1,0 +1,39 @@
+// stage.hpp -- plan of the staged (materialised) evaluation: fused banks + per-cut-node register programs.
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#include "graph.hpp"
+#include "kernels.hpp"
+#include "match.hpp"
+
+namespace fr {
+
+// Voices rendered by one bank launch.
+struct BankLaunch {
+    uint32_t log2_p = 0;
+    uint32_t input_slot = 0;
+    bool fast_ok = true;
+    bool to_ring = false;            // rows are ring indices (window with look-back) instead of output rows
+    std::vector<uint32_t> rows;      // destination row per voice
+    std::vector<float> params;       // [voices][P]{w, -4*amp}
+};
+
+struct StagedPlan {
+    std::vector<BankLaunch> banks;
+    std::vector<StageInstr> instrs;
+    std::vector<StageProg> progs;          // ordered by level
+    std::vector<uint32_t> level_first;     // level l = progs[level_first[l] .. level_first[l+1])
+    uint32_t n_rings = 0;
+    uint64_t lmax = 0;                     // deepest look-back any ring must serve
+    std::vector<uint32_t> input_slots;     // dense input index used by programs -> external slot
+    std::vector<uint32_t> pull_rows;       // output rows left to the pull interpreter
+    bool uses_rings() const { return n_rings != 0; }
+};
+
+// allow_banks: recognise fused oscillator banks; allow_programs: stage everything else that qualifies.
+StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p);
+
+}  // namespace fr

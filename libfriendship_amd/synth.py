@@ -163,6 +163,53 @@ def additive_tree(n_voices, n_partials, seed=0x5EED0002, detune=False, sr=48000.
     return t
 
 
+def adsr_envelope(g, attack=480.0, decay=2400.0, sustain=0.6, release=4800.0, t_end=48000.0, time_slot=0):
+    """N5: piecewise-linear ADSR from Minimum/Sum2/Multiply/Divide of t, with
+    max(a, b) = -Minimum(-a, -b) (the identity noted at reference src/routing/effect.rs:106-111):
+      a = t/A;  d = max(S, 1 - (1-S)*(t-A)/D);  r = S*(T_end - t)/R;  env = max(0, min(min(a, d), r)).
+    One node each (about 17 nodes in all); returns the handle of env."""
+    f = np.float32
+    t = IN(time_slot)
+    a = g.binop(K_DIV, t, C(f(attack)), 1)
+    ta = g.binop(K_SUM2, t, C(f(-attack)), 1)
+    fr = g.binop(K_DIV, ta, C(f(decay)), 1)
+    dd = g.binop(K_MUL, C(f(1.0) - f(sustain)), fr, 1)
+    d0 = g.binop(K_SUM2, C(f(1.0)), g.binop(K_MUL, C(f(-1.0)), dd, 1), 1)
+    d = g.binop(K_MUL, C(f(-1.0)), g.binop(K_MIN, C(f(-sustain)), g.binop(K_MUL, C(f(-1.0)), d0, 1), 1), 1)
+    rem = g.binop(K_SUM2, C(f(t_end)), g.binop(K_MUL, C(f(-1.0)), t, 1), 1)
+    r = g.binop(K_MUL, C(f(sustain)), g.binop(K_DIV, rem, C(f(release)), 1), 1)
+    m2 = g.binop(K_MIN, g.binop(K_MIN, a, d, 1), r, 1)
+    return g.binop(K_MUL, C(f(-1.0)), g.binop(K_MIN, C(f(0.0)), g.binop(K_MUL, C(f(-1.0)), m2, 1), 1), 1)
+
+
+def delay_chain(g, x, taps=4, base_delay=2400.0):
+    """N6: `taps` feed-forward taps in series, y = Sum2(x, Multiply(C(g_j), Delay(x, C(d_j)))),
+    d_j = base_delay*(j+1) frames, g_j = 0.5^(j+1).  x: handle array; returns the handles after the last tap."""
+    x = np.asarray(x, dtype=np.uint32).ravel()
+    for j in range(taps):
+        dl = g.binop(K_DELAY, x, C(np.float32(base_delay * (j + 1))), len(x))
+        x = g.binop(K_SUM2, x, g.binop(K_MUL, C(np.float32(0.5 ** (j + 1))), dl, len(x)), len(x))
+    return x
+
+
+def effects_tree(n_voices, n_partials, seed=0x5EED0003, detune=True, envelope=True, taps=4, base_delay=2400.0,
+                 sr=48000.0, time_slot=0):
+    """config D: harmonics + per-partial detune + ADSR envelope + delay chain, one output slot per voice."""
+    p = voice_params(n_voices, n_partials, seed, detune, sr)
+    g = GraphArrays()
+    leaves = partial_leaves(g, p["w"], p["amp"], time_slot).reshape(n_voices, n_partials)
+    x = sum_tree(g, leaves)
+    if envelope:
+        env = adsr_envelope(g, time_slot=time_slot)
+        x = g.binop(K_MUL, np.broadcast_to(env, x.shape), x, len(x))
+    if taps:
+        x = delay_chain(g, x, taps, base_delay)
+    g.edge(x, 0, 0, np.arange(n_voices, dtype=np.uint32))
+    t = g.finish(n_voices)
+    t["params"] = p
+    return t
+
+
 _PRIM_EFFECTS = None
 
 

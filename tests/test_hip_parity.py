@@ -144,7 +144,8 @@ def test_bank_unusual_time_inputs(hip_lib, oracle_lib):
 
 
 def test_bank_negative_frequency_and_mixed_outputs(hip_lib, oracle_lib):
-    """A voice with negative w (general path), plus an output that is not a bank (pull) next to banks."""
+    """A voice with negative w (general fract path), next to outputs that are not banks: the bank delayed by 5
+    frames (staged: the bank fills a ring, two small programs read it) and the time input itself."""
     g = synth.GraphArrays()
     w = np.linspace(-0.01, 0.02, 64).astype(np.float32)
     amp = np.linspace(1.0, 0.1, 64).astype(np.float32)
@@ -162,7 +163,8 @@ def test_bank_negative_frequency_and_mixed_outputs(hip_lib, oracle_lib):
         got, exp = hip.fill_buffer(3, 0, 300, [t]), ref.fill_buffer(3, 0, 300, [t])
         assert same_bits(got, exp), first_diff(got, exp)
         plan = hip.plan()
-        assert len(plan["banks"]) == 1 and plan["pull_rows"] == 2 and not plan["banks"][0]["fast_ok"]
+        assert len(plan["banks"]) == 1 and not plan["banks"][0]["fast_ok"] and plan["banks"][0]["to_ring"], plan
+        assert plan["pull_rows"] == 0 and plan["rings"] == 1 and plan["stage_programs"] == 3, plan
 
 
 def test_chunked_calls_equal_one_call(hip_lib):
@@ -282,4 +284,126 @@ def test_device_calls_keep_input_history(hip_lib, oracle_lib):
             torch.cuda.synchronize()
             exp = ref.fill_buffer(3, k * T, (k + 1) * T, [t[k * T:(k + 1) * T]])
             assert same_bits(d_out.cpu().numpy(), exp), f"call {k}: " + first_diff(d_out.cpu().numpy(), exp)
-        assert hip.plan()["banks"] and hip.plan()["pull_rows"] == 1
+        assert hip.plan()["banks"] and hip.plan()["pull_rows"] == 0 and hip.plan()["stage_programs"] == 1
+
+
+# ---- staged evaluator: envelope + delay chains (N5, N6) ------------------------------------------------------------
+def _effects_sequence(hip, ref, V, T, calls, seek_to=None):
+    """Contiguous calls, then a seek, on both renderers; returns nothing, asserts bit equality."""
+    for k in range(calls):
+        t = synth.time_ramp(k * T, (k + 1) * T)
+        got, exp = hip.fill_buffer(V, k * T, (k + 1) * T, [t]), ref.fill_buffer(V, k * T, (k + 1) * T, [t])
+        assert same_bits(got, exp), f"call {k}: " + first_diff(got, exp)
+    if seek_to is not None:
+        t = synth.time_ramp(seek_to, seek_to + T)
+        got, exp = hip.fill_buffer(V, seek_to, seek_to + T, [t]), ref.fill_buffer(V, seek_to, seek_to + T, [t])
+        assert same_bits(got, exp), "after seek: " + first_diff(got, exp)
+
+
+@pytest.mark.parametrize("V,P,taps,delay,T", [(3, 64, 3, 50.0, 128), (2, 32, 4, 7.0, 33), (1, 128, 2, 300.0, 100), (4, 32, 1, 1.0, 64)])
+def test_effects_chain_staged(hip_lib, oracle_lib, V, P, taps, delay, T):
+    """config D's shape at sizes the oracle can render in full: bank -> envelope -> K delay taps."""
+    tree = synth.effects_tree(V, P, taps=taps, base_delay=delay)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        _effects_sequence(hip, ref, V, T, calls=5, seek_to=10 * T + 3)
+        plan = hip.plan()
+        assert plan["pull_rows"] == 0 and plan["stage_programs"] >= V * (taps + 1) and plan["rings"] >= V * taps, plan
+        assert plan["banks"] and plan["banks"][0]["to_ring"] is False or plan["rings"] > 0
+
+
+def test_staged_matches_pull_on_larger_chain(hip_lib):
+    """Same graph through the staged evaluator and the pull interpreter, on device (the oracle would take minutes)."""
+    tree = synth.effects_tree(8, 256, taps=4, base_delay=100.0)
+    T = 700
+    with Renderer(hip_lib, mode="auto") as a, Renderer(hip_lib, mode="pull") as b:
+        synth.install(a, tree)
+        synth.install(b, tree)
+        for k in range(3):
+            t = synth.time_ramp(k * T, (k + 1) * T)
+            x, y = a.fill_buffer(8, k * T, (k + 1) * T, [t]), b.fill_buffer(8, k * T, (k + 1) * T, [t])
+            assert same_bits(x, y), f"call {k}: " + first_diff(x, y)
+        assert a.plan()["stage_programs"] > 0 and b.plan()["stage_programs"] == 0
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_graphs_staged_mode(hip_lib, oracle_lib, seed):
+    """Random graphs with constant delays only, forced through the staged evaluator (no fused banks)."""
+    rng = np.random.default_rng(5000 + seed)
+    steps, n_out = randgraph.random_graph(100 + seed, n_nodes=int(rng.integers(4, 40)), n_inputs=2, n_outputs=3,
+                                          signal_delays=False)
+    T = 80
+    with Renderer(hip_lib, mode="staged") as hip, Renderer(oracle_lib) as ref:
+        randgraph.install_steps(hip, steps)
+        randgraph.install_steps(ref, steps)
+        noise = lambda n: (rng.normal(size=n) * 3).astype(np.float32)
+        for k, (start, rows) in enumerate([(0, [synth.time_ramp(0, T), noise(T)]),
+                                           (T, [synth.time_ramp(T, 2 * T), noise(17)]),
+                                           (2 * T, [synth.time_ramp(2 * T, 3 * T), noise(T)]),
+                                           (9000, [synth.time_ramp(9000, 9000 + T), noise(T)])]):
+            try:
+                exp = ref.fill_buffer(n_out, start, start + T, rows)
+            except RenderError as e:
+                with pytest.raises(RenderError) as ei:
+                    hip.fill_buffer(n_out, start, start + T, rows)
+                assert ei.value.status == e.status
+                return
+            got = hip.fill_buffer(n_out, start, start + T, rows)
+            assert same_bits(got, exp), f"seed {seed} call {k}: " + first_diff(got, exp)
+
+
+def test_graph_edit_rebuilds_delay_state(hip_lib, oracle_lib):
+    """Edits between calls apply to ALL times evaluated afterwards, look-back included: the rings
+    are rebuilt from the input history with the new graph."""
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        for r in (hip, ref):
+            r.on_add_node(1, "F32Constant")
+            r.on_add_node(2, "Multiply")    # x = in0 * 2
+            r.on_add_node(3, "Delay")       # d = Delay(x, 5)
+            r.on_add_node(4, "Sum2")        # out = x + d
+            r.on_add_edge(0, 2, 0, 0)
+            r.on_add_edge(1, 2, f32_bits(2.0), 1)
+            r.on_add_edge(2, 3, 0, 0)
+            r.on_add_edge(1, 3, f32_bits(5.0), 1)
+            r.on_add_edge(2, 4, 0, 0)
+            r.on_add_edge(3, 4, 0, 1)
+            r.on_add_edge(4, 0, 0, 0)
+        rng = np.random.default_rng(3)
+        rows = [rng.normal(size=32).astype(np.float32) for _ in range(4)]
+        for k in range(2):
+            assert same_bits(hip.fill_buffer(1, 32 * k, 32 * (k + 1), [rows[k]]), ref.fill_buffer(1, 32 * k, 32 * (k + 1), [rows[k]]))
+        for r in (hip, ref):   # change the gain: history before the edit must now be seen through gain 3
+            r.on_del_edge(1, 2, f32_bits(2.0), 1)
+            r.on_add_edge(1, 2, f32_bits(3.0), 1)
+        for k in range(2, 4):
+            got, exp = hip.fill_buffer(1, 32 * k, 32 * (k + 1), [rows[k]]), ref.fill_buffer(1, 32 * k, 32 * (k + 1), [rows[k]])
+            assert same_bits(got, exp), first_diff(got, exp)
+        assert hip.plan()["rings"] == 1
+
+
+def test_config_d_full_size_sampled_against_oracle(hip_lib, oracle_lib):
+    """BASELINE config D (1024 partials x 128 voices, detune + ADSR + 4-tap delay chain reaching back 24000
+    frames).  The oracle cannot render it in full (the pull model costs 2^4 upstream evaluations per sample), so:
+    both sides first take in 28800 frames of input with NO outputs connected (cheap), then the output edges are
+    added (a graph edit: the engine must rebuild its delay state from the input history) and a few frames of a few
+    voices are compared bit for bit."""
+    V, P = 128, 1024
+    tree = synth.effects_tree(V, P)
+    out_edges = tree["edges"][tree["edges"][:, 1] == 0]
+    body = dict(tree, edges=tree["edges"][tree["edges"][:, 1] != 0])
+    H = 28800
+    t = synth.time_ramp(0, H + 8)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, body)
+        synth.install(ref, body)
+        assert not hip.fill_buffer(4, 0, H, [t[:H]]).any() and not ref.fill_buffer(4, 0, H, [t[:H]]).any()
+        hip.on_add_edges(out_edges)
+        ref.on_add_edges(out_edges)
+        got = hip.fill_buffer(V, H, H + 8, [t[H:]])
+        plan = hip.plan()
+        # per voice: the bank's mix (read by the envelope stage) + x0..x3 (each read back by the next tap)
+        assert plan["pull_rows"] == 0 and plan["rings"] == V * 5 and plan["max_lookback"] == 24000, plan
+        exp = ref.fill_buffer(4, H, H + 2, [t[H:H + 2]])     # 4 voices x 2 frames on the CPU
+        assert same_bits(got[:4, :2], exp), first_diff(got[:4, :2], exp)
+        assert np.abs(got).max() > 0.01
