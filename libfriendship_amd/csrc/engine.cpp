@@ -382,7 +382,7 @@ struct fr_renderer {
             a.log2_p = bs.grp.log2_p;
             a.n_times = blen;
             a.fast_ok = bs.grp.fast_ok ? 1u : 0u;
-            bank_shape(a.log2_p, a.n_voices, blen, a.chunk_log2, a.frames_per_lane);
+            bank_shape(a.log2_p, a.n_voices, blen, a.chunk_log2, a.frames_per_lane, a.waves_per_group);
             a.leaf_variant = bank_leaf_variant;
             if (a.chunk_log2 != a.log2_p) {
                 d_bank_ws.ensure(((size_t)a.n_voices << (a.log2_p - a.chunk_log2)) * blen * sizeof(float));

@@ -288,9 +288,9 @@ __device__ __forceinline__ void bank_wave_sum(const float *params, uint32_t ngro
 // The AND is order-free, so here lanes run over PARTIALS (coalesced float2 loads), unlike the hot loop.
 // Returns, for this thread's share of partials [0, n), whether all leaves at time t are exactly -0.0 in the
 // graph's arithmetic (product-form leaf, general fract: bit-identical to the graph for every input).
-__device__ __forceinline__ bool leaves_all_negzero(const float2 *params, uint32_t n, float t, uint32_t tid) {
+__device__ __forceinline__ bool leaves_all_negzero(const float2 *params, uint32_t n, float t, uint32_t tid, uint32_t nthreads) {
     bool ok = true;
-    for (uint32_t k = tid; k < n && ok; k += 256u) {
+    for (uint32_t k = tid; k < n && ok; k += nthreads) {
         float2 p = params[k];
         ok = __float_as_uint(bank_leaf<false, true>(t, p.x, p.y)) == 0x80000000u;
     }
@@ -311,8 +311,10 @@ __device__ __forceinline__ uint64_t bank_out_index(const BankArgs &a, uint64_t t
 // (Recomputing flagged tiles with the product-form loop inside the same kernel was tried first: with a second
 //  copy of the hot loop inlined, register allocation degrades and the kernel runs 1.6x slower;
 //  profiles/r01_bank_variants.txt.)
-template <int F, int MODE>
-__global__ void __launch_bounds__(256) bank_kernel(BankArgs a, uint32_t tiles, uint32_t nblocks) {
+// NW = waves per workgroup (4 or 8): a wave is the unit of work that cannot be split further, so more, smaller
+// waves shorten the kernel's tail at a given call size (measured: profiles/r01_bank_variants.txt).
+template <int F, int MODE, int NW>
+__global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tiles, uint32_t nblocks) {
     // XCD-aware order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
     // contiguous range of (voice, chunk, tile) work: its L2 then sees 1/8 of the parameter streams.
     uint32_t b = blockIdx.x;
@@ -339,19 +341,19 @@ __global__ void __launch_bounds__(256) bank_kernel(BankArgs a, uint32_t tiles, u
     }
     const bool fast = a.fast_ok && __all(nonneg);   // then every x = t*w is in [0, 2^64]: finite, >= 0
 
-    const uint32_t Pc = 1u << a.chunk_log2;           // partials per workgroup, 32 <= Pc <= 8192
-    const uint32_t Pw = Pc >> 2;                      // partials per wave
+    const uint32_t Pc = 1u << a.chunk_log2;           // partials per workgroup, 8*NW <= Pc <= 2048*NW
+    const uint32_t Pw = Pc / NW;                      // partials per wave
     const float2 *cparams = a.params + ((size_t)voice << a.log2_p) + (size_t)chunk * Pc;
     const float *params = (const float *)(cparams + (size_t)wave * Pw);
     const uint32_t ngroups = Pw >> 3;
-    const uint32_t levels = a.chunk_log2 - 5u;        // log2(ngroups) <= 8
+    const uint32_t levels = a.chunk_log2 - 3u - (NW == 8 ? 3u : 2u);   // log2(ngroups) <= 8
 
     float res[F];
     constexpr bool EXACT = (MODE == 0);
     if (fast) bank_wave_sum<F, true, EXACT>(params, ngroups, levels, t, res);
     else bank_wave_sum<F, false, EXACT>(params, ngroups, levels, t, res);
 
-    __shared__ float sm[4][F][64];
+    __shared__ float sm[NW][F][64];
     __shared__ unsigned long long zmask[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) sm[wave][f][lane] = res[f];
@@ -365,6 +367,7 @@ __global__ void __launch_bounds__(256) bank_kernel(BankArgs a, uint32_t tiles, u
         for (int f = 0; f < F; ++f) {
             uint64_t ti = t0 + (uint32_t)f * 64u + lane;
             float r = (sm[0][f][lane] + sm[1][f][lane]) + (sm[2][f][lane] + sm[3][f][lane]);
+            if (NW == 8) r = r + ((sm[4][f][lane] + sm[5][f][lane]) + (sm[6][f][lane] + sm[7][f][lane]));
             bool live = ti < a.n_times;
             if (live) orow[direct ? bank_out_index(a, ti) : ti] = r;
             if (MODE == 1) {
@@ -383,7 +386,7 @@ __global__ void __launch_bounds__(256) bank_kernel(BankArgs a, uint32_t tiles, u
                 m &= m - 1;
                 uint64_t ti = t0 + (uint32_t)f * 64u + l;
                 float tz = bank_time(a, ti);
-                int all = __syncthreads_and(leaves_all_negzero(cparams, Pc, tz, threadIdx.x) ? 1 : 0);
+                int all = __syncthreads_and(leaves_all_negzero(cparams, Pc, tz, threadIdx.x, 64u * NW) ? 1 : 0);
                 if (threadIdx.x == 0) orow[direct ? bank_out_index(a, ti) : ti] = all ? -0.0f : 0.0f;
             }
         }
@@ -429,9 +432,16 @@ static hipError_t launch_bank_f(const BankArgs &a, hipStream_t s) {
     if (nblocks64 == 0) return hipSuccess;
     if (nblocks64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     uint32_t tiles = (uint32_t)((a.n_times + 64 * F - 1) / (64 * F)), nblocks = (uint32_t)nblocks64;
-    if (a.leaf_variant == 0) hipLaunchKernelGGL((bank_kernel<F, 0>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
-    else if (a.leaf_variant == 1) hipLaunchKernelGGL((bank_kernel<F, 1>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
-    else hipLaunchKernelGGL((bank_kernel<F, 2>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
+    const bool w8 = a.waves_per_group == 8;
+    if (a.leaf_variant == 0) {
+        if (w8) hipLaunchKernelGGL((bank_kernel<F, 0, 8>), dim3(nblocks), dim3(512), 0, s, a, tiles, nblocks);
+        else hipLaunchKernelGGL((bank_kernel<F, 0, 4>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
+    } else if (a.leaf_variant == 1) {
+        if (w8) hipLaunchKernelGGL((bank_kernel<F, 1, 8>), dim3(nblocks), dim3(512), 0, s, a, tiles, nblocks);
+        else hipLaunchKernelGGL((bank_kernel<F, 1, 4>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
+    } else {
+        hipLaunchKernelGGL((bank_kernel<F, 2, 4>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || a.chunk_log2 == a.log2_p) return e;
     uint64_t total = (uint64_t)a.n_voices * a.n_times;
@@ -443,16 +453,23 @@ static hipError_t launch_bank_f(const BankArgs &a, hipStream_t s) {
 // (tools/bank_bench.hip, profiles/r01_bank_variants.txt): one 64-frame tile per wave (F = 1) is never
 // slower than 2 or 4; whole voices per workgroup (<= 8192 partials) win as soon as that yields ~512
 // workgroups (2 per CU); below that, splitting partials into chunks (+ one combine pass) pays.
-void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane) {
+void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane,
+                uint32_t &waves_per_group) {
     const uint64_t want_blocks = 512;
-    chunk_log2 = log2_p < 13 ? log2_p : 13;
+    // 8 waves per workgroup only where that keeps a 16384-partial voice in one workgroup (no combine pass);
+    // at 4096 partials 4 and 8 waves measured equal
+    waves_per_group = log2_p >= 14 ? 8 : 4;
+    const uint32_t cmin = waves_per_group == 8 ? 6 : 5, cmax = waves_per_group == 8 ? 14 : 13;
+    chunk_log2 = log2_p < cmax ? log2_p : cmax;
     frames_per_lane = 1;
     auto blocks = [&](uint32_t cl) { return ((n_times + 63) / 64) * n_voices << (log2_p - cl); };
-    while (chunk_log2 > 5 && blocks(chunk_log2) < want_blocks) --chunk_log2;
+    while (chunk_log2 > cmin && blocks(chunk_log2) < want_blocks) --chunk_log2;
 }
 
 hipError_t launch_bank(const BankArgs &a, hipStream_t s) {
-    if (a.log2_p < 5 || a.log2_p > 24 || a.chunk_log2 < 5 || a.chunk_log2 > 13 || a.chunk_log2 > a.log2_p)
+    if (a.waves_per_group != 4 && a.waves_per_group != 8) return hipErrorInvalidValue;
+    const uint32_t cmin = a.waves_per_group == 8 ? 6 : 5, cmax = a.waves_per_group == 8 ? 14 : 13;
+    if (a.log2_p < cmin || a.log2_p > 24 || a.chunk_log2 < cmin || a.chunk_log2 > cmax || a.chunk_log2 > a.log2_p)
         return hipErrorInvalidValue;
     if (a.chunk_log2 != a.log2_p && !a.ws) return hipErrorInvalidValue;
     switch (a.frames_per_lane) {
