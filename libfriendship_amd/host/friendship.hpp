@@ -33,7 +33,12 @@
 #include <variant>
 #include <vector>
 
+#include <filesystem>
+#include <fstream>
+#include <sstream>
+
 #include "../../include/friendship_render.h"
+#include "json_sha.hpp"
 
 namespace friendship {
 
@@ -289,35 +294,152 @@ struct AdjList {
     std::vector<Edge> edges;
 };
 
-// effect.rs:44-48,258-282
+// effect.rs:44-48,258-282.  to_json()/from_json() produce and accept the wire shape serde derives for the
+// reference's structs: {"meta":{"id":{"name","sha256","urls"},"inputs":[{"name","channel"}],
+// "outputs":[...]},"adjlist":{"nodes":[[{"node_handle":n},{id}]...],"edges":[{"from":{"node_handle":n},
+// "to":{...},"weight":{"from_slot","to_slot"}}]}}; NodeHandle's NullableInt is a plain integer, 0 = null
+// (nullable_int.rs:88-102); sha256 is null or an array of 32 integers.
 struct EffectDesc {
     EffectMeta meta;
     AdjList adjlist;
     static EffectDesc make(EffectMeta m, AdjList a) { return EffectDesc{std::move(m), std::move(a)}; }
+
+    static json::Value id_to_json(const EffectId &id) {
+        json::Value sha = json::Value::null();
+        if (id.sha256) {
+            sha = json::Value::array();
+            for (uint8_t b : *id.sha256) sha.a->push_back(json::Value::integer(b));
+        }
+        json::Value urls = json::Value::array();
+        for (auto &u : id.urls) urls.a->push_back(json::Value::string(u));
+        return json::Value::object({{"name", json::Value::string(id.name)}, {"sha256", sha}, {"urls", urls}});
+    }
+    static EffectId id_from_json(const json::Value &v) {
+        EffectId id;
+        id.name = v.at("name").str();
+        const json::Value &sha = v.at("sha256");
+        if (!sha.is_null()) {
+            if (sha.arr().size() != 32) throw std::runtime_error("sha256 must have 32 entries");
+            std::array<uint8_t, 32> a{};
+            for (size_t i = 0; i < 32; ++i) a[i] = (uint8_t)sha.arr()[i].u64();
+            id.sha256 = a;
+        }
+        for (auto &u : v.at("urls").arr()) id.urls.insert(u.str());
+        return id;
+    }
+    static json::Value handle_to_json(NodeHandle h) {
+        return json::Value::object({{"node_handle", json::Value::integer(h.node_handle)}});
+    }
+    static NodeHandle handle_from_json(const json::Value &v) { return NodeHandle::make((uint32_t)v.at("node_handle").u64()); }
+
+    json::Value to_json() const {
+        auto ios = [](const std::vector<EffectIO> &v) {
+            json::Value a = json::Value::array();
+            for (auto &io : v)
+                a.a->push_back(json::Value::object({{"name", json::Value::string(io.name)}, {"channel", json::Value::integer(io.channel)}}));
+            return a;
+        };
+        json::Value nodes = json::Value::array(), edges = json::Value::array();
+        for (auto &hn : adjlist.nodes) nodes.a->push_back(json::Value::array({handle_to_json(hn.first), id_to_json(hn.second)}));
+        for (auto &e : adjlist.edges)
+            edges.a->push_back(json::Value::object(
+                {{"from", handle_to_json(e.from)}, {"to", handle_to_json(e.to)},
+                 {"weight", json::Value::object({{"from_slot", json::Value::integer(e.weight.from_slot)},
+                                                 {"to_slot", json::Value::integer(e.weight.to_slot)}})}}));
+        return json::Value::object(
+            {{"meta", json::Value::object({{"id", id_to_json(meta.id)}, {"inputs", ios(meta.inputs_)}, {"outputs", ios(meta.outputs_)}})},
+             {"adjlist", json::Value::object({{"nodes", nodes}, {"edges", edges}})}});
+    }
+    std::string to_json_string() const { return json::to_string(to_json()); }   // serde_json::to_writer
+
+    static EffectDesc from_json(const json::Value &v) {
+        EffectDesc d;
+        const json::Value &m = v.at("meta");
+        d.meta.id = id_from_json(m.at("id"));
+        auto ios = [](const json::Value &a) {
+            std::vector<EffectIO> out;
+            for (auto &io : a.arr()) out.push_back(EffectIO::make(io.at("name").str(), (uint8_t)io.at("channel").u64()));
+            return out;
+        };
+        d.meta.inputs_ = ios(m.at("inputs"));
+        d.meta.outputs_ = ios(m.at("outputs"));
+        const json::Value &adj = v.at("adjlist");
+        for (auto &n : adj.at("nodes").arr()) {
+            if (n.arr().size() != 2) throw std::runtime_error("adjlist node must be a [handle, id] pair");
+            d.adjlist.nodes.emplace_back(handle_from_json(n.arr()[0]), id_from_json(n.arr()[1]));
+        }
+        for (auto &e : adj.at("edges").arr()) {
+            const json::Value &w = e.at("weight");
+            d.adjlist.edges.push_back(Edge::make(handle_from_json(e.at("from")), handle_from_json(e.at("to")),
+                                                 EdgeWeight::make((uint32_t)w.at("from_slot").u64(), (uint32_t)w.at("to_slot").u64())));
+        }
+        return d;
+    }
+    static EffectDesc from_json_string(const std::string &text) { return from_json(json::parse(text)); }
+
+    // effect.rs:272-281: an id without a hash gets the sha256 of the description's own serialisation
+    void update_id() {
+        if (!meta.id.sha256) meta.id.sha256 = sha256(to_json_string());
+    }
 };
 
 }  // namespace routing
 
 namespace resman {
-// src/resman.rs.  In-memory form: descriptions are registered with add_desc() instead of being found
-// as JSON files by sha256 (the on-disk loader is SURVEY.md 8f row 1, not built yet).  add_dir() is
-// accepted and recorded so that dispatch messages keep their shape.
+// src/resman.rs: a list of search directories plus a sha256 -> path cache.  find_effect() yields every
+// candidate file for an id -- the cached path for its sha256 first, then every regular file of every
+// directory -- filtered by the sha256 of the file's bytes when the id carries one (resman.rs:39-60).
+// add_desc() additionally registers in-memory descriptions (not in the reference; handy for hosts that
+// build effects programmatically).
 class ResMan {
     std::vector<std::string> dirs_;
     std::vector<routing::EffectDesc> descs_;
+    mutable std::map<std::array<uint8_t, 32>, std::string> sha256_to_path_;   // ResCache (resman.rs:25-28,99-108)
+
+    static bool read_file(const std::string &path, std::string &out) {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) return false;
+        std::ostringstream ss;
+        ss << f.rdbuf();
+        out = ss.str();
+        return true;
+    }
 
 public:
+    struct Candidate { std::string path; std::string text; };
+
     void add_dir(std::string dir) { dirs_.push_back(std::move(dir)); }
     void add_desc(routing::EffectDesc d) { descs_.push_back(std::move(d)); }
     const std::vector<std::string> &dirs() const { return dirs_; }
-    // candidates for an id: same role as find_effect (resman.rs:39-43)
-    std::vector<const routing::EffectDesc *> find_effect(const routing::EffectId &id) const {
-        std::vector<const routing::EffectDesc *> v;
-        for (auto &d : descs_) {
-            if (id.sha256 && d.meta.id.sha256 && *id.sha256 != *d.meta.id.sha256) continue;
-            v.push_back(&d);
+    const std::vector<routing::EffectDesc> &descs() const { return descs_; }
+
+    std::vector<Candidate> find_effect(const routing::EffectId &id) const {
+        std::vector<std::string> paths;
+        if (id.sha256) {   // iter_all_files: the cached path is visited first (and possibly again below)
+            auto it = sha256_to_path_.find(*id.sha256);
+            if (it != sha256_to_path_.end()) paths.push_back(it->second);
         }
-        return v;
+        for (auto &d : dirs_) {
+            std::error_code ec;
+            std::filesystem::directory_iterator di(d, ec), end;
+            if (ec) continue;   // "ResMan: Failed to read directory"
+            for (; di != end; di.increment(ec)) {
+                if (ec) break;
+                if (di->is_regular_file(ec)) paths.push_back(di->path().string());
+            }
+        }
+        std::vector<Candidate> out;
+        for (auto &p : paths) {
+            Candidate c{p, {}};
+            if (!read_file(p, c.text)) continue;
+            if (id.sha256) {
+                auto h = sha256(c.text);
+                sha256_to_path_[h] = p;   // notify_sha256
+                if (h != *id.sha256) continue;
+            }
+            out.push_back(std::move(c));
+        }
+        return out;
     }
 };
 }  // namespace resman
@@ -351,8 +473,22 @@ public:
             m.id = id;   // primitive effects have undocumented I/O: empty lists (effect.rs:145-147)
             return std::make_shared<const Effect>(std::move(m), *prim);
         }
-        for (const EffectDesc *desc : res.find_effect(id)) {
-            if (desc->meta.id.name != id.name) continue;
+        // candidates: files found by the ResMan (parsed here, like serde_json::from_reader at effect.rs:160),
+        // then descriptions registered in memory
+        std::vector<EffectDesc> cands;
+        for (auto &c : res.find_effect(id)) {
+            try {
+                cands.push_back(EffectDesc::from_json_string(c.text));
+            } catch (const std::exception &) {
+                // "Unable to deserialize EffectDesc": skip the file (effect.rs:213-215)
+            }
+        }
+        for (auto &d : res.descs())
+            if (!id.sha256 || !d.meta.id.sha256 || *id.sha256 == *d.meta.id.sha256) cands.push_back(d);
+        for (EffectDesc &cand : cands) {
+            if (cand.meta.id.name != id.name) continue;
+            cand.update_id();
+            const EffectDesc *desc = &cand;
             try {
                 RouteGraph graph = graph_from_adjlist(desc->adjlist, res);
                 // all outputs driven, exactly once each, 0..n (effect.rs:168-175)

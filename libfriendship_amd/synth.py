@@ -210,6 +210,59 @@ def effects_tree(n_voices, n_partials, seed=0x5EED0003, detune=True, envelope=Tr
     return t
 
 
+def partial_effect():
+    """The partial oscillator as ONE composite effect `Partial(t, w, amp) -> leaf` (what a `.fnd` effect file would
+    hold): inputs 0,1,2 = time, w, amp as signals; per instance the host feeds w and amp through F32Constant edges.
+    Lowering inlines the instances and folds the constants, so the engine sees the same graph as the flat form."""
+    f = np.float32
+    c = 100   # the F32Constant node inside the effect
+    nodes = [(c, Effect.primitive("F32Constant")),
+             (1, Effect.primitive("Multiply")),   # x = t * w
+             (2, Effect.primitive("Modulo")),     # phase = x mod 1
+             (3, Effect.primitive("Sum2")),       # u = phase + -0.5
+             (4, Effect.primitive("Multiply")),   # nu = -1 * u
+             (5, Effect.primitive("Minimum")),    # m = min(u, nu)
+             (6, Effect.primitive("Multiply")),   # absu = -1 * m
+             (7, Effect.primitive("Multiply")),   # n1 = -1 * absu
+             (8, Effect.primitive("Sum2")),       # q = 0.5 + n1
+             (9, Effect.primitive("Multiply")),   # p = -16 * u
+             (10, Effect.primitive("Multiply")),  # y = p * q
+             (11, Effect.primitive("Multiply"))]  # leaf = amp * y
+    k = lambda v: f32_bits(f(v))
+    edges = [(0, 1, 0, 0), (0, 1, 1, 1),
+             (1, 2, 0, 0), (c, 2, k(1.0), 1),
+             (2, 3, 0, 0), (c, 3, k(-0.5), 1),
+             (c, 4, k(-1.0), 0), (3, 4, 0, 1),
+             (3, 5, 0, 0), (4, 5, 0, 1),
+             (c, 6, k(-1.0), 0), (5, 6, 0, 1),
+             (c, 7, k(-1.0), 0), (6, 7, 0, 1),
+             (c, 8, k(0.5), 0), (7, 8, 0, 1),
+             (c, 9, k(-16.0), 0), (3, 9, 0, 1),
+             (9, 10, 0, 0), (8, 10, 0, 1),
+             (0, 11, 2, 0), (10, 11, 0, 1),
+             (11, 0, 0, 0)]
+    return Effect.graph(nodes, edges)
+
+
+def install_composite_tree(renderer, n_voices, n_partials, seed=0x5EED0002, detune=False, sr=48000.0):
+    """The same V x P additive tree as additive_tree(), built from instances of the composite Partial effect."""
+    p = voice_params(n_voices, n_partials, seed, detune, sr)
+    eff = partial_effect()
+    n = n_voices * n_partials
+    g = GraphArrays()
+    part = np.arange(g.next, g.next + n, dtype=np.uint32)   # handles of the composite instances
+    g.next += n
+    g.edge(0, part, 0, 0)                                   # time -> input 0
+    g.const(part, p["w"].ravel(), 1)                        # w    -> input 1
+    g.const(part, p["amp"].ravel(), 2)                      # amp  -> input 2
+    roots = sum_tree(g, part.reshape(n_voices, n_partials))
+    g.edge(roots, 0, 0, np.arange(n_voices, dtype=np.uint32))
+    tree = g.finish(n_voices)
+    renderer.on_add_nodes(part, eff)
+    install(renderer, tree)
+    return p
+
+
 _PRIM_EFFECTS = None
 
 

@@ -9,6 +9,10 @@
 // Build: g++ -std=c++17 -O1 -o render_tests render_tests.cpp -ldl      Run: ./render_tests [test-name]
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <sstream>
 #include <deque>
 #include <functional>
 #include <iostream>
@@ -178,18 +182,79 @@ static EffectDesc create_multby2() {
 
 static void load_multby2() {
     auto [dispatch, rx] = test_setup();
-    // The reference writes the description to a temp dir as JSON and finds it by sha256; the on-disk
-    // loader is a later row, so the description is registered with the ResMan directly.
-    dispatch.dispatch(OscResMan::AddDir{"/nonexistent-libfriendship-test-dir"});
-    dispatch.resman().add_desc(create_multby2());
+    // let dir = TempDir::new("libfriendship")
+    char tmpl[] = "/tmp/libfriendship.XXXXXX";
+    const char *dir = mkdtemp(tmpl);
+    if (!dir) throw std::runtime_error("mkdtemp failed");
+    auto mulby2_desc = create_multby2();
+
+    // Add the temp dir as a search dir
+    dispatch.dispatch(OscResMan::AddDir{dir});
+
+    // Write the effect definition to file (serde_json::to_writer)
+    std::string mulby2_path = std::string(dir) + "/mulby2.fnd";
+    {
+        std::ofstream f(mulby2_path, std::ios::binary);
+        f << mulby2_desc.to_json_string();
+    }
+    // Determine the hash of our file
+    std::string bytes;
+    {
+        std::ifstream f(mulby2_path, std::ios::binary);
+        std::ostringstream ss;
+        ss << f.rdbuf();
+        bytes = ss.str();
+    }
+    auto sha = friendship::sha256(bytes);
+
+    // Create the MulBy2 node (id=1), found on disk by its sha256
     auto mul_hnd = NodeHandle::make(1);
-    dispatch.dispatch(OscRouteGraph::AddNode{mul_hnd, EffectId::make("MulBy2", std::nullopt, {})});
+    dispatch.dispatch(OscRouteGraph::AddNode{mul_hnd, EffectId::make("MulBy2", sha, {})});
     dispatch.dispatch(OscRouteGraph::AddEdge{Edge::new_to_null(mul_hnd, EdgeWeight::make(0, 0))});
     auto const_hnd = NodeHandle::make(2);
     dispatch.dispatch(OscRouteGraph::AddNode{const_hnd, EffectId::make("Constant", std::nullopt, {"primitive:///F32Constant"})});
     dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(const_hnd, mul_hnd, EdgeWeight::make(f32_to_bits(0.5f), 0))});
     dispatch.dispatch(render_range(0, 4, 1));
     ASSERT_EQ_ARR(recv(rx), array({2.5f, 2.5f, 2.5f, 2.5f}));
+
+    // a wrong hash, or a file that is not an effect, finds nothing: dispatch::Error::EffectError(NoMatchingEffect)
+    {
+        std::ofstream f(std::string(dir) + "/garbage.fnd");
+        f << "{not json";
+    }
+    auto bad = sha;
+    bad[0] ^= 1;
+    for (auto id : {EffectId::make("MulBy2", bad, {}), EffectId::make("NoSuchEffect", std::nullopt, {})}) {
+        bool raised = false;
+        try {
+            dispatch.dispatch(OscRouteGraph::AddNode{NodeHandle::make(7), id});
+        } catch (const friendship::dispatch::Error &e) {
+            raised = e.kind == friendship::dispatch::Error::EffectError;
+        }
+        if (!raised) throw std::runtime_error("expected EffectError(NoMatchingEffect)");
+    }
+    std::filesystem::remove_all(dir);
+}
+
+// The wire shape serde derives for EffectDesc, byte for byte, and its round trip.
+static void effect_desc_json() {
+    auto desc = create_multby2();
+    std::string text = desc.to_json_string();
+    const char *want =
+        "{\"meta\":{\"id\":{\"name\":\"MulBy2\",\"sha256\":null,\"urls\":[]},\"inputs\":[{\"name\":\"source\",\"channel\":0}],"
+        "\"outputs\":[{\"name\":\"result\",\"channel\":0}]},\"adjlist\":{\"nodes\":[[{\"node_handle\":1},{\"name\":\"Multiply\","
+        "\"sha256\":null,\"urls\":[\"primitive:///Multiply\"]}],[{\"node_handle\":2},{\"name\":\"Constant\",\"sha256\":null,"
+        "\"urls\":[\"primitive:///F32Constant\"]}]],\"edges\":[{\"from\":{\"node_handle\":0},\"to\":{\"node_handle\":1},"
+        "\"weight\":{\"from_slot\":0,\"to_slot\":0}},{\"from\":{\"node_handle\":1},\"to\":{\"node_handle\":0},\"weight\":"
+        "{\"from_slot\":0,\"to_slot\":0}},{\"from\":{\"node_handle\":2},\"to\":{\"node_handle\":1},\"weight\":"
+        "{\"from_slot\":1084227584,\"to_slot\":1}}]}}";
+    if (text != want) throw std::runtime_error("unexpected serialisation: " + text);
+    auto back = EffectDesc::from_json_string(text);
+    if (back.to_json_string() != text) throw std::runtime_error("round trip changed the description");
+    // FIPS 180-4 test vector
+    auto h = friendship::sha256(std::string("abc"));
+    const uint8_t abc[4] = {0xba, 0x78, 0x16, 0xbf};
+    if (std::memcmp(h.data(), abc, 4) != 0 || h[31] != 0xad) throw std::runtime_error("sha256 is wrong");
 }
 
 // ---- RouteGraph validation (src/routing/routegraph.rs:165-208): host-side, no renderer compute ----
@@ -243,7 +308,8 @@ int main(int argc, char **argv) {
         {"render_mult", render_mult}, {"render_sum2", render_sum2}, {"render_div", render_div},
         {"render_mod", render_mod}, {"render_min", render_min},
         {"ext_render_passthrough", ext_render_passthrough}, {"ext_render_delay", ext_render_delay},
-        {"load_multby2", load_multby2}, {"routegraph_validation", routegraph_validation}};
+        {"load_multby2", load_multby2}, {"effect_desc_json", effect_desc_json},
+        {"routegraph_validation", routegraph_validation}};
     int failed = 0, ran = 0;
     for (auto &t : tests) {
         if (argc > 1 && std::string(argv[1]) != t.first) continue;

@@ -407,3 +407,19 @@ def test_config_d_full_size_sampled_against_oracle(hip_lib, oracle_lib):
         exp = ref.fill_buffer(4, H, H + 2, [t[H:H + 2]])     # 4 voices x 2 frames on the CPU
         assert same_bits(got[:4, :2], exp), first_diff(got[:4, :2], exp)
         assert np.abs(got).max() > 0.01
+
+
+def test_bank_from_composite_effect_instances(hip_lib, oracle_lib):
+    """The voice built from instances of ONE composite `Partial(t, w, amp)` effect (the shape an effect file gives):
+    lowering inlines the instances, folds the constant inputs, and the planner still finds the bank."""
+    V, P, T = 3, 128, 300
+    t = synth.time_ramp(0, T)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref, Renderer(hip_lib) as flat:
+        synth.install_composite_tree(hip, V, P, seed=4, detune=True)
+        synth.install_composite_tree(ref, V, P, seed=4, detune=True)
+        synth.install(flat, synth.additive_tree(V, P, seed=4, detune=True))
+        got, exp = hip.fill_buffer(V, 0, T, [t]), ref.fill_buffer(V, 0, T, [t])
+        assert same_bits(got, exp), first_diff(got, exp)
+        assert same_bits(got, flat.fill_buffer(V, 0, T, [t]))
+        plan = hip.plan()
+        assert plan["pull_rows"] == 0 and plan["banks"][0]["voices"] == V and plan["banks"][0]["partials"] == P, plan
