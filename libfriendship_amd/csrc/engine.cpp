@@ -69,7 +69,7 @@ struct InSlot {
 
 struct BankStage {
     BankLaunch grp;          // rows/params kept on the host for the plan description
-    DevBuf d_params, d_rows;
+    DevBuf d_params, d_rows, d_groups, d_group_off;
 };
 
 struct Plan {
@@ -185,8 +185,13 @@ struct fr_renderer {
     bool bank_time_slot(uint32_t n_slots, uint32_t slot) const {
         if (!plan.valid || plan.version != mirror.version || plan.n_slots != n_slots) return false;
         if (plan.sp.uses_rings() || !plan.sp.progs.empty()) return false;   // windows with look-back read the stored history
-        for (const BankStage &bs : plan.banks) if (bs.grp.input_slot == slot) return true;
-        return false;
+        bool any = false;
+        for (const BankStage &bs : plan.banks) {
+            if (bs.grp.input_slot != slot) continue;
+            if (bs.grp.general) return false;   // only the balanced kernel appends history
+            any = true;
+        }
+        return any;
     }
 
     // `device_rows`: in_data is a device pointer (fr_fill_buffer_device).
@@ -270,6 +275,12 @@ struct fr_renderer {
             bs.d_rows.ensure(bs.grp.rows.size() * sizeof(uint32_t));
             HIP_CHECK(hipMemcpyAsync(bs.d_params.p, bs.grp.params.data(), bs.grp.params.size() * sizeof(float), hipMemcpyHostToDevice, st));
             HIP_CHECK(hipMemcpyAsync(bs.d_rows.p, bs.grp.rows.data(), bs.grp.rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            if (bs.grp.general) {
+                bs.d_groups.ensure(bs.grp.groups.size() * sizeof(uint32_t));
+                bs.d_group_off.ensure(bs.grp.group_off.size() * sizeof(uint32_t));
+                HIP_CHECK(hipMemcpyAsync(bs.d_groups.p, bs.grp.groups.data(), bs.grp.groups.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+                HIP_CHECK(hipMemcpyAsync(bs.d_group_off.p, bs.grp.group_off.data(), bs.grp.group_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            }
             p.banks.push_back(std::move(bs));
         }
         p.sp.banks.clear();
@@ -307,7 +318,8 @@ struct fr_renderer {
            << ",\"lowered_nodes\":" << p.fg.nodes.size() << ",\"max_depth\":" << p.fg.max_depth << ",\"banks\":[";
         for (size_t i = 0; i < p.banks.size(); ++i) {
             const BankLaunch &g = p.banks[i].grp;
-            js << (i ? "," : "") << "{\"voices\":" << g.rows.size() << ",\"partials\":" << (1u << g.log2_p)
+            js << (i ? "," : "") << "{\"voices\":" << g.rows.size() << ",\"partials\":" << (g.general ? g.max_leaves : (1u << g.log2_p))
+               << ",\"general_tree\":" << (g.general ? "true" : "false")
                << ",\"input_slot\":" << g.input_slot << ",\"fast_ok\":" << (g.fast_ok ? "true" : "false")
                << ",\"to_ring\":" << (g.to_ring ? "true" : "false")
                << ",\"param_bytes\":" << g.params.size() * sizeof(float) << "}";
@@ -382,6 +394,15 @@ struct fr_renderer {
             a.log2_p = bs.grp.log2_p;
             a.n_times = blen;
             a.fast_ok = bs.grp.fast_ok ? 1u : 0u;
+            if (bs.grp.general) {
+                a.groups = bs.d_groups.as<uint32_t>();
+                a.group_off = bs.d_group_off.as<uint32_t>();
+                a.hist_dst = nullptr;   // (the schedule kernel does not append history)
+                Scope sc(this, &t_bank, st);
+                HIP_CHECK(launch_gbank(a, st));
+                sc.done();
+                continue;
+            }
             bank_shape(a.log2_p, a.n_voices, blen, a.chunk_log2, a.frames_per_lane, a.waves_per_group);
             a.leaf_variant = bank_leaf_variant;
             if (a.chunk_log2 != a.log2_p) {

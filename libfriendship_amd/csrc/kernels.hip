@@ -481,6 +481,109 @@ hipError_t launch_bank(const BankArgs &a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// General voices: the same leaf, any Sum2 tree (odd carries, unbalanced, non-power-of-two partial counts).
+// The host cuts the tree into groups = maximal complete sub-trees of 1/2/4/8 consecutive leaves and a post-order
+// schedule "group, then m merges"; one wave per (voice, 64-frame tile) runs it with a small register stack whose
+// pointer is wave-uniform (scalar branch ladders, no dynamic register indexing).  Same bits as the graph: every
+// add is the tree's own add.  One wave per voice tile keeps the schedule sequential; voices x tiles give the
+// parallelism (this path exists for generality, the balanced kernel above is the fast one).
+// ---------------------------------------------------------------------------------------------------
+#define FR_STACK_REGS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+
+template <bool FAST>
+__device__ __forceinline__ float gbank_wave(const float *params, const uint32_t *gmeta, uint32_t ngroups, float t) {
+#define FR_DECL(i) float s##i = 0.0f;
+    FR_STACK_REGS(FR_DECL)
+#undef FR_DECL
+    uint32_t sp = 0;
+    const_f32_ptr p = (const_f32_ptr)params;
+    typedef uint32_t __attribute__((address_space(4))) const *const_u32_ptr;
+    const_u32_ptr gm = (const_u32_ptr)gmeta;
+    for (uint32_t g = 0; g < ngroups; ++g) {
+        ParamGroup pg;
+        load_group(pg, p, g);
+        const uint32_t meta = gm[g];
+        const uint32_t j = meta & 15u;
+        float l0 = bank_leaf<FAST, false>(t, pg.w[0], pg.A[0]);
+        float v = l0;
+        if (j >= 1u) {
+            float l1 = bank_leaf<FAST, false>(t, pg.w[1], pg.A[1]);
+            v = l0 + l1;
+            if (j >= 2u) {
+                float l2 = bank_leaf<FAST, false>(t, pg.w[2], pg.A[2]);
+                float l3 = bank_leaf<FAST, false>(t, pg.w[3], pg.A[3]);
+                v = v + (l2 + l3);
+                if (j >= 3u) {
+                    float l4 = bank_leaf<FAST, false>(t, pg.w[4], pg.A[4]);
+                    float l5 = bank_leaf<FAST, false>(t, pg.w[5], pg.A[5]);
+                    float l6 = bank_leaf<FAST, false>(t, pg.w[6], pg.A[6]);
+                    float l7 = bank_leaf<FAST, false>(t, pg.w[7], pg.A[7]);
+                    v = v + ((l4 + l5) + (l6 + l7));
+                }
+            }
+        }
+        for (uint32_t m = meta >> 4; m != 0u; --m) {   // v = pop() + v
+            --sp;
+            float top = 0.0f;
+#define FR_POP(i) if (sp == i##u) top = s##i;
+            FR_STACK_REGS(FR_POP)
+#undef FR_POP
+            v = top + v;
+        }
+#define FR_PUSH(i) if (sp == i##u) s##i = v;
+        FR_STACK_REGS(FR_PUSH)
+#undef FR_PUSH
+        ++sp;
+    }
+    return s0;   // a well-formed schedule leaves exactly the root
+}
+
+__global__ void __launch_bounds__(64) gbank_kernel(BankArgs a, uint32_t tiles, uint32_t nblocks) {
+    uint32_t b = blockIdx.x;
+    uint32_t lid = (nblocks % 8u == 0u) ? (b % 8u) * (nblocks / 8u) + b / 8u : b;
+    const uint32_t voice = lid / tiles;
+    const uint32_t tile = lid - voice * tiles;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t ti = (uint64_t)tile * 64u + lane;
+    const float t = bank_time(a, ti);
+    const bool fast = a.fast_ok && __all(t >= 0.0f && t <= 4294967296.0f);
+    const uint32_t g0 = a.group_off[voice], ng = a.group_off[voice + 1] - g0;
+    const float2 *vparams = a.params + (size_t)g0 * 8u;
+    float r = fast ? gbank_wave<true>((const float *)vparams, a.groups + g0, ng, t)
+                   : gbank_wave<false>((const float *)vparams, a.groups + g0, ng, t);
+    float *orow = a.out + (size_t)a.rows[voice] * a.out_stride;
+    const bool live = ti < a.n_times;
+    if (live) orow[bank_out_index(a, ti)] = r;
+    // sign of a zero result: -0 iff every (valid) leaf is -0, see leaves_all_negzero
+    unsigned long long zm = __ballot(live && r == 0.0f);
+    while (zm) {
+        uint32_t l = (uint32_t)__builtin_ctzll(zm);
+        zm &= zm - 1;
+        uint64_t tz_i = (uint64_t)tile * 64u + l;
+        float tz = bank_time(a, tz_i);
+        bool ok = true;
+        for (uint32_t k = lane; k < ng * 8u && ok; k += 64u) {
+            uint32_t sz = 1u << (a.groups[g0 + (k >> 3)] & 15u);
+            if ((k & 7u) < sz) {
+                float2 p = vparams[k];
+                ok = __float_as_uint(bank_leaf<false, true>(tz, p.x, p.y)) == 0x80000000u;
+            }
+        }
+        bool all = __all(ok);
+        if (lane == 0) orow[bank_out_index(a, tz_i)] = all ? -0.0f : 0.0f;
+    }
+}
+
+hipError_t launch_gbank(const BankArgs &a, hipStream_t s) {
+    if (!a.groups || !a.group_off) return hipErrorInvalidValue;
+    uint64_t tiles64 = (a.n_times + 63) / 64, nblocks64 = tiles64 * a.n_voices;
+    if (nblocks64 == 0) return hipSuccess;
+    if (nblocks64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gbank_kernel, dim3((uint32_t)nblocks64), dim3(64), 0, s, a, (uint32_t)tiles64, (uint32_t)nblocks64);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Staged evaluator: one thread per (program, frame).  Temporaries live in LDS as [register][thread] columns
 // (conflict-free, no barriers: a thread only touches its own column).  Ring reads are the materialised
 // form of the reference's "re-evaluate the source at t - d" (reference.rs:213-215): the ring holds exactly the

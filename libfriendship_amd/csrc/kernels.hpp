@@ -62,11 +62,16 @@ struct BankArgs {
     uint32_t leaf_variant;     // 0 = product-form leaves; 1 = FMA-form leaves + zero-sign repair (same bits, faster)
     float *hist_dst;           // if non-null: the kernel also copies time[0..time_valid) here (input-history append)
     float *ws;                 // [P >> chunk_log2][n_voices][n_times] partial sums; unused when one chunk
+    // general voices (launch_gbank): params = [group][8]{w, -4*amp}; groups[g] = log2(size) | merges_after << 4;
+    // voice v owns groups [group_off[v], group_off[v+1])
+    const uint32_t *groups;
+    const uint32_t *group_off;
 };
 void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane,
                 uint32_t &waves_per_group);
 uint64_t bank_blocks(const BankArgs &a);
 hipError_t launch_bank(const BankArgs &a, hipStream_t s);
+hipError_t launch_gbank(const BankArgs &a, hipStream_t s);   // voices that are arbitrary Sum2 trees (schedule form)
 
 // ---- staged evaluator -------------------------------------------------------------------------------
 // A cut node (a value some Delay reads back in time, or an output) is computed per frame by a small

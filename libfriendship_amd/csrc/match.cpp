@@ -15,6 +15,7 @@
 // mismatch costs speed, never correctness.
 #include "match.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <unordered_map>
 
@@ -119,6 +120,78 @@ struct Matcher {
 
 struct BankMatcher::Impl : Matcher {
     using Matcher::Matcher;
+
+    // height of the complete sub-tree of matched leaves rooted at n (0 = a leaf, up to 3 = 8 leaves), -1 if n is a
+    // Sum2 node that is not such a sub-tree, -2 if n is neither a leaf nor a Sum2 (not a voice at all)
+    std::unordered_map<uint32_t, int> cj_memo;
+    int complete_height(uint32_t id, uint64_t &budget) {
+        auto it = cj_memo.find(id);
+        if (it != cj_memo.end()) return it->second;
+        if (budget == 0) return -2;
+        --budget;
+        int r;
+        if (match_leaf(id).ok) {
+            r = 0;
+        } else if (n(id).op != OP_SUM2) {
+            r = -2;
+        } else {
+            int a = complete_height(n(id).a, budget), b = complete_height(n(id).b, budget);
+            if (a == -2 || b == -2) r = -2;
+            else if (a >= 0 && a == b && a < 3) r = a + 1;
+            else r = -1;
+        }
+        cj_memo.emplace(id, r);
+        return r;
+    }
+
+    void append_leaves(uint32_t id, VoiceMatch &vm, bool &first, bool &ok) {
+        Leaf L = match_leaf(id);
+        if (L.ok) {
+            if (first) { vm.input_slot = L.slot; first = false; }
+            else if (vm.input_slot != L.slot) ok = false;
+            vm.params.push_back(L.w);
+            vm.params.push_back(L.A);
+            if (!(L.w >= 0.0f && L.w <= 4294967296.0f)) vm.fast_ok = false;
+            ++vm.n_leaves;
+            return;
+        }
+        append_leaves(n(id).a, vm, first, ok);
+        append_leaves(n(id).b, vm, first, ok);
+    }
+
+    // post-order emission: complete sub-trees become groups, every other Sum2 node a merge after its right operand
+    bool emit_general(uint32_t root, VoiceMatch &vm) {
+        uint64_t budget = 1u << 22;
+        if (complete_height(root, budget) == -2) return false;
+        struct Item { uint32_t id; int state; };
+        std::vector<Item> st{{root, 0}};
+        bool first = true, ok = true;
+        uint32_t depth = 0, max_depth = 0;
+        while (!st.empty() && ok) {
+            Item it = st.back();
+            st.pop_back();
+            if (it.state == 1) {   // both operands emitted: one merge
+                if (vm.groups.empty()) return false;
+                vm.groups.back() += 1u << 4;
+                --depth;
+                continue;
+            }
+            int cj = cj_memo.at(it.id);
+            if (cj >= 0) {
+                size_t before = vm.params.size();
+                append_leaves(it.id, vm, first, ok);
+                vm.params.resize(before + 16, 0.0f);   // pad the group to 8 {w, A4} pairs
+                vm.groups.push_back((uint32_t)cj);
+                max_depth = std::max(max_depth, ++depth);
+                if (vm.groups.size() > (1u << 20)) return false;
+                continue;
+            }
+            st.push_back({it.id, 1});
+            st.push_back({n(it.id).b, 0});
+            st.push_back({n(it.id).a, 0});
+        }
+        return ok && max_depth <= 16 && vm.n_leaves >= 16;
+    }
 };
 
 BankMatcher::BankMatcher(const FlatGraph &g, uint32_t max_log2_p) : impl_(new Impl(g)), g_(g), max_log2_p_(max_log2_p) {}
@@ -143,6 +216,16 @@ bool BankMatcher::try_voice(uint32_t root, VoiceMatch &out) {
         if (impl_->collect(root, h, vm.params, vm.input_slot, first, vm.fast_ok)) {
             memo_.emplace(root, (int64_t)found_.size());
             found_.push_back(vm);
+            out = found_.back();
+            return true;
+        }
+    }
+    if (g_.nodes[root].op == OP_SUM2) {   // not a balanced power-of-two tree: try the general schedule
+        VoiceMatch vm;
+        vm.general = true;
+        if (impl_->emit_general(root, vm)) {
+            memo_.emplace(root, (int64_t)found_.size());
+            found_.push_back(std::move(vm));
             out = found_.back();
             return true;
         }

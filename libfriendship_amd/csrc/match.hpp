@@ -10,11 +10,19 @@
 namespace fr {
 
 // One recognised voice: a complete balanced Sum2 tree over 2^log2_p partial leaves.
+// One recognised voice: a Sum2 tree over partial leaves.
+//   balanced (general == false): complete tree over 2^log2_p leaves; params = [P]{w, -4*amp}.
+//   general  (general == true):  any Sum2 tree (odd carries, unbalanced, non-power-of-two leaf counts), cut into
+//     groups = maximal complete sub-trees of 1, 2, 4 or 8 consecutive leaves, evaluated in post-order with a stack:
+//     groups[i] = log2(size) | merges_after << 4; params = [n_groups][8]{w, -4*amp}, unused entries zero.
 struct VoiceMatch {
     uint32_t log2_p = 0;
     uint32_t input_slot = 0;        // external input slot read as `t`
     bool fast_ok = true;            // every w in [0, 2^32]
-    std::vector<float> params;      // [P]{w, -4*amp}
+    std::vector<float> params;
+    bool general = false;
+    uint32_t n_leaves = 0;
+    std::vector<uint32_t> groups;
 };
 
 class BankMatcher {

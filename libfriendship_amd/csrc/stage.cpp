@@ -87,6 +87,29 @@ struct Planner {
     }
 };
 
+// Adds a voice to the launch that shares its kind (balanced: partial count; general: all together), time slot
+// and destination kind.
+void add_voice(std::vector<BankLaunch> &banks, std::unordered_map<uint64_t, size_t> &grp, const VoiceMatch &vm, uint32_t row, bool ring) {
+    uint64_t key = ((uint64_t)(vm.general ? 63u : vm.log2_p) << 34) | ((uint64_t)vm.input_slot << 2) | (vm.general ? 2u : 0u) | (ring ? 1u : 0u);
+    auto gi = grp.find(key);
+    if (gi == grp.end()) {
+        gi = grp.emplace(key, banks.size()).first;
+        BankLaunch bl;
+        bl.log2_p = vm.log2_p; bl.input_slot = vm.input_slot; bl.to_ring = ring; bl.general = vm.general;
+        if (vm.general) bl.group_off.push_back(0);
+        banks.push_back(std::move(bl));
+    }
+    BankLaunch &bl = banks[gi->second];
+    bl.rows.push_back(row);
+    bl.params.insert(bl.params.end(), vm.params.begin(), vm.params.end());
+    bl.fast_ok = bl.fast_ok && vm.fast_ok;
+    if (vm.general) {
+        bl.groups.insert(bl.groups.end(), vm.groups.begin(), vm.groups.end());
+        bl.group_off.push_back((uint32_t)bl.groups.size());
+        bl.max_leaves = std::max(bl.max_leaves, vm.n_leaves);
+    }
+}
+
 struct ProgBuild {
     std::vector<StageInstr> instrs;   // `buf` holds the cut NODE id until rings are assigned
     uint32_t result_reg = 0;
@@ -213,18 +236,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
             auto it = P.bank_of.find(g.outputs[row]);
             if (it == P.bank_of.end()) { fb.pull_rows.push_back(row); continue; }
             const VoiceMatch &vm = it->second;
-            uint64_t key = ((uint64_t)vm.log2_p << 32) | vm.input_slot;
-            auto gi = grp.find(key);
-            if (gi == grp.end()) {
-                gi = grp.emplace(key, fb.banks.size()).first;
-                BankLaunch bl;
-                bl.log2_p = vm.log2_p; bl.input_slot = vm.input_slot; bl.to_ring = false;
-                fb.banks.push_back(std::move(bl));
-            }
-            BankLaunch &bl = fb.banks[gi->second];
-            bl.rows.push_back(row);
-            bl.params.insert(bl.params.end(), vm.params.begin(), vm.params.end());
-            bl.fast_ok = bl.fast_ok && vm.fast_ok;
+            add_voice(fb.banks, grp, vm, row, false);
         }
         std::sort(fb.pull_rows.begin(), fb.pull_rows.end());
         return fb;
@@ -270,18 +282,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
             bool ring = needs_ring.count(n) != 0;
             auto ro = rows_of.find(n);
             if (!ring && ro == rows_of.end()) continue;   // unreachable
-            uint64_t key = ((uint64_t)vm.log2_p << 33) | ((uint64_t)vm.input_slot << 1) | (ring ? 1u : 0u);
-            auto gi = grp.find(key);
-            if (gi == grp.end()) {
-                gi = grp.emplace(key, sp.banks.size()).first;
-                BankLaunch bl;
-                bl.log2_p = vm.log2_p; bl.input_slot = vm.input_slot; bl.to_ring = ring;
-                sp.banks.push_back(std::move(bl));
-            }
-            BankLaunch &bl = sp.banks[gi->second];
-            bl.rows.push_back(ring ? ring_of[n] : ro->second[0]);
-            bl.params.insert(bl.params.end(), vm.params.begin(), vm.params.end());
-            bl.fast_ok = bl.fast_ok && vm.fast_ok;
+            add_voice(sp.banks, grp, vm, ring ? ring_of[n] : ro->second[0], ring);
         }
     }
 

@@ -18,7 +18,11 @@ struct BankLaunch {
     bool fast_ok = true;
     bool to_ring = false;            // rows are ring indices (window with look-back) instead of output rows
     std::vector<uint32_t> rows;      // destination row per voice
-    std::vector<float> params;       // [voices][P]{w, -4*amp}
+    std::vector<float> params;       // balanced: [voices][P]{w, -4*amp}; general: [groups][8]{w, -4*amp}
+    bool general = false;            // voices are arbitrary Sum2 trees evaluated by schedule (match.hpp VoiceMatch)
+    std::vector<uint32_t> groups;    // general: group words of all voices, concatenated
+    std::vector<uint32_t> group_off; // general: [voices + 1] first group of each voice
+    uint32_t max_leaves = 0;
 };
 
 struct StagedPlan {

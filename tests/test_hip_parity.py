@@ -423,3 +423,51 @@ def test_bank_from_composite_effect_instances(hip_lib, oracle_lib):
         assert same_bits(got, flat.fill_buffer(V, 0, T, [t]))
         plan = hip.plan()
         assert plan["pull_rows"] == 0 and plan["banks"][0]["voices"] == V and plan["banks"][0]["partials"] == P, plan
+
+
+# ---- voices that are not balanced power-of-two trees -------------------------------------------------------------------
+@pytest.mark.parametrize("V,P,T", [(2, 1000, 200), (3, 100, 130), (1, 24, 64), (2, 17, 70), (1, 4097, 65), (4, 255, 129)])
+def test_bank_general_partial_counts(hip_lib, oracle_lib, V, P, T):
+    """Partial counts that are not powers of two: the adjacent-pairs tree carries odd elements up, the planner cuts
+    it into complete sub-trees and a merge schedule (match.hpp), the schedule kernel evaluates it in the tree's order."""
+    tree = synth.additive_tree(V, P, seed=P, detune=True)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        for k, idx in enumerate([0, T, 5 * T]):
+            t = synth.time_ramp(idx, idx + T)
+            got, exp = hip.fill_buffer(V, idx, idx + T, [t]), ref.fill_buffer(V, idx, idx + T, [t])
+            assert same_bits(got, exp), f"call {k}: " + first_diff(got, exp)
+        plan = hip.plan()
+        assert plan["pull_rows"] == 0 and plan["stage_programs"] == 0, plan
+        assert plan["banks"][0]["general_tree"] and plan["banks"][0]["partials"] == P, plan
+
+
+def test_bank_unbalanced_trees(hip_lib, oracle_lib):
+    """A left-leaning chain (((l0+l1)+l2)+...), a chain of balanced blocks, and a balanced voice side by side; the
+    chain then feeds a Delay (general voice -> ring -> program)."""
+    g = synth.GraphArrays()
+    p = synth.voice_params(3, 64, seed=21, detune=True)
+    leaves = synth.partial_leaves(g, p["w"], p["amp"]).reshape(3, 64)
+    acc = leaves[0, 0:1]
+    for k in range(1, 40):                                   # left chain over 40 leaves
+        acc = g.binop(synth.K_SUM2, acc, leaves[0, k:k + 1], 1)
+    blocks = [synth.sum_tree(g, leaves[1:2, i:i + 8]) for i in range(0, 64, 8)]
+    chain2 = blocks[0]
+    for b in blocks[1:]:                                     # chain of 8-leaf balanced blocks
+        chain2 = g.binop(synth.K_SUM2, chain2, b, 1)
+    bal = synth.sum_tree(g, leaves[2:3, :])                  # ordinary balanced voice
+    d = g.binop(synth.K_SUM2, acc, g.binop(synth.K_DELAY, acc, synth.C(np.float32(9.0)), 1), 1)
+    for row, h in enumerate([acc, chain2, bal, d]):
+        g.edge(h, 0, 0, row)
+    tree = g.finish(4)
+    T = 150
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        for idx in (0, T):
+            t = synth.time_ramp(idx, idx + T)
+            got, exp = hip.fill_buffer(4, idx, idx + T, [t]), ref.fill_buffer(4, idx, idx + T, [t])
+            assert same_bits(got, exp), first_diff(got, exp)
+        plan = hip.plan()
+        assert plan["pull_rows"] == 0 and any(b["general_tree"] for b in plan["banks"]) and any(not b["general_tree"] for b in plan["banks"]), plan
