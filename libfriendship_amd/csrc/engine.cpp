@@ -324,7 +324,8 @@ struct fr_renderer {
                << ",\"to_ring\":" << (g.to_ring ? "true" : "false")
                << ",\"param_bytes\":" << g.params.size() * sizeof(float) << "}";
         }
-        js << "],\"stage_programs\":" << p.sp.progs.size() << ",\"stage_instrs\":" << p.sp.instrs.size()
+        js << "],\"stage_programs\":" << (p.sp.progs.size() - p.sp.fused_count) << ",\"stage_instrs\":" << p.sp.instrs.size()
+           << ",\"fused_programs\":" << p.sp.fused_count << ",\"fused_max_frames\":" << p.sp.fused_max_frames
            << ",\"stage_levels\":" << (p.sp.level_first.empty() ? 0 : p.sp.level_first.size() - 1)
            << ",\"rings\":" << p.sp.n_rings << ",\"max_lookback\":" << p.sp.lmax
            << ",\"pull_rows\":" << p.pull_rows.size() << "}";
@@ -417,13 +418,17 @@ struct fr_renderer {
         if (!sp.progs.empty()) {
             std::vector<DevInput> tab(sp.input_slots.size());
             for (size_t i = 0; i < tab.size(); ++i) tab[i] = dev_input(sp.input_slots[i]);
-            d_in_table_stage.ensure(std::max<size_t>(tab.size(), 1) * sizeof(DevInput));
-            if (!tab.empty()) {
+            if (tab.size() > STAGE_INLINE_INPUTS) {   // rare: more input slots than fit in the kernel arguments
+                d_in_table_stage.ensure(tab.size() * sizeof(DevInput));
                 HIP_CHECK(hipMemcpyAsync(d_in_table_stage.p, tab.data(), tab.size() * sizeof(DevInput), hipMemcpyHostToDevice, st));
                 HIP_CHECK(hipStreamSynchronize(st));   // `tab` is a stack object
             }
-            for (size_t l = 0; l + 1 < sp.level_first.size(); ++l) {
-                uint32_t first = sp.level_first[l], count = sp.level_first[l + 1] - first;
+            // Steady state: every delayed ring read of the fused form reaches at least fused_max_frames back, so the call
+            // is cut into sub-windows of that length, one fused launch each, when that takes fewer launches than levels.
+            const size_t n_levels = sp.level_first.size() - 1;
+            const uint64_t n_sub = sp.fused_count ? (n_times + sp.fused_max_frames - 1) / sp.fused_max_frames : 0;
+            const bool fused = sp.fused_count != 0 && w0 == idx && plan.stage_valid && n_sub < n_levels;
+            auto launch_range = [&](uint32_t first, uint32_t count, uint64_t s0, uint64_t slen) {
                 for (uint32_t off = 0; off < count; off += 65535u) {   // grid.y limit
                     StageArgs a{};
                     a.instrs = plan.d_instrs.as<StageInstr>();
@@ -433,15 +438,23 @@ struct fr_renderer {
                     a.ring_mask = ring_cap ? ring_cap - 1 : 0;
                     a.inputs = d_in_table_stage.as<DevInput>();
                     a.n_inputs = (uint32_t)tab.size();
+                    for (size_t i = 0; i < tab.size() && i < STAGE_INLINE_INPUTS; ++i) a.inline_inputs[i] = tab[i];
                     a.out = d_dst;
                     a.n_times = n_times;
                     a.idx = idx;
-                    a.w0 = w0;
-                    a.w_len = w_len;
+                    a.w0 = s0;
+                    a.w_len = slen;
                     Scope sc(this, &t_stage, st);
                     HIP_CHECK(launch_stage(a, st));
                     sc.done();
                 }
+            };
+            if (fused) {
+                for (uint64_t s0 = idx; s0 < idx + n_times; s0 += sp.fused_max_frames)
+                    launch_range(sp.fused_first, sp.fused_count, s0, std::min<uint64_t>(sp.fused_max_frames, idx + n_times - s0));
+            } else {
+                for (size_t l = 0; l < n_levels; ++l)
+                    launch_range(sp.level_first[l], sp.level_first[l + 1] - sp.level_first[l], w0, w_len);
             }
         }
         if (sp.uses_rings()) {

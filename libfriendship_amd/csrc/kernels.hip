@@ -589,6 +589,13 @@ hipError_t launch_gbank(const BankArgs &a, hipStream_t s) {
 // form of the reference's "re-evaluate the source at t - d" (reference.rs:213-215): the ring holds exactly the
 // values that re-evaluation would produce, because it was filled by the same graph from the same input history.
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float stage_input(const StageArgs &a, uint32_t slot, uint64_t t) {
+    if (slot >= a.n_inputs) return 0.0f;
+    DevInput s = a.n_inputs <= STAGE_INLINE_INPUTS ? a.inline_inputs[slot] : a.inputs[slot];
+    if (t < s.base || t >= s.len) return 0.0f;
+    return s.data[t - s.base];
+}
+
 __global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
     __shared__ float tmp[STAGE_REGS][256];
     const uint64_t wi = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -601,14 +608,15 @@ __global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
         float v;
         switch (in.op) {
         case S_CONST: v = __uint_as_float(in.imm); break;
-        case S_INPUT: v = read_input(a.inputs, a.n_inputs, in.imm, t); break;
+        case S_INPUT: v = stage_input(a, in.imm, t); break;
         case S_READ: v = t >= in.d_lo ? a.rings[(size_t)in.buf * (a.ring_mask + 1) + ((t - in.d_lo) & a.ring_mask)] : 0.0f; break;
-        case S_READ_INPUT: v = t >= in.d_lo ? read_input(a.inputs, a.n_inputs, in.imm, t - in.d_lo) : 0.0f; break;
+        case S_READ_INPUT: v = t >= in.d_lo ? stage_input(a, in.imm, t - in.d_lo) : 0.0f; break;
         case S_STEP: v = t >= in.d_lo ? __uint_as_float(in.imm) : 0.0f; break;
         case S_SUM2: v = tmp[in.a][tid] + tmp[in.b][tid]; break;
         case S_MUL: v = tmp[in.a][tid] * tmp[in.b][tid]; break;
         case S_DIV: v = tmp[in.a][tid] / tmp[in.b][tid]; break;
         case S_MOD: v = prim_mod(tmp[in.a][tid], tmp[in.b][tid]); break;
+        case S_STORE: a.rings[(size_t)in.buf * (a.ring_mask + 1) + (t & a.ring_mask)] = tmp[in.a][tid]; continue;
         default: v = prim_min(tmp[in.a][tid], tmp[in.b][tid]); break;
         }
         tmp[in.dst][tid] = v;

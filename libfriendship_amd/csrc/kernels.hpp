@@ -83,6 +83,7 @@ enum StageOp : uint8_t {
     S_READ_INPUT = 3,  // dst = t >= d ? input[imm] at t - d : 0
     S_STEP = 4,        // dst = t >= d ? bits(imm) : 0                           Delay of a constant
     S_SUM2 = 5, S_MUL = 6, S_DIV = 7, S_MOD = 8, S_MIN = 9,   // dst = a op b
+    S_STORE = 10,      // ring[buf][t & mask] = a        (fused form: an inlined cut node still feeds its ring)
 };
 struct StageInstr {    // 16 bytes
     uint8_t op, dst, a, b;
@@ -98,13 +99,15 @@ struct StageProg {
     uint32_t pad[3];
 };
 constexpr int STAGE_REGS = 48;
+constexpr uint32_t STAGE_INLINE_INPUTS = 8;
 struct StageArgs {
     const StageInstr *instrs;
     const StageProg *progs;    // programs of this level
     uint32_t n_progs;
     float *rings;              // [n_rings][ring_mask + 1]
     uint64_t ring_mask;
-    const DevInput *inputs;
+    const DevInput *inputs;    // [n_inputs] in device memory, used when n_inputs > STAGE_INLINE_INPUTS
+    DevInput inline_inputs[8]; // the usual case: the table travels in the kernel arguments (no copy, no sync)
     uint32_t n_inputs;
     float *out;                // [n_slots, n_times] of the call
     uint64_t n_times;

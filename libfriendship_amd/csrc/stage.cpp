@@ -117,9 +117,19 @@ struct ProgBuild {
 };
 
 // Emits the program computing cut node `m`.  Returns false if it does not fit the budgets.
+// fuse == false: other cut nodes are read from their rings (level-by-level mode).
+// fuse == true:  program cut nodes used at the SAME frame are computed inline (and stored to their ring with S_STORE
+//                when `stored` says they have one), so that only delayed reads touch rings; `min_delay` receives the
+//                smallest delay with which a program cut node's ring is read (the fused mode is valid for calls of at
+//                most that many frames, in steady state).
 bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unordered_map<uint32_t, uint32_t> &dense_input,
-                   std::vector<uint32_t> &input_slots, ProgBuild &out) {
-    auto is_boundary = [&](uint32_t n) { return n != m && (P.cut.count(n) || P.bank_of.count(n)); };
+                   std::vector<uint32_t> &input_slots, ProgBuild &out, bool fuse = false,
+                   const std::unordered_set<uint32_t> *stored = nullptr, uint64_t *min_delay = nullptr) {
+    auto is_boundary = [&](uint32_t n) {
+        if (n == m) return false;
+        if (P.bank_of.count(n)) return true;
+        return !fuse && P.cut.count(n) != 0;
+    };
     // post-order over the expression DAG inside this stage
     std::vector<uint32_t> order;
     std::unordered_map<uint32_t, uint32_t> uses;
@@ -166,7 +176,10 @@ bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unorde
             in.d_lo = (uint32_t)d;
             if (src.op == OP_CONST) { in.op = S_STEP; in.imm = src.a; }
             else if (src.op == OP_INPUT) { in.op = S_READ_INPUT; in.imm = dense(src.a); }
-            else { in.op = S_READ; in.buf = x.a; out.reads.push_back({x.a, d}); }
+            else {
+                in.op = S_READ; in.buf = x.a; out.reads.push_back({x.a, d});
+                if (min_delay && !P.bank_of.count(x.a)) *min_delay = std::min(*min_delay, d);
+            }
         } else {
             switch (x.op) {
             case OP_SUM2: in.op = S_SUM2; break;
@@ -185,6 +198,11 @@ bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unorde
         free_regs.pop_back();
         reg_of[n] = in.dst;
         out.instrs.push_back(in);
+        if (fuse && n != m && P.cut.count(n) && stored && stored->count(n)) {   // an inlined cut node still feeds its ring
+            StageInstr stx{};
+            stx.op = S_STORE; stx.a = in.dst; stx.buf = n;
+            out.instrs.push_back(stx);
+        }
     }
     out.result_reg = reg_of.at(m);
     return true;
@@ -330,6 +348,60 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         ++sp.level_first[pd.level + 1];
     }
     for (size_t l = 1; l < sp.level_first.size(); ++l) sp.level_first[l] += sp.level_first[l - 1];
+
+    // Fused steady-state form: one launch.  Sinks = cut nodes no other program uses at the same frame; everything they
+    // use at the same frame is computed inline.  Worth it only if the level form needs more than one launch.
+    if (max_level >= 2) {
+        std::unordered_set<uint32_t> same_frame_used;
+        for (auto &kv : built)
+            for (auto &rd : kv.second.reads)
+                if (rd.second == 0 && !P.bank_of.count(rd.first)) same_frame_used.insert(rd.first);
+        uint64_t min_delay = ~0ull;
+        bool fits = true;
+        std::vector<StageInstr> finstrs;
+        std::vector<StageProg> fprogs;
+        auto emit = [&](const ProgBuild &pb, uint32_t dst_ring, int32_t out_row) {
+            StageProg pg{};
+            pg.first_instr = (uint32_t)(sp.instrs.size() + finstrs.size());
+            pg.n_instr = (uint32_t)pb.instrs.size();
+            pg.result_reg = pb.result_reg;
+            pg.dst_ring = dst_ring;
+            pg.out_row = out_row;
+            for (StageInstr in : pb.instrs) {
+                if (in.op == S_READ || in.op == S_STORE) in.buf = ring_of.at(in.buf);
+                finstrs.push_back(in);
+            }
+            fprogs.push_back(pg);
+        };
+        for (uint32_t m : cuts) {
+            auto ro = rows_of.find(m);
+            bool sink = !same_frame_used.count(m);
+            // a non-sink with output rows still needs those rows written: compute it as its own (fused) program too
+            if (!sink && ro == rows_of.end()) continue;
+            ProgBuild pb;
+            if (!build_program(g, P, m, dense_input, sp.input_slots, pb, true, &needs_ring, &min_delay)) { fits = false; break; }
+            emit(pb, needs_ring.count(m) ? ring_of[m] : NO_RING, ro != rows_of.end() ? (int32_t)ro->second[0] : -1);
+            if (ro != rows_of.end())
+                for (size_t i = 1; i < ro->second.size(); ++i) emit(pb, NO_RING, (int32_t)ro->second[i]);   // extra rows: recompute
+        }
+        for (auto &kv : rows_of) {   // bank roots that live in a ring: copy programs, as in the level form
+            if (!P.bank_of.count(kv.first) || !needs_ring.count(kv.first)) continue;
+            for (uint32_t row : kv.second) {
+                ProgBuild pb;
+                StageInstr in{};
+                in.op = S_READ; in.buf = kv.first; in.dst = 0;
+                pb.instrs.push_back(in);
+                emit(pb, NO_RING, (int32_t)row);
+            }
+        }
+        if (fits && !fprogs.empty() && min_delay >= 64) {
+            sp.fused_first = (uint32_t)sp.progs.size();
+            sp.fused_count = (uint32_t)fprogs.size();
+            sp.fused_max_frames = min_delay;
+            sp.instrs.insert(sp.instrs.end(), finstrs.begin(), finstrs.end());
+            sp.progs.insert(sp.progs.end(), fprogs.begin(), fprogs.end());
+        }
+    }
     std::sort(sp.pull_rows.begin(), sp.pull_rows.end());
     return sp;
 }

@@ -30,6 +30,10 @@ struct StagedPlan {
     std::vector<StageInstr> instrs;
     std::vector<StageProg> progs;          // ordered by level
     std::vector<uint32_t> level_first;     // level l = progs[level_first[l] .. level_first[l+1])
+    // fused steady-state form (optional): progs[fused_first .. fused_first + fused_count) do the work of all levels in
+    // one launch; valid when the rings are current and the call is at most fused_max_frames long
+    uint32_t fused_first = 0, fused_count = 0;
+    uint64_t fused_max_frames = 0;
     uint32_t n_rings = 0;
     uint64_t lmax = 0;                     // deepest look-back any ring must serve
     std::vector<uint32_t> input_slots;     // dense input index used by programs -> external slot

@@ -471,3 +471,17 @@ def test_bank_unbalanced_trees(hip_lib, oracle_lib):
             assert same_bits(got, exp), first_diff(got, exp)
         plan = hip.plan()
         assert plan["pull_rows"] == 0 and any(b["general_tree"] for b in plan["banks"]) and any(not b["general_tree"] for b in plan["banks"]), plan
+
+
+def test_fused_stage_mode_equals_level_mode(hip_lib, oracle_lib):
+    """Steady-state calls no longer than the shortest ring delay run every delay level in ONE launch (sub-windows of
+    that length when the call is longer); first call, seek and edits use the level-by-level form.  Same bits."""
+    V, P, T = 3, 64, 100
+    tree = synth.effects_tree(V, P, taps=3, base_delay=70.0)   # delays 70, 140, 210: fused in sub-windows of 70 frames
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        _effects_sequence(hip, ref, V, T, calls=6, seek_to=40 * T)
+        _effects_sequence(hip, ref, V, 64, calls=3)            # seek back to 0 with a shorter call length
+        plan = hip.plan()
+        assert plan["fused_programs"] > 0 and plan["fused_max_frames"] == 70, plan
