@@ -128,17 +128,28 @@ def main():
     log(f"[rank {rank}] graph: {len(tree['handles'])} nodes, {len(tree['edges'])} edges, "
         f"installed in {time.perf_counter() - t_build:.1f}s")
 
-    # this rank's stripe of frames; every step's time-ramp row is already resident in HBM
+    # this rank's stripe of frames; every step's time-ramp row is already resident in HBM.  The ramp is the f32 frame
+    # number, exact below 2^24, so its VALUES wrap at 2^23 (idx itself, a u64, keeps counting); rows live in a ring of
+    # at most 64 steps so that any --steps fits in memory.
     n_calls = W + K
     stripe0 = rank * n_calls * T if shard_mode == "time" else 0
-    assert stripe0 + n_calls * T < (1 << 24), "f32 frame ramp is exact only below 2^24 frames"
-    d_time = torch.from_numpy(synth.time_ramp(stripe0, stripe0 + n_calls * T)).cuda()
+    ring_steps = min(n_calls, 64)
+    WRAP = 1 << 23
+
+    def ramp_row(k):
+        f0 = stripe0 + k * T
+        return (np.arange(f0, f0 + T, dtype=np.int64) % WRAP).astype(np.float32)
+
+    d_time = torch.from_numpy(np.concatenate([ramp_row(k) for k in range(ring_steps)])).cuda()
+    if n_calls > ring_steps:   # later steps reuse ring rows: keep their values consistent with ramp_row(k) only modulo the ring
+        log(f"[rank {rank}] {n_calls} calls share a ring of {ring_steps} resident input rows")
     d_out = torch.empty((max(V_local, 1), T), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     d_mixes = [torch.empty_like(d_out) for _ in range(world)] if shard_mode == "partials" else None
 
     def step(k):
-        row = d_time[k * T:(k + 1) * T]
+        r = k % ring_steps
+        row = d_time[r * T:(r + 1) * T]
         hip.fill_buffer_device(d_out.data_ptr(), V_local, T, stripe0 + k * T, row.data_ptr(), [0, T], stream)
         if shard_mode == "partials":
             # the one exchange step of the path: every rank's partial mix to every rank (RCCL over xGMI), then the
@@ -192,11 +203,10 @@ def main():
     # reported as an extra, never as `value`
     host_rate = None
     if rank == 0:
-        ramp = synth.time_ramp(stripe0, stripe0 + 6 * T)
-        hip.fill_buffer(V_local, stripe0, stripe0 + T, [ramp[:T]])
+        hip.fill_buffer(V_local, stripe0, stripe0 + T, [ramp_row(0)])
         th = time.perf_counter()
         for k in range(1, 6):
-            hip.fill_buffer(V_local, stripe0 + k * T, stripe0 + (k + 1) * T, [ramp[k * T:(k + 1) * T]])
+            hip.fill_buffer(V_local, stripe0 + k * T, stripe0 + (k + 1) * T, [ramp_row(k)])
         host_rate = 5 * T / (time.perf_counter() - th) / 1e6
 
     if rank != 0:
