@@ -73,8 +73,8 @@ def cpu_baseline(tree, V, P, frames_1t, frames_mt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--voices", type=int, default=64)
     ap.add_argument("--partials", type=int, default=4096)
     ap.add_argument("--frames", type=int, default=4800, help="frames per fill_buffer call (T)")

@@ -182,8 +182,9 @@ struct fr_renderer {
     // the caller's row directly and appends it to the history itself (BankArgs::hist_dst).
     struct Deferred { uint32_t slot; const float *src; float *dst; };
     std::vector<Deferred> deferred;
-    bool bank_time_slot(uint32_t n_slots, uint32_t slot) const {
+    bool bank_time_slot(uint32_t n_slots, uint64_t n_times, uint32_t slot) const {
         if (!plan.valid || plan.version != mirror.version || plan.n_slots != n_slots) return false;
+        if (n_times <= 2) return false;   // the shortest calls use bank_small_kernel, which does not append history
         if (plan.sp.uses_rings() || !plan.sp.progs.empty()) return false;   // windows with look-back read the stored history
         bool any = false;
         for (const BankStage &bs : plan.banks) {
@@ -223,7 +224,7 @@ struct fr_renderer {
             uint64_t stored = s.len - s.base;
             grow(s, stored + n_times, st);
             float *dst = s.buf.as<float>() + stored;
-            if (device_rows && rl == n_times && rl > 0 && bank_time_slot(n_slots, r)) {
+            if (device_rows && rl == n_times && rl > 0 && bank_time_slot(n_slots, n_times, r)) {
                 deferred.push_back(Deferred{r, in_data + offs[r], dst});
             } else if (device_rows) {
                 if (rl) HIP_CHECK(hipMemcpyAsync(dst, in_data + offs[r], rl * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -404,7 +405,8 @@ struct fr_renderer {
                 sc.done();
                 continue;
             }
-            bank_shape(a.log2_p, a.n_voices, blen, a.chunk_log2, a.frames_per_lane, a.waves_per_group);
+            bank_shape(a.log2_p, a.n_voices, blen, a.chunk_log2, a.frames_per_lane, a.waves_per_group, a.small_call);
+            if (a.small_call && a.hist_dst) throw Error(FR_ERR_DEVICE, "internal: deferred history append on a short call");
             a.leaf_variant = bank_leaf_variant;
             if (a.chunk_log2 != a.log2_p) {
                 d_bank_ws.ensure(((size_t)a.n_voices << (a.log2_p - a.chunk_log2)) * blen * sizeof(float));

@@ -393,6 +393,52 @@ __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tile
     }
 }
 
+// Short calls (fewer frames than half a wave has lanes): time-major lanes would idle, so here lanes run over
+// PARTIALS -- the layout the north star sketches: coalesced float2 loads of each partial's {w, A4} (held in
+// registers for the call's frames), a wavefront-shuffle butterfly for the per-voice mix, LDS for the 4 waves.
+// The butterfly IS the graph's balanced tree: at step m lane i adds the sub-tree sum of lanes i^m, and f32 add is
+// bitwise commutative, so after 6 steps every lane holds the tree-ordered sum of its wave's 64 consecutive
+// partials.  A workgroup covers 256 consecutive partials of one voice; chunks combine with bank_combine_kernel.
+constexpr uint32_t SMALL_MAX_FRAMES = 32;   // capacity of the kernel; bank_shape uses it for T <= 2 only (measured)
+
+__global__ void __launch_bounds__(256) bank_small_kernel(BankArgs a) {
+    const uint32_t chunk = blockIdx.x, voice = blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t nchunks = 1u << (a.log2_p - 8u);
+    const float2 prm = a.params[((size_t)voice << a.log2_p) + (size_t)chunk * 256u + threadIdx.x];
+    __shared__ float sm[4][SMALL_MAX_FRAMES];
+    __shared__ uint32_t zmask;
+    for (uint32_t ti = 0; ti < (uint32_t)a.n_times; ++ti) {
+        const float t = bank_time(a, ti);                                  // wave-uniform
+        const bool fast = a.fast_ok && t >= 0.0f && t <= 4294967296.0f;
+        float v = fast ? bank_leaf<true, false>(t, prm.x, prm.y) : bank_leaf<false, false>(t, prm.x, prm.y);
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m, 64);
+        if (lane == 0) sm[wave][ti] = v;
+    }
+    if (threadIdx.x == 0) zmask = 0u;
+    __syncthreads();
+    const bool direct = nchunks == 1u;
+    float *orow = direct ? a.out + (size_t)a.rows[voice] * a.out_stride
+                         : a.ws + ((size_t)chunk * a.n_voices + voice) * a.n_times;
+    if (threadIdx.x < a.n_times) {
+        const uint32_t ti = threadIdx.x;
+        float r = (sm[0][ti] + sm[1][ti]) + (sm[2][ti] + sm[3][ti]);
+        orow[direct ? bank_out_index(a, ti) : ti] = r;
+        if (r == 0.0f) atomicOr(&zmask, 1u << ti);
+    }
+    __syncthreads();
+    uint32_t zm = zmask;                                                   // workgroup-uniform
+    while (zm) {   // the sign of a zero: -0 iff each of this workgroup's 256 leaves is -0 in the graph's arithmetic
+        uint32_t ti = (uint32_t)__builtin_ctz(zm);
+        zm &= zm - 1;
+        float tz = bank_time(a, ti);
+        bool neg = __float_as_uint(bank_leaf<false, true>(tz, prm.x, prm.y)) == 0x80000000u;
+        int all = __syncthreads_and(neg ? 1 : 0);
+        if (threadIdx.x == 0) orow[direct ? bank_out_index(a, ti) : ti] = all ? -0.0f : 0.0f;
+    }
+}
+
 // Upper levels of the voice's Sum2 tree when a voice was split over several workgroups:
 // out[v][t] = TREE_c ws[c][v][t], same binary-counter association, one thread per (v, t).
 __global__ void __launch_bounds__(256) bank_combine_kernel(BankArgs a) {
@@ -449,24 +495,42 @@ static hipError_t launch_bank_f(const BankArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Chooses how a voice's partials are split over workgroups for this call's shape.  Measured on MI355X
-// (tools/bank_bench.hip, profiles/r01_bank_variants.txt): one 64-frame tile per wave (F = 1) is never
-// slower than 2 or 4; whole voices per workgroup (<= 8192 partials) win as soon as that yields ~512
-// workgroups (2 per CU); below that, splitting partials into chunks (+ one combine pass) pays.
+// Chooses the launch shape for this call.  Measured on MI355X at 64 voices x 4096 partials
+// (tools/bank_bench.hip, profiles/r01_bank_variants.txt, profiles/r01_bank_small_calls.txt):
+//  * one 64-frame tile per wave (F = 1) is never slower than 2 or 4;
+//  * long calls (>= 512 workgroups): 4 waves x 1024 partials per workgroup; 8 waves measured equal;
+//  * short calls: ONE workgroup of 8 waves per (voice, tile) beats splitting voices into chunks + a combine
+//    pass (T = 32: 13.9 us vs 31 us) and beats the lanes-over-partials kernel from T = 8 up (13.8 vs 17.4 us;
+//    T = 32: 13.9 vs 37 us); lanes-over-partials only ties at T = 1 (11.4 us), so it is used for T <= 2;
+//  * voices larger than one workgroup's capacity (8192 / 16384 partials) are split into chunks.
 void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane,
-                uint32_t &waves_per_group) {
-    const uint64_t want_blocks = 512;
-    // 8 waves per workgroup only where that keeps a 16384-partial voice in one workgroup (no combine pass);
-    // at 4096 partials 4 and 8 waves measured equal
-    waves_per_group = log2_p >= 14 ? 8 : 4;
-    const uint32_t cmin = waves_per_group == 8 ? 6 : 5, cmax = waves_per_group == 8 ? 14 : 13;
-    chunk_log2 = log2_p < cmax ? log2_p : cmax;
+                uint32_t &waves_per_group, uint32_t &small_call) {
     frames_per_lane = 1;
-    auto blocks = [&](uint32_t cl) { return ((n_times + 63) / 64) * n_voices << (log2_p - cl); };
-    while (chunk_log2 > cmin && blocks(chunk_log2) < want_blocks) --chunk_log2;
+    small_call = (n_times <= 2 && log2_p >= 8 && n_voices <= 65535u) ? 1u : 0u;
+    if (small_call) {
+        chunk_log2 = 8;
+        waves_per_group = 4;
+        return;
+    }
+    const uint64_t blocks = ((n_times + 63) / 64) * n_voices;
+    waves_per_group = (log2_p >= 14 || (blocks < 512 && log2_p >= 6)) ? 8 : 4;
+    const uint32_t cmax = waves_per_group == 8 ? 14 : 13;
+    chunk_log2 = log2_p < cmax ? log2_p : cmax;
 }
 
 hipError_t launch_bank(const BankArgs &a, hipStream_t s) {
+    if (a.small_call) {   // lanes over partials
+        if (a.log2_p < 8 || a.log2_p > 24 || a.n_times > SMALL_MAX_FRAMES || a.chunk_log2 != 8) return hipErrorInvalidValue;
+        if (a.log2_p != 8 && !a.ws) return hipErrorInvalidValue;
+        if (a.n_times == 0 || a.n_voices == 0) return hipSuccess;
+        if (a.n_voices > 65535u) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(bank_small_kernel, dim3(1u << (a.log2_p - 8u), a.n_voices), dim3(256), 0, s, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || a.log2_p == 8) return e;
+        uint64_t total = (uint64_t)a.n_voices * a.n_times;
+        hipLaunchKernelGGL(bank_combine_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     if (a.waves_per_group != 4 && a.waves_per_group != 8) return hipErrorInvalidValue;
     const uint32_t cmin = a.waves_per_group == 8 ? 6 : 5, cmax = a.waves_per_group == 8 ? 14 : 13;
     if (a.log2_p < cmin || a.log2_p > 24 || a.chunk_log2 < cmin || a.chunk_log2 > cmax || a.chunk_log2 > a.log2_p)

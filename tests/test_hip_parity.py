@@ -485,3 +485,46 @@ def test_fused_stage_mode_equals_level_mode(hip_lib, oracle_lib):
         _effects_sequence(hip, ref, V, 64, calls=3)            # seek back to 0 with a shorter call length
         plan = hip.plan()
         assert plan["fused_programs"] > 0 and plan["fused_max_frames"] == 70, plan
+
+
+@pytest.mark.parametrize("V,P,T", [(2, 256, 1), (3, 1024, 7), (1, 4096, 32), (5, 512, 16), (2, 8192, 3)])
+def test_bank_short_calls(hip_lib, oracle_lib, V, P, T):
+    """Calls of <= 32 frames use the lanes-over-partials kernel (wavefront-shuffle tree + LDS + chunk combine)."""
+    tree = synth.additive_tree(V, P, seed=P + T, detune=True)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        idx = 0
+        for k in range(4):   # includes frame 0 (all phases zero: the zero-sign repair) and a longer call in between
+            n = T if k != 2 else 100
+            t = synth.time_ramp(idx, idx + n)
+            got, exp = hip.fill_buffer(V, idx, idx + n, [t]), ref.fill_buffer(V, idx, idx + n, [t])
+            assert same_bits(got, exp), f"call {k}: " + first_diff(got, exp)
+            idx += n
+        assert hip.plan()["pull_rows"] == 0
+
+
+def test_short_device_calls_keep_history(hip_lib, oracle_lib):
+    """Short device-resident calls must still append the time row to the input history (no deferred append there)."""
+    import torch
+    g = synth.GraphArrays()
+    p = synth.voice_params(1, 256, seed=5)
+    root = synth.sum_tree(g, synth.partial_leaves(g, p["w"], p["amp"]).reshape(1, 256))
+    g.edge(root, 0, 0, 0)
+    d = g.binop(synth.K_DELAY, synth.IN(0), synth.C(np.float32(20.0)), 1)
+    g.edge(d, 0, 0, 1)
+    tree = g.finish(2)
+    T = 16
+    t = synth.time_ramp(0, 6 * T)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        d_t = torch.from_numpy(t).cuda()
+        d_out = torch.empty((2, T), dtype=torch.float32, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        for k in range(6):
+            row = d_t[k * T:(k + 1) * T]
+            hip.fill_buffer_device(d_out.data_ptr(), 2, T, k * T, row.data_ptr(), [0, T], s)
+            torch.cuda.synchronize()
+            exp = ref.fill_buffer(2, k * T, (k + 1) * T, [t[k * T:(k + 1) * T]])
+            assert same_bits(d_out.cpu().numpy(), exp), f"call {k}: " + first_diff(d_out.cpu().numpy(), exp)
