@@ -53,7 +53,7 @@ struct Matcher {
     }
 
     bool match_q(uint32_t q, uint32_t u) const {
-        uint32_t n1, absu, m, nu_chk;
+        uint32_t n1 = 0, absu = 0, m = 0, nu_chk = 0;
         if (!bin_const(q, OP_SUM2, 0.5f, n1)) return false;
         if (!bin_const(n1, OP_MUL, -1.0f, absu)) return false;
         if (!bin_const(absu, OP_MUL, -1.0f, m)) return false;

@@ -1,0 +1,489 @@
+// plan_tests.cpp -- CPU tests of the engine's HOST logic (no GPU, no kernels): graph mirror, lowering, bank
+// recognition, staged planning.  The lowered graph and the staged plan are executed by small interpreters written
+// here (test code, mirroring what pull_kernel / stage_kernel / bank kernels do) and compared bit-for-bit with the CPU
+// oracle rendering the same graph through the C ABI.  That proves the planner's output *means* what the reference
+// means before any kernel runs it.
+//
+// Build: g++ -std=c++17 -O1 -ffp-contract=off -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -o plan_tests plan_tests.cpp -ldl
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <random>
+
+#include "../../libfriendship_amd/csrc/graph.cpp"
+#include "../../libfriendship_amd/csrc/match.cpp"
+#include "../../libfriendship_amd/csrc/stage.cpp"
+
+using namespace fr;
+
+#define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "%s:%d: CHECK failed: %s\n", __FILE__, __LINE__, #c); throw std::runtime_error("check failed"); } } while (0)
+
+// ---- the oracle, loaded as a plugin (same C ABI) ---------------------------------------------------------
+struct Oracle {
+    void *dl;
+    decltype(&fr_renderer_create) create;
+    decltype(&fr_renderer_destroy) destroy;
+    decltype(&fr_on_add_node) add_node;
+    decltype(&fr_on_add_edge) add_edge;
+    decltype(&fr_fill_buffer) fill;
+    Oracle() {
+        const char *p = std::getenv("FRIENDSHIP_ORACLE_LIB");
+        dl = dlopen(p ? p : "oracle/_build/libfr_oracle.so", RTLD_NOW | RTLD_LOCAL);
+        if (!dl) throw std::runtime_error("cannot load the oracle library");
+        create = (decltype(create))dlsym(dl, "fr_renderer_create");
+        destroy = (decltype(destroy))dlsym(dl, "fr_renderer_destroy");
+        add_node = (decltype(add_node))dlsym(dl, "fr_on_add_node");
+        add_edge = (decltype(add_edge))dlsym(dl, "fr_on_add_edge");
+        fill = (decltype(fill))dlsym(dl, "fr_fill_buffer");
+    }
+};
+static Oracle &oracle() { static Oracle o; return o; }
+
+// ---- graph builder: records primitive nodes + edges, applies them to a Mirror and to an oracle renderer ----
+struct Operand { int kind; uint32_t v; };   // 0 = node handle, 1 = constant bits, 2 = input slot, 3 = unconnected
+static Operand N(uint32_t h) { return {0, h}; }
+static Operand Cf(float f) { return {1, f32_to_bits(f)}; }
+static Operand In(uint32_t s) { return {2, s}; }
+static Operand None() { return {3, 0}; }
+
+struct Build {
+    std::vector<std::pair<uint32_t, int>> nodes{{1, FR_PRIM_F32CONSTANT}};
+    std::vector<fr_edge> edges;
+    uint32_t next = 2;
+    uint32_t op(int kind, Operand a, Operand b) {
+        uint32_t h = next++;
+        nodes.push_back({h, kind});
+        Operand ops[2] = {a, b};
+        for (uint32_t s = 0; s < 2; ++s) {
+            if (ops[s].kind == 0) edges.push_back({ops[s].v, h, 0, s});
+            else if (ops[s].kind == 1) edges.push_back({1, h, ops[s].v, s});
+            else if (ops[s].kind == 2) edges.push_back({0, h, ops[s].v, s});
+        }
+        return h;
+    }
+    void out(Operand src, uint32_t slot) {
+        if (src.kind == 0) edges.push_back({src.v, 0, 0, slot});
+        else if (src.kind == 1) edges.push_back({1, 0, src.v, slot});
+        else if (src.kind == 2) edges.push_back({0, 0, src.v, slot});
+    }
+    void apply(Mirror &m) const {
+        for (auto &n : nodes) { fr_effect e{}; e.kind = n.second; m.add_node(n.first, &e); }
+        for (auto &e : edges) m.add_edge(e);
+    }
+    fr_renderer *apply_oracle() const {
+        fr_renderer *r = nullptr;
+        CHECK(oracle().create(nullptr, &r) == FR_OK);
+        for (auto &n : nodes) { fr_effect e{}; e.kind = n.second; CHECK(oracle().add_node(r, n.first, &e) == FR_OK); }
+        for (auto &e : edges) CHECK(oracle().add_edge(r, &e) == FR_OK);
+        return r;
+    }
+};
+
+// the 11-node partial and the adjacent-pairs tree (same definitions as libfriendship_amd/synth.py)
+static uint32_t partial(Build &b, float w, float amp) {
+    uint32_t x = b.op(FR_PRIM_MULTIPLY, In(0), Cf(w));
+    uint32_t ph = b.op(FR_PRIM_MODULO, N(x), Cf(1.0f));
+    uint32_t u = b.op(FR_PRIM_SUM2, N(ph), Cf(-0.5f));
+    uint32_t nu = b.op(FR_PRIM_MULTIPLY, Cf(-1.0f), N(u));
+    uint32_t m = b.op(FR_PRIM_MINIMUM, N(u), N(nu));
+    uint32_t ab = b.op(FR_PRIM_MULTIPLY, Cf(-1.0f), N(m));
+    uint32_t n1 = b.op(FR_PRIM_MULTIPLY, Cf(-1.0f), N(ab));
+    uint32_t q = b.op(FR_PRIM_SUM2, Cf(0.5f), N(n1));
+    uint32_t p = b.op(FR_PRIM_MULTIPLY, Cf(-16.0f), N(u));
+    uint32_t y = b.op(FR_PRIM_MULTIPLY, N(p), N(q));
+    return b.op(FR_PRIM_MULTIPLY, Cf(amp), N(y));
+}
+static uint32_t sum_tree(Build &b, std::vector<uint32_t> cur) {
+    while (cur.size() > 1) {
+        std::vector<uint32_t> nx;
+        for (size_t i = 0; i + 1 < cur.size(); i += 2) nx.push_back(b.op(FR_PRIM_SUM2, N(cur[i]), N(cur[i + 1])));
+        if (cur.size() % 2) nx.push_back(cur.back());
+        cur = nx;
+    }
+    return cur[0];
+}
+static uint32_t voice(Build &b, int P, float f0, std::mt19937 &rng) {
+    std::vector<uint32_t> leaves;
+    std::uniform_real_distribution<float> det(-0.005f, 0.005f);
+    for (int k = 0; k < P; ++k) leaves.push_back(partial(b, f0 * (k + 1) * (1.0f + det(rng)) / 48000.0f, 1.0f / (k + 1)));
+    return sum_tree(b, leaves);
+}
+
+// ---- interpreters of the planner's outputs ----------------------------------------------------------------
+using Inputs = std::vector<std::vector<float>>;   // per slot, absolute time from 0; beyond the end -> 0
+static float in_at(const Inputs &in, uint32_t slot, uint64_t t) { return slot < in.size() && t < in[slot].size() ? in[slot][t] : 0.0f; }
+
+// value of a lowered node at time t: the reference's recursion on the flat graph
+static float flat_eval(const FlatGraph &g, uint32_t id, uint64_t t, const Inputs &in) {
+    const FlatNode &n = g.nodes[id];
+    switch (n.op) {
+    case OP_CONST: return f32_from_bits(n.a);
+    case OP_INPUT: return in_at(in, n.a, t);
+    case OP_DELAY: {
+        float d = flat_eval(g, n.b, t, in);
+        if (d >= 18446744073709551616.0f) return 0.0f;
+        uint64_t fr_ = (d < 0.0f || d != d) ? 0 : (uint64_t)d;
+        return fr_ > t ? 0.0f : flat_eval(g, n.a, t - fr_, in);
+    }
+    default: return host_binop((FlatOp)n.op, flat_eval(g, n.a, t, in), flat_eval(g, n.b, t, in));
+    }
+}
+
+// the bank leaf exactly as kernels.hip's product form (EXACT = true, general fract)
+static float leaf_host(float t, float w, float A4) {
+    float x = t * w;
+    float r = x - std::trunc(x);
+    r = r < 0.0f ? r + 1.0f : r;
+    float u = r - 0.5f;
+    float q = 0.5f - std::fabs(u);
+    float z = u * q;
+    return (4.0f * A4) * z;
+}
+static float bank_voice_host(const BankLaunch &bl, size_t v, float t) {
+    if (!bl.general) {
+        size_t P = (size_t)1 << bl.log2_p;
+        std::vector<float> cur(P);
+        for (size_t k = 0; k < P; ++k) cur[k] = leaf_host(t, bl.params[(v * P + k) * 2], bl.params[(v * P + k) * 2 + 1]);
+        while (cur.size() > 1) {
+            std::vector<float> nx(cur.size() / 2);
+            for (size_t i = 0; i < nx.size(); ++i) nx[i] = cur[2 * i] + cur[2 * i + 1];
+            cur = nx;
+        }
+        return cur[0];
+    }
+    std::vector<float> st;
+    for (uint32_t g = bl.group_off[v]; g < bl.group_off[v + 1]; ++g) {
+        uint32_t j = bl.groups[g] & 15u, m = bl.groups[g] >> 4;
+        float l[8];
+        for (int k = 0; k < 8; ++k) l[k] = leaf_host(t, bl.params[((size_t)g * 8 + k) * 2], bl.params[((size_t)g * 8 + k) * 2 + 1]);
+        float val = l[0];
+        if (j >= 1) val = l[0] + l[1];
+        if (j >= 2) val = val + (l[2] + l[3]);
+        if (j >= 3) val = val + ((l[4] + l[5]) + (l[6] + l[7]));
+        for (; m; --m) { val = st.back() + val; st.pop_back(); }
+        st.push_back(val);
+    }
+    CHECK(st.size() == 1);
+    return st[0];
+}
+
+// Executes a StagedPlan call by call like engine.cpp does (rings by absolute time; level or fused form).
+struct StagedSim {
+    const StagedPlan &sp;
+    std::vector<std::map<uint64_t, float>> rings;
+    bool valid = false;
+    uint64_t end = 0;
+    explicit StagedSim(const StagedPlan &p) : sp(p), rings(p.n_rings) {}
+
+    void run_progs(uint32_t first, uint32_t count, uint64_t w0, uint64_t wlen, uint64_t idx, uint64_t T, const Inputs &in, std::vector<float> &out) {
+        for (uint32_t pi = first; pi < first + count; ++pi) {
+            const StageProg &pg = sp.progs[pi];
+            for (uint64_t t = w0; t < w0 + wlen; ++t) {
+                float tmp[STAGE_REGS] = {0};
+                for (uint32_t i = 0; i < pg.n_instr; ++i) {
+                    const StageInstr &x = sp.instrs[pg.first_instr + i];
+                    float v = 0;
+                    switch (x.op) {
+                    case S_CONST: v = f32_from_bits(x.imm); break;
+                    case S_INPUT: v = in_at(in, sp.input_slots[x.imm], t); break;
+                    case S_READ: v = t >= x.d_lo ? rings[x.buf][t - x.d_lo] : 0.0f; break;   // (a missing entry would read 0: tests catch it)
+                    case S_READ_INPUT: v = t >= x.d_lo ? in_at(in, sp.input_slots[x.imm], t - x.d_lo) : 0.0f; break;
+                    case S_STEP: v = t >= x.d_lo ? f32_from_bits(x.imm) : 0.0f; break;
+                    case S_STORE: rings[x.buf][t] = tmp[x.a]; continue;
+                    case S_SUM2: v = host_binop(OP_SUM2, tmp[x.a], tmp[x.b]); break;
+                    case S_MUL: v = host_binop(OP_MUL, tmp[x.a], tmp[x.b]); break;
+                    case S_DIV: v = host_binop(OP_DIV, tmp[x.a], tmp[x.b]); break;
+                    case S_MOD: v = host_binop(OP_MOD, tmp[x.a], tmp[x.b]); break;
+                    default: v = host_binop(OP_MIN, tmp[x.a], tmp[x.b]); break;
+                    }
+                    tmp[x.dst] = v;
+                }
+                float r = tmp[pg.result_reg];
+                if (pg.dst_ring != 0xFFFFFFFFu) rings[pg.dst_ring][t] = r;
+                if (pg.out_row >= 0 && t >= idx) out[(size_t)pg.out_row * T + (t - idx)] = r;
+            }
+        }
+    }
+
+    // renders [idx, idx+T) into out [n_rows, T]; `force_levels` disables the fused form
+    void call(uint64_t idx, uint64_t T, const Inputs &in, std::vector<float> &out, bool force_levels, bool *used_fused = nullptr) {
+        uint64_t w0 = idx;
+        if (sp.uses_rings() && !(valid && end == idx)) {
+            w0 = idx > sp.lmax ? idx - sp.lmax : 0;
+            for (auto &r : rings) r.clear();   // stale contents must not leak into results
+            valid = false;
+        }
+        uint64_t wlen = idx + T - w0;
+        for (const BankLaunch &bl : sp.banks)
+            for (size_t v = 0; v < bl.rows.size(); ++v) {
+                uint64_t b0 = bl.to_ring ? w0 : idx, blen = bl.to_ring ? wlen : T;
+                for (uint64_t t = b0; t < b0 + blen; ++t) {
+                    float val = bank_voice_host(bl, v, in_at(in, bl.input_slot, t));
+                    if (bl.to_ring) rings[bl.rows[v]][t] = val;
+                    else out[(size_t)bl.rows[v] * T + (t - idx)] = val;
+                }
+            }
+        size_t n_levels = sp.level_first.empty() ? 0 : sp.level_first.size() - 1;
+        uint64_t n_sub = sp.fused_count ? (T + sp.fused_max_frames - 1) / sp.fused_max_frames : 0;
+        bool fused = !force_levels && sp.fused_count && w0 == idx && valid && n_sub < n_levels;
+        if (used_fused) *used_fused = fused;
+        if (fused) {
+            for (uint64_t s0 = idx; s0 < idx + T; s0 += sp.fused_max_frames)
+                run_progs(sp.fused_first, sp.fused_count, s0, std::min<uint64_t>(sp.fused_max_frames, idx + T - s0), idx, T, in, out);
+        } else {
+            for (size_t l = 0; l < n_levels; ++l)
+                run_progs(sp.level_first[l], sp.level_first[l + 1] - sp.level_first[l], w0, wlen, idx, T, in, out);
+        }
+        if (sp.uses_rings()) { valid = true; end = idx + T; }
+    }
+};
+
+static bool same_bits(float a, float b) { return f32_to_bits(a) == f32_to_bits(b) || (a != a && b != b); }
+
+// Renders the same calls on the oracle and through (lower -> plan -> simulators); compares everything.
+static void check_graph(const Build &b, uint32_t n_slots, uint64_t T, int calls, bool allow_banks, const char *what,
+                        std::function<void(const FlatGraph &, const StagedPlan &)> inspect = nullptr) {
+    Mirror m;
+    b.apply(m);
+    FlatGraph fg = lower(m, n_slots);
+    StagedPlan sp = plan_stages(fg, allow_banks, true, 20);
+    if (inspect) inspect(fg, sp);
+    fr_renderer *ref = b.apply_oracle();
+    StagedSim sim_levels(sp), sim_fused(sp);
+    Inputs hist(2);
+    std::mt19937 rng(7);
+    std::normal_distribution<float> nd(0.0f, 3.0f);
+    bool any_fused = false;
+    for (int c = 0; c < calls; ++c) {
+        uint64_t idx = (uint64_t)c * T;
+        std::vector<float> row0(T), row1(T);
+        for (uint64_t i = 0; i < T; ++i) { row0[i] = (float)(idx + i); row1[i] = nd(rng); }
+        hist[0].insert(hist[0].end(), row0.begin(), row0.end());
+        hist[1].insert(hist[1].end(), row1.begin(), row1.end());
+        std::vector<float> data(row0);
+        data.insert(data.end(), row1.begin(), row1.end());
+        uint64_t offs[3] = {0, T, 2 * T};
+        std::vector<float> exp((size_t)n_slots * T), a((size_t)n_slots * T, -77.0f), f2((size_t)n_slots * T, -77.0f);
+        CHECK(oracle().fill(ref, exp.data(), n_slots, T, idx, data.data(), offs, 2) == FR_OK);
+        bool uf = false;
+        sim_levels.call(idx, T, hist, a, true);
+        sim_fused.call(idx, T, hist, f2, false, &uf);
+        any_fused = any_fused || uf;
+        for (uint32_t s = 0; s < n_slots; ++s) {
+            bool staged_row = std::find(sp.pull_rows.begin(), sp.pull_rows.end(), s) == sp.pull_rows.end();
+            for (uint64_t i = 0; i < T; ++i) {
+                float e = exp[(size_t)s * T + i];
+                float fl = flat_eval(fg, fg.outputs[s], idx + i, hist);
+                if (!same_bits(fl, e)) { std::fprintf(stderr, "%s: lowered graph differs from oracle at slot %u t %llu: %a vs %a\n", what, s, (unsigned long long)(idx + i), fl, e); throw std::runtime_error("mismatch"); }
+                if (!staged_row) continue;
+                if (!same_bits(a[(size_t)s * T + i], e) || !same_bits(f2[(size_t)s * T + i], e)) {
+                    std::fprintf(stderr, "%s: staged plan differs from oracle at slot %u t %llu: levels %a fused %a oracle %a\n", what, s,
+                                 (unsigned long long)(idx + i), a[(size_t)s * T + i], f2[(size_t)s * T + i], e);
+                    throw std::runtime_error("mismatch");
+                }
+            }
+        }
+    }
+    oracle().destroy(ref);
+    (void)any_fused;
+}
+
+// ---- tests ---------------------------------------------------------------------------------------------------
+static void lowering_folds_constants() {
+    Build b;
+    uint32_t mul = b.op(FR_PRIM_MULTIPLY, Cf(0.5f), Cf(-3.0f));
+    b.out(N(mul), 0);
+    uint32_t dl = b.op(FR_PRIM_DELAY, Cf(0.5f), Cf(2.0f));       // a unit step is NOT a constant
+    b.out(N(dl), 1);
+    uint32_t d0 = b.op(FR_PRIM_DELAY, In(0), Cf(0.0f));          // zero delay folds away
+    b.out(N(d0), 2);
+    uint32_t big = b.op(FR_PRIM_DELAY, In(0), Cf(3.0e19f));      // >= 2^64 -> 0
+    b.out(N(big), 3);
+    Mirror m;
+    b.apply(m);
+    FlatGraph fg = lower(m, 5);
+    CHECK(fg.is_const(fg.outputs[0], -1.5f));
+    CHECK(fg.nodes[fg.outputs[1]].op == OP_DELAY);
+    CHECK(fg.nodes[fg.outputs[2]].op == OP_INPUT);
+    CHECK(fg.is_const(fg.outputs[3], 0.0f));
+    CHECK(fg.is_const(fg.outputs[4], 0.0f));                      // unconnected output slot
+    check_graph(b, 5, 8, 2, true, "folding");
+}
+
+static void lowering_errors() {
+    auto code_of = [](const Build &b, uint32_t slots) {
+        Mirror m;
+        b.apply(m);
+        try { lower(m, slots); } catch (const Error &e) { return (int)e.code; }
+        return (int)FR_OK;
+    };
+    {   // a cycle the reference's RouteGraph is documented to reject
+        Build b;
+        uint32_t s = b.op(FR_PRIM_SUM2, None(), Cf(1.0f));
+        b.edges.push_back({s, s, 0, 0});
+        b.out(N(s), 0);
+        CHECK(code_of(b, 1) == FR_ERR_CYCLE);
+        CHECK(code_of(b, 0) == FR_OK);   // not reachable from a rendered slot: the reference never evaluates it either
+    }
+    {   // edge from a node the renderer was never told about (reference.rs:186 panics when it is evaluated)
+        Build b;
+        b.edges.push_back({99, 0, 0, 0});
+        CHECK(code_of(b, 1) == FR_ERR_NO_SUCH_NODE);
+    }
+    {   // primitive read through output slot 1 (reference.rs:223 assert)
+        Build b;
+        uint32_t s = b.op(FR_PRIM_SUM2, Cf(1.0f), Cf(2.0f));
+        b.edges.push_back({s, 0, 1, 0});
+        CHECK(code_of(b, 1) == FR_ERR_BAD_SLOT);
+    }
+    {   // add_edge into an unknown node (reference.rs:145 unwrap)
+        Mirror m;
+        bool threw = false;
+        try { m.add_edge({0, 42, 0, 0}); } catch (const Error &e) { threw = e.code == FR_ERR_NO_SUCH_NODE; }
+        CHECK(threw);
+    }
+}
+
+static void random_graphs_lower_correctly() {
+    for (unsigned seed = 0; seed < 40; ++seed) {
+        std::mt19937 rng(seed);
+        Build b;
+        std::vector<uint32_t> avail;
+        int kinds[6] = {FR_PRIM_DELAY, FR_PRIM_SUM2, FR_PRIM_MULTIPLY, FR_PRIM_DIVIDE, FR_PRIM_MODULO, FR_PRIM_MINIMUM};
+        float consts[10] = {0.0f, 1.0f, -1.0f, 0.5f, 2.0f, 3.0f, -3.5f, 7.25f, 1e-30f, NAN};
+        int n = 4 + (int)(rng() % 24);
+        for (int i = 0; i < n; ++i) {
+            int k = kinds[rng() % 6];
+            auto pick = [&](bool delay_amount) -> Operand {
+                unsigned r = rng() % 10;
+                if (delay_amount && (seed % 2 == 0 || r < 7)) return Cf((float)(rng() % 9));   // even seeds: constant delays only
+                if (r < 1) return None();
+                if (r < 3 || avail.empty()) return (rng() % 2) ? In(rng() % 2) : Cf(consts[rng() % 10]);
+                return N(avail[rng() % avail.size()]);
+            };
+            Operand a = pick(false), bb = pick(k == FR_PRIM_DELAY);
+            avail.push_back(b.op(k, a, bb));
+        }
+        for (uint32_t s = 0; s < 3; ++s) b.out(N(avail[avail.size() - 1 - (rng() % std::min<size_t>(avail.size(), 6))]), s);
+        char what[32];
+        std::snprintf(what, sizeof what, "random seed %u", seed);
+        check_graph(b, 3, 24, 3, true, what);
+    }
+}
+
+static void banks_are_recognised() {
+    std::mt19937 rng(3);
+    Build b;
+    b.out(N(voice(b, 64, 55.0f, rng)), 0);
+    b.out(N(voice(b, 64, 110.0f, rng)), 1);
+    b.out(N(voice(b, 32, 220.0f, rng)), 2);
+    b.out(N(voice(b, 100, 82.4f, rng)), 3);   // not a power of two: general schedule
+    b.out(N(voice(b, 8, 82.4f, rng)), 4);     // too small to be a bank: a stage program (89 instructions)
+    check_graph(b, 5, 16, 2, true, "banks", [](const FlatGraph &, const StagedPlan &sp) {
+        CHECK(sp.pull_rows.empty());
+        size_t balanced = 0, general = 0;
+        for (auto &bl : sp.banks) (bl.general ? general : balanced) += bl.rows.size();
+        CHECK(balanced == 3 && general == 1);
+        CHECK(sp.progs.size() == 1 && sp.n_rings == 0);
+        for (auto &bl : sp.banks)
+            if (bl.general) {
+                CHECK(bl.max_leaves == 100);
+                uint32_t leaves = 0, merges = 0;
+                for (uint32_t g : bl.groups) { leaves += 1u << (g & 15u); merges += g >> 4; }
+                CHECK(leaves == 100 && merges + 1 == bl.groups.size());
+            }
+    });
+    check_graph(b, 5, 16, 1, false, "banks off");   // same graph with banks disabled: 64-leaf trees exceed a program -> pull
+}
+
+static void effects_chain_is_staged() {
+    std::mt19937 rng(9);
+    Build b;
+    for (uint32_t v = 0; v < 2; ++v) {
+        uint32_t mix = voice(b, 32, 55.0f * (v + 1), rng);
+        // envelope: max(0, min(t/20, (200 - t)/50)) built with Minimum and negations
+        uint32_t a = b.op(FR_PRIM_DIVIDE, In(0), Cf(20.0f));
+        uint32_t r = b.op(FR_PRIM_DIVIDE, N(b.op(FR_PRIM_SUM2, Cf(200.0f), N(b.op(FR_PRIM_MULTIPLY, Cf(-1.0f), In(0))))), Cf(50.0f));
+        uint32_t mn = b.op(FR_PRIM_MINIMUM, N(a), N(r));
+        uint32_t env = b.op(FR_PRIM_MULTIPLY, Cf(-1.0f), N(b.op(FR_PRIM_MINIMUM, Cf(0.0f), N(b.op(FR_PRIM_MULTIPLY, Cf(-1.0f), N(mn))))));
+        uint32_t x = b.op(FR_PRIM_MULTIPLY, N(env), N(mix));
+        for (int j = 0; j < 3; ++j) {
+            uint32_t dl = b.op(FR_PRIM_DELAY, N(x), Cf(70.0f * (j + 1)));
+            x = b.op(FR_PRIM_SUM2, N(x), N(b.op(FR_PRIM_MULTIPLY, Cf(0.5f), N(dl))));
+        }
+        b.out(N(x), v);
+    }
+    uint32_t dn = b.op(FR_PRIM_DELAY, In(1), Cf(5.0f));            // a delay of an input and of a constant
+    b.out(N(b.op(FR_PRIM_SUM2, N(dn), N(b.op(FR_PRIM_DELAY, Cf(2.0f), Cf(3.0f))))), 2);
+    check_graph(b, 3, 100, 5, true, "effects chain", [](const FlatGraph &, const StagedPlan &sp) {
+        CHECK(sp.pull_rows.empty());
+        CHECK(sp.lmax == 70 + 140 + 210);
+        CHECK(sp.n_rings == 2 * 4);                 // per voice: the bank's mix + x0, x1, x2
+        CHECK(sp.fused_count > 0 && sp.fused_max_frames == 70);
+        CHECK(sp.level_first.size() - 1 >= 5);
+    });
+    check_graph(b, 3, 33, 7, true, "effects chain, short calls");
+}
+
+static void dynamic_delay_goes_to_pull() {
+    Build b;
+    uint32_t amt = b.op(FR_PRIM_MODULO, In(0), Cf(5.0f));
+    uint32_t d = b.op(FR_PRIM_DELAY, In(1), N(amt));
+    b.out(N(d), 0);
+    b.out(N(b.op(FR_PRIM_SUM2, In(1), Cf(1.0f))), 1);
+    check_graph(b, 2, 20, 2, true, "dynamic delay", [](const FlatGraph &, const StagedPlan &sp) {
+        CHECK(sp.pull_rows.size() == 1 && sp.pull_rows[0] == 0);
+        CHECK(sp.progs.size() == 1);
+    });
+}
+
+static void composite_instances_are_interned() {
+    // MulBy2-style composite used twice: one definition, two instances, inlined correctly
+    fr_effect mul{}, cst{};
+    mul.kind = FR_PRIM_MULTIPLY;
+    cst.kind = FR_PRIM_F32CONSTANT;
+    uint32_t handles[2] = {1, 2};
+    const fr_effect *effs[2] = {&mul, &cst};
+    fr_edge edges[3] = {{0, 1, 0, 0}, {1, 0, 0, 0}, {2, 1, f32_to_bits(5.0f), 1}};
+    fr_effect comp{};
+    comp.kind = FR_EFFECT_GRAPH;
+    comp.n_nodes = 2; comp.node_handles = handles; comp.node_effects = effs;
+    comp.n_edges = 3; comp.edges = edges;
+    Mirror m;
+    m.add_node(10, &comp);
+    m.add_node(11, &comp);
+    CHECK(m.nodes.at(10).sub == m.nodes.at(11).sub);        // interned once
+    m.add_edge({0, 10, 0, 0});
+    m.add_edge({10, 11, 0, 0});
+    m.add_edge({11, 0, 0, 0});
+    FlatGraph fg = lower(m, 1);
+    Inputs in{{1.0f, 2.0f, 3.0f}};
+    for (uint64_t t = 0; t < 3; ++t) CHECK(flat_eval(fg, fg.outputs[0], t, in) == 25.0f * (t + 1));
+}
+
+int main(int argc, char **argv) {
+    std::vector<std::pair<const char *, std::function<void()>>> tests = {
+        {"lowering_folds_constants", lowering_folds_constants}, {"lowering_errors", lowering_errors},
+        {"random_graphs_lower_correctly", random_graphs_lower_correctly}, {"banks_are_recognised", banks_are_recognised},
+        {"effects_chain_is_staged", effects_chain_is_staged}, {"dynamic_delay_goes_to_pull", dynamic_delay_goes_to_pull},
+        {"composite_instances_are_interned", composite_instances_are_interned}};
+    int failed = 0, ran = 0;
+    for (auto &t : tests) {
+        if (argc > 1 && std::string(argv[1]) != t.first) continue;
+        ++ran;
+        try {
+            t.second();
+            std::printf("test %s ... ok\n", t.first);
+        } catch (const std::exception &e) {
+            std::printf("test %s ... FAILED: %s\n", t.first, e.what());
+            ++failed;
+        }
+    }
+    std::printf("test result: %s. %d passed; %d failed\n", failed ? "FAILED" : "ok", ran - failed, failed);
+    return failed ? 1 : 0;
+}
