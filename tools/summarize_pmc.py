@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Turns the counter_collection CSVs of tools/collect_profiles.sh into profiles/<tag>_bank_pmc_summary.json
+(per-launch means for the bank kernel + derived HBM traffic, VALU instructions per partial-frame group, clock)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+src, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r01")
+V, P, T = 64, 4096, 4800
+out = {}
+for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for f in glob.glob(f"{src}/{name}/*/*counter_collection.csv"):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "bank_kernel" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            out[k] = {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
+stats = {}
+for f in glob.glob(f"{src}/trace/*/*kernel_stats.csv"):
+    for r in csv.DictReader(open(f)):
+        if "bank_kernel" in r["Name"]:
+            stats = {"calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
+pf = V * P * T
+avg_s = stats.get("average_ns", 0) * 1e-9
+summ = {
+    "command": "tools/collect_profiles.sh (rocprofv3 --pmc <counters> -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2; one pass per TCC counter)",
+    "kernel": "fr::bank_kernel<1, 1, 4>", "per": "launch (one 4800-frame fill_buffer over 64 voices x 4096 partials)",
+    "kernel_trace_stats": stats, "counters": out,
+    "derived": {
+        "hbm_read_bytes": out["FETCH_SIZE"]["mean"] * 1024, "hbm_write_bytes": out["WRITE_SIZE"]["mean"] * 1024,
+        "hbm_traffic_bytes": (out["FETCH_SIZE"]["mean"] + out["WRITE_SIZE"]["mean"]) * 1024,
+        "algorithmic_bytes": V * P * 8 + 4 * T + 4 * V * T,
+        "fetch_note": "FETCH_SIZE/WRITE_SIZE are KiB. The parameter stream is read through the scalar cache (64-B s_load_dwordx16 "
+                      "requests), not 16-B/lane vector loads, so the gfx950 x2 FETCH_SIZE correction for wide coalesced reads does not "
+                      "apply: the read figure equals 2048 KiB of parameters + the 18.75 KiB time row + tables, i.e. every parameter byte "
+                      "leaves HBM once per launch and all 75 time tiles re-read it from L2.",
+        "valu_instr_per_partial_frame_group": out["SQ_INSTS_VALU"]["mean"] / (pf / 64),
+        "clock_ghz_from_GRBM_GUI_ACTIVE": out["GRBM_GUI_ACTIVE"]["mean"] / 8 / avg_s / 1e9 if avg_s else None,
+    },
+}
+json.dump(summ, open(f"profiles/{tag}_bank_pmc_summary.json", "w"), indent=1)
+print(json.dumps(summ["derived"], indent=1))
