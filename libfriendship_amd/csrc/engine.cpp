@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "graph.hpp"
+#include "jit.hpp"
 #include "kernels.hpp"
 #include "match.hpp"
 #include "stage.hpp"
@@ -70,6 +71,7 @@ struct InSlot {
 struct BankStage {
     BankLaunch grp;          // rows/params kept on the host for the plan description
     DevBuf d_params, d_rows, d_groups, d_group_off;
+    std::shared_ptr<JitKernel> jit;   // grp.jit: the hipRTC specialisation
 };
 
 struct Plan {
@@ -114,12 +116,15 @@ struct fr_renderer {
     std::vector<float> h_stage;
     bool timing = false;
     uint32_t bank_leaf_variant = 1;
+    bool allow_jit = true;               // FR_JIT=0 disables hipRTC specialisation (those voices then run as programs / pull)
+    JitCache jit_cache;
    // see kernels.hpp BankArgs::leaf_variant; FR_BANK_LEAF env overrides (A/B runs)
     TimerClass t_bank, t_pull, t_stage;
     DevBuf d_rings, d_in_table_stage;
     uint64_t ring_cap = 0;               // floats per ring (power of two)
     std::vector<hipEvent_t> event_pool;
     std::string last_error;
+    std::string jit_error;
     std::string plan_json_cache;
 
     ~fr_renderer() {
@@ -188,8 +193,12 @@ struct fr_renderer {
         if (plan.sp.uses_rings() || !plan.sp.progs.empty()) return false;   // windows with look-back read the stored history
         bool any = false;
         for (const BankStage &bs : plan.banks) {
+            if (bs.grp.jit) {
+                for (uint32_t sl : bs.grp.shape.input_slots) if (sl == slot) return false;
+                continue;
+            }
             if (bs.grp.input_slot != slot) continue;
-            if (bs.grp.general) return false;   // only the balanced kernel appends history
+            if (bs.grp.general || bs.grp.jit) return false;   // only the balanced hand-written kernel appends history
             any = true;
         }
         return any;
@@ -268,9 +277,23 @@ struct fr_renderer {
         p.version = mirror.version;
         p.n_slots = n_slots;
         p.fg = lower(mirror, n_slots);
-        p.sp = plan_stages(p.fg, mode == FR_MODE_AUTO, mode != FR_MODE_PULL, 20);
+        bool use_jit = allow_jit && mode == FR_MODE_AUTO;
+        p.sp = plan_stages(p.fg, mode == FR_MODE_AUTO, mode != FR_MODE_PULL, 20, use_jit);
+        std::vector<std::shared_ptr<JitKernel>> jits(p.sp.banks.size());
+        if (use_jit) {
+            try {
+                for (size_t i = 0; i < p.sp.banks.size(); ++i)
+                    if (p.sp.banks[i].jit) jits[i] = jit_cache.get(p.sp.banks[i].shape, p.sp.banks[i].varying, p.sp.banks[i].literal_bits, p.sp.banks[i].alias);
+            } catch (const Error &e) {   // hipRTC unavailable or the generated source did not compile: plan without it
+                jit_error = e.what();
+                p.sp = plan_stages(p.fg, true, true, 20, false);
+                jits.assign(p.sp.banks.size(), nullptr);
+            }
+        }
+        size_t bank_i = 0;
         for (BankLaunch &bg : p.sp.banks) {
             BankStage bs;
+            bs.jit = jits[bank_i++];
             bs.grp = std::move(bg);
             bs.d_params.ensure(bs.grp.params.size() * sizeof(float));
             bs.d_rows.ensure(bs.grp.rows.size() * sizeof(uint32_t));
@@ -320,7 +343,8 @@ struct fr_renderer {
         for (size_t i = 0; i < p.banks.size(); ++i) {
             const BankLaunch &g = p.banks[i].grp;
             js << (i ? "," : "") << "{\"voices\":" << g.rows.size() << ",\"partials\":" << (g.general ? g.max_leaves : (1u << g.log2_p))
-               << ",\"general_tree\":" << (g.general ? "true" : "false")
+               << ",\"general_tree\":" << (g.general ? "true" : "false") << ",\"jit\":" << (g.jit ? "true" : "false")
+               << ",\"leaf_ops\":" << (g.jit ? g.shape.ops.size() : 0) << ",\"leaf_params\":" << (g.jit ? g.k : 2)
                << ",\"input_slot\":" << g.input_slot << ",\"fast_ok\":" << (g.fast_ok ? "true" : "false")
                << ",\"to_ring\":" << (g.to_ring ? "true" : "false")
                << ",\"param_bytes\":" << g.params.size() * sizeof(float) << "}";
@@ -329,6 +353,7 @@ struct fr_renderer {
            << ",\"fused_programs\":" << p.sp.fused_count << ",\"fused_max_frames\":" << p.sp.fused_max_frames
            << ",\"stage_levels\":" << (p.sp.level_first.empty() ? 0 : p.sp.level_first.size() - 1)
            << ",\"rings\":" << p.sp.n_rings << ",\"max_lookback\":" << p.sp.lmax
+           << ",\"jit_kernels_compiled\":" << jit_cache.compiled() << ",\"jit_compile_ms\":" << jit_cache.compile_ms()
            << ",\"pull_rows\":" << p.pull_rows.size() << "}";
         p.json = js.str();
         p.valid = true;
@@ -396,6 +421,33 @@ struct fr_renderer {
             a.log2_p = bs.grp.log2_p;
             a.n_times = blen;
             a.fast_ok = bs.grp.fast_ok ? 1u : 0u;
+            if (bs.grp.jit) {
+                JitBankArgs j{};
+                j.params = bs.d_params.as<float>();
+                for (size_t i = 0; i < bs.grp.shape.input_slots.size(); ++i) {   // every input row over the same window
+                    DevInput dj = dev_input(bs.grp.shape.input_slots[i]);
+                    if (dj.data && dj.len > dj.base) {
+                        uint64_t start = std::max(b0, dj.base);
+                        j.in_skip[i] = std::min(start - b0, blen);
+                        j.in[i] = dj.data + (start - dj.base);
+                        j.in_valid[i] = dj.len > start ? dj.len - start : 0;
+                    }
+                }
+                j.out = a.out;
+                j.rows = a.rows;
+                j.out_stride = a.out_stride;
+                j.ring_mask = a.ring_mask;
+                j.ring_t0 = a.ring_t0;
+                j.n_times = blen;
+                j.n_voices = a.n_voices;
+                j.log2_p = a.log2_p;
+                j.tiles = (uint32_t)((blen + 63) / 64);
+                j.nblocks = j.tiles * j.n_voices;
+                Scope sc(this, &t_bank, st);
+                HIP_CHECK(launch_jit_bank(*bs.jit, j, st));
+                sc.done();
+                continue;
+            }
             if (bs.grp.general) {
                 a.groups = bs.d_groups.as<uint32_t>();
                 a.group_off = bs.d_group_off.as<uint32_t>();
@@ -568,6 +620,7 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     r->device = dev;
     r->mode = mode;
     if (const char *lv = std::getenv("FR_BANK_LEAF")) r->bank_leaf_variant = (lv[0] == '1') ? 1u : 0u;
+    if (const char *jv = std::getenv("FR_JIT")) r->allow_jit = jv[0] != '0';
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {
         delete r;
         return FR_ERR_DEVICE;

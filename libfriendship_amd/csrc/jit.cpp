@@ -1,0 +1,179 @@
+// jit.cpp -- code generation + hipRTC compilation of shape-specialised bank kernels (see jit.hpp).
+#include "jit.hpp"
+
+#include <hip/hiprtc.h>
+
+#include <chrono>
+#include <cstdio>
+#include <sstream>
+
+#include "graph.hpp"
+
+namespace fr {
+
+#define FR_STR2(...) #__VA_ARGS__
+#define FR_STR(...) FR_STR2(__VA_ARGS__)
+
+JitKernel::~JitKernel() {
+    if (module) (void)hipModuleUnload(module);
+}
+
+// The skeleton is the hand-written bank kernel's structure (kernels.hip) with one 64-frame tile per wave, 4 waves
+// per workgroup and one workgroup per (voice, tile); only leaf() and K differ between specialisations.
+static const char *kSkeleton = R"JIT(
+typedef float __attribute__((address_space(4))) const *cptr;
+
+__device__ __forceinline__ float jit_mod(float a, float b) {   // reference.rs:254-261
+    float rem = fmodf(a, b);
+    return rem < 0.0f ? rem + b : rem;
+}
+__device__ __forceinline__ float jit_min(float a, float b) {   // Rust >= 1.20 f32::min
+    return (a < b || b != b) ? a : b;
+}
+
+LEAF_FUNCTION
+
+extern "C" __global__ void __launch_bounds__(256) jit_bank(JitBankArgs a) {
+    unsigned b = blockIdx.x;
+    unsigned lid = (a.nblocks % 8u == 0u) ? (b % 8u) * (a.nblocks / 8u) + b / 8u : b;   // XCD-contiguous work ranges
+    const unsigned voice = lid / a.tiles, tile = lid - voice * a.tiles;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long ti = (unsigned long long)tile * 64u + lane;
+    float x[NIN > 0 ? NIN : 1];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i)
+        x[i] = (ti >= a.in_skip[i] && ti - a.in_skip[i] < a.in_valid[i]) ? a.in[i][ti - a.in_skip[i]] : 0.0f;
+
+    const unsigned P = 1u << a.log2_p, Pw = P >> 2, ngroups = Pw >> 3, levels = a.log2_p - 5u;
+    cptr p = (cptr)(a.params + ((size_t)voice * P + (size_t)wave * Pw) * K);
+    float s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0, s8 = 0;
+    for (unsigned g = 0; g < ngroups; ++g) {
+        float c[8 * K];
+#pragma unroll
+        for (int i = 0; i < 8 * K; ++i) c[i] = p[(size_t)g * (8 * K) + i];
+        float l0 = LEAF_CALL(0), l1 = LEAF_CALL(1), l2 = LEAF_CALL(2), l3 = LEAF_CALL(3);
+        float l4 = LEAF_CALL(4), l5 = LEAF_CALL(5), l6 = LEAF_CALL(6), l7 = LEAF_CALL(7);
+        float v = ((l0 + l1) + (l2 + l3)) + ((l4 + l5) + (l6 + l7));
+        // binary-counter carry chain over the tree levels above the 8-leaf group (g < 2^levels stops it)
+        do {
+            if (!(g & 1u)) { s0 = v; break; } v = s0 + v;
+            if (!(g & 2u)) { s1 = v; break; } v = s1 + v;
+            if (!(g & 4u)) { s2 = v; break; } v = s2 + v;
+            if (!(g & 8u)) { s3 = v; break; } v = s3 + v;
+            if (!(g & 16u)) { s4 = v; break; } v = s4 + v;
+            if (!(g & 32u)) { s5 = v; break; } v = s5 + v;
+            if (!(g & 64u)) { s6 = v; break; } v = s6 + v;
+            if (!(g & 128u)) { s7 = v; break; } v = s7 + v;
+            s8 = v;
+        } while (0);
+    }
+    float r = s8;
+    r = levels == 7u ? s7 : r; r = levels == 6u ? s6 : r; r = levels == 5u ? s5 : r; r = levels == 4u ? s4 : r;
+    r = levels == 3u ? s3 : r; r = levels == 2u ? s2 : r; r = levels == 1u ? s1 : r; r = levels == 0u ? s0 : r;
+
+    __shared__ float sm[4][64];
+    sm[wave][lane] = r;
+    __syncthreads();
+    if (wave == 0 && ti < a.n_times) {
+        float t = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+        unsigned long long o = a.ring_mask ? ((a.ring_t0 + ti) & a.ring_mask) : ti;
+        a.out[(size_t)a.rows[voice] * a.out_stride + o] = t;
+    }
+}
+)JIT";
+
+std::string JitCache::generate_source(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
+                                      const std::vector<uint32_t> &alias) {
+    std::ostringstream leaf;
+    uint32_t k = 0;
+    std::vector<int> pidx(shape.n_consts, -1);
+    for (uint32_t c = 0; c < shape.n_consts; ++c)
+        if (varying[c]) pidx[c] = alias[c] == c ? (int)k++ : pidx[alias[c]];
+    leaf << "__device__ __forceinline__ float leaf(const float *x";
+    for (uint32_t i = 0; i < (k ? k : 1); ++i) leaf << ", float p" << i;
+    leaf << ") {\n    (void)x; (void)p0;\n";
+    for (size_t i = 0; i < shape.ops.size(); ++i) {
+        const LeafShape::Op &o = shape.ops[i];
+        leaf << "    float v" << i << " = ";
+        char buf[64];
+        switch (o.op) {
+        case OP_CONST:
+            if (varying[o.a]) leaf << "p" << pidx[o.a];
+            else { std::snprintf(buf, sizeof buf, "__builtin_bit_cast(float, 0x%08xu)", literal_bits[o.a]); leaf << buf; }
+            break;
+        case OP_INPUT: leaf << "x[" << o.a << "]"; break;
+        case OP_SUM2: leaf << "v" << o.a << " + v" << o.b; break;
+        case OP_MUL: leaf << "v" << o.a << " * v" << o.b; break;
+        case OP_DIV: leaf << "v" << o.a << " / v" << o.b; break;
+        case OP_MOD: leaf << "jit_mod(v" << o.a << ", v" << o.b << ")"; break;
+        default: leaf << "jit_min(v" << o.a << ", v" << o.b << ")"; break;
+        }
+        leaf << ";\n";
+    }
+    leaf << "    return v" << shape.ops.size() - 1 << ";\n}\n";
+    const uint32_t K = k ? k : 1;
+    std::ostringstream call;
+    call << "leaf(x";
+    for (uint32_t i = 0; i < K; ++i) call << ", c[(j) * K + " << i << "]";
+    call << ")";
+    std::ostringstream src;
+    src << "#pragma clang fp contract(off)\n";
+    src << FR_STR(FR_JIT_ARGS_TEXT) << "\n";
+    src << "#define K " << K << "\n#define NIN " << shape.input_slots.size() << "\n";
+    src << "#define LEAF_CALL(j) " << call.str() << "\n";
+    std::string body = kSkeleton;
+    const std::string tag = "LEAF_FUNCTION";
+    body.replace(body.find(tag), tag.size(), leaf.str());
+    src << body;
+    return src.str();
+}
+
+std::shared_ptr<JitKernel> JitCache::get(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
+                                         const std::vector<uint32_t> &alias) {
+    std::string src = generate_source(shape, varying, literal_bits, alias);
+    auto it = cache_.find(src);
+    if (it != cache_.end()) return it->second;
+    auto t0 = std::chrono::steady_clock::now();
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        throw Error(FR_ERR_DEVICE, "jit: cannot query the device");
+    std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "fr_jit_bank.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        throw Error(FR_ERR_DEVICE, "jit: hiprtcCreateProgram failed");
+    const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+                          "-fno-slp-vectorize", "-mllvm", "-simplifycfg-sink-common=false"};
+    hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t ls = 0;
+        hiprtcGetProgramLogSize(prog, &ls);
+        std::string log(ls, '\0');
+        if (ls) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        throw Error(FR_ERR_DEVICE, "jit: compilation failed: " + log.substr(0, 2000));
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    auto jk = std::make_shared<JitKernel>();
+    for (size_t c = 0; c < varying.size(); ++c) jk->k += (varying[c] && alias[c] == c) ? 1 : 0;
+    if (hipModuleLoadData(&jk->module, code.data()) != hipSuccess) throw Error(FR_ERR_DEVICE, "jit: hipModuleLoadData failed");
+    if (hipModuleGetFunction(&jk->fn, jk->module, "jit_bank") != hipSuccess) throw Error(FR_ERR_DEVICE, "jit: kernel symbol missing");
+    compile_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ++compiled_;
+    cache_.emplace(std::move(src), jk);
+    return jk;
+}
+
+hipError_t launch_jit_bank(const JitKernel &k, const JitBankArgs &a, hipStream_t s) {
+    if (a.nblocks == 0) return hipSuccess;
+    JitBankArgs copy = a;
+    void *args[] = {&copy};
+    return hipModuleLaunchKernel(k.fn, a.nblocks, 1, 1, 256, 1, 1, 0, s, args, nullptr);
+}
+
+}  // namespace fr

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <unordered_map>
 
 namespace fr {
@@ -192,9 +193,150 @@ struct BankMatcher::Impl : Matcher {
         }
         return ok && max_depth <= 16 && vm.n_leaves >= 16;
     }
+
+    // ---- shape matching (for jit.hpp): leaves of ANY common expression shape -------------------------------
+    std::unordered_map<uint32_t, uint64_t> shape_memo;   // 0 = not a leaf expression (contains a Delay, too deep)
+    static uint64_t hmix(uint64_t h, uint64_t v) {
+        h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h *= 0xBF58476D1CE4E5B9ull;
+        return h ^ (h >> 29);
+    }
+    uint64_t shape_hash(uint32_t id, int depth = 0) {
+        auto it = shape_memo.find(id);
+        if (it != shape_memo.end()) return it->second;
+        uint64_t r;
+        const FlatNode &x = n(id);
+        if (depth > 48 || x.op == OP_DELAY) r = 0;
+        else if (x.op == OP_CONST) r = 0xC0757ull;
+        else if (x.op == OP_INPUT) r = hmix(0x17B07ull, x.a) | 1;
+        else {
+            uint64_t a = shape_hash(x.a, depth + 1), b = shape_hash(x.b, depth + 1);
+            if (!a || !b) r = 0;
+            else {
+                if ((x.op == OP_SUM2 || x.op == OP_MUL) && a > b) std::swap(a, b);
+                r = hmix(hmix(0x0F00ull + x.op, a), b) | 1;
+            }
+        }
+        shape_memo.emplace(id, r);
+        return r;
+    }
+
+    // Canonical serialisation of one leaf as a TREE: every use of a node is emitted again (hash-consing may have
+    // merged sub-expressions or constants in one leaf that stay distinct in another, so the DAG is not canonical;
+    // the tree is, and the device compiler's CSE puts the sharing back -- exact, since every op is pure).
+    // Operands of the commutative ops are ordered by shape hash.  Fills ops/input_slots when `define`, else checks
+    // that this leaf serialises to the same ops; appends the leaf's constants (one column per USE) to `consts`.
+    bool serialise_leaf(uint32_t root, LeafShape &shape, std::vector<uint32_t> &consts, bool define) {
+        std::vector<LeafShape::Op> ops;
+        std::vector<uint32_t> inputs = define ? std::vector<uint32_t>{} : shape.input_slots;
+        bool ok = true;
+        std::function<uint32_t(uint32_t)> emit = [&](uint32_t id) -> uint32_t {
+            if (!ok) return 0;
+            if (ops.size() >= 96) { ok = false; return 0; }
+            const FlatNode &x = n(id);
+            if (x.op == OP_CONST) {
+                ops.push_back({OP_CONST, (uint32_t)consts.size(), 0});
+                consts.push_back(x.a);
+                return (uint32_t)ops.size() - 1;
+            }
+            if (x.op == OP_INPUT) {
+                uint32_t idx = 0;
+                while (idx < inputs.size() && inputs[idx] != x.a) ++idx;
+                if (idx == inputs.size()) {
+                    if (!define) { ok = false; return 0; }
+                    inputs.push_back(x.a);
+                }
+                ops.push_back({OP_INPUT, idx, 0});
+                return (uint32_t)ops.size() - 1;
+            }
+            uint32_t a = x.a, b = x.b;
+            if ((x.op == OP_SUM2 || x.op == OP_MUL) && shape_hash(a) > shape_hash(b)) std::swap(a, b);
+            uint32_t la = emit(a), lb = emit(b);
+            ops.push_back({x.op, la, lb});
+            return (uint32_t)ops.size() - 1;
+        };
+        emit(root);
+        if (!ok) return false;
+        if (define) {
+            shape.ops = ops;
+            shape.input_slots = inputs;
+            shape.n_consts = (uint32_t)consts.size();
+            return true;
+        }
+        if (ops.size() != shape.ops.size() || consts.size() != shape.n_consts) return false;
+        for (size_t i = 0; i < ops.size(); ++i)
+            if (ops[i].op != shape.ops[i].op || ops[i].a != shape.ops[i].a || ops[i].b != shape.ops[i].b) return false;
+        return true;
+    }
+
+    bool collect_shape(uint32_t id, uint32_t height, uint64_t leaf_hash, std::vector<uint32_t> &leaves) {
+        if (height == 0) {
+            if (shape_hash(id) != leaf_hash) return false;
+            leaves.push_back(id);
+            return true;
+        }
+        const FlatNode &x = n(id);
+        return x.op == OP_SUM2 && collect_shape(x.a, height - 1, leaf_hash, leaves) && collect_shape(x.b, height - 1, leaf_hash, leaves);
+    }
+
+    bool match_shape_voice(uint32_t root, uint32_t max_log2_p, VoiceMatch &vm) {
+        uint32_t h = 0, cur = root;
+        while (n(cur).op == OP_SUM2 && shape_hash(n(cur).a) != 0 && shape_hash(n(cur).a) == shape_hash(n(cur).b) && h < max_log2_p) {
+            cur = n(cur).a;
+            ++h;
+        }
+        if (h < 5 || h > 13) return false;                 // one workgroup per voice tile: 32..8192 leaves
+        if (n(cur).op == OP_CONST || n(cur).op == OP_INPUT) return false;   // a sum of bare inputs/constants is not worth a kernel
+        std::vector<uint32_t> leaves;
+        leaves.reserve((size_t)1 << h);
+        if (!collect_shape(root, h, shape_hash(cur), leaves)) return false;
+        std::vector<uint32_t> first, row;
+        if (!serialise_leaf(leaves[0], vm.shape, first, true)) return false;
+        if (vm.shape.n_consts > 32 || vm.shape.input_slots.size() > 4 || vm.shape.ops.empty()) return false;
+        const uint32_t nc = vm.shape.n_consts;
+        std::vector<uint32_t> all((size_t)leaves.size() * nc);
+        std::copy(first.begin(), first.end(), all.begin());
+        vm.varying.assign(nc, false);
+        for (size_t i = 1; i < leaves.size(); ++i) {
+            row.clear();
+            if (!serialise_leaf(leaves[i], vm.shape, row, false)) return false;
+            for (uint32_t c = 0; c < nc; ++c) {
+                all[i * nc + c] = row[c];
+                if (row[c] != first[c]) vm.varying[c] = true;
+            }
+        }
+        // the tree form repeats a shared sub-expression's constants: columns equal in every leaf share one parameter
+        vm.alias.resize(nc);
+        for (uint32_t c = 0; c < nc; ++c) {
+            vm.alias[c] = c;
+            if (!vm.varying[c]) continue;
+            for (uint32_t e = 0; e < c && vm.alias[c] == c; ++e) {
+                if (!vm.varying[e] || vm.alias[e] != e) continue;
+                bool same = true;
+                for (size_t i = 0; i < leaves.size() && same; ++i) same = all[i * nc + c] == all[i * nc + e];
+                if (same) vm.alias[c] = e;
+            }
+        }
+        vm.k = 0;
+        for (uint32_t c = 0; c < nc; ++c) vm.k += (vm.varying[c] && vm.alias[c] == c) ? 1 : 0;
+        if (vm.k > 8) return false;
+        vm.literal_bits = first;
+        const uint32_t K = vm.k ? vm.k : 1;
+        vm.params.assign((size_t)leaves.size() * K, 0.0f);
+        for (size_t i = 0; i < leaves.size(); ++i) {
+            uint32_t j = 0;
+            for (uint32_t c = 0; c < nc; ++c)
+                if (vm.varying[c] && vm.alias[c] == c) vm.params[i * K + j++] = f32_from_bits(all[i * nc + c]);
+        }
+        vm.jit = true;
+        vm.log2_p = h;
+        vm.n_leaves = (uint32_t)leaves.size();
+        return true;
+    }
 };
 
-BankMatcher::BankMatcher(const FlatGraph &g, uint32_t max_log2_p) : impl_(new Impl(g)), g_(g), max_log2_p_(max_log2_p) {}
+BankMatcher::BankMatcher(const FlatGraph &g, uint32_t max_log2_p, bool allow_jit)
+    : impl_(new Impl(g)), g_(g), max_log2_p_(max_log2_p), allow_jit_(allow_jit) {}
 BankMatcher::~BankMatcher() { delete impl_; }
 
 bool BankMatcher::try_voice(uint32_t root, VoiceMatch &out) {
@@ -224,6 +366,15 @@ bool BankMatcher::try_voice(uint32_t root, VoiceMatch &out) {
         VoiceMatch vm;
         vm.general = true;
         if (impl_->emit_general(root, vm)) {
+            memo_.emplace(root, (int64_t)found_.size());
+            found_.push_back(std::move(vm));
+            out = found_.back();
+            return true;
+        }
+    }
+    if (allow_jit_ && g_.nodes[root].op == OP_SUM2) {   // leaves of some other common shape: hipRTC specialisation
+        VoiceMatch vm;
+        if (impl_->match_shape_voice(root, max_log2_p_, vm)) {
             memo_.emplace(root, (int64_t)found_.size());
             found_.push_back(std::move(vm));
             out = found_.back();

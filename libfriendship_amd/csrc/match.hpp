@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "graph.hpp"
+#include "leafshape.hpp"
 
 namespace fr {
 
@@ -23,11 +24,19 @@ struct VoiceMatch {
     bool general = false;
     uint32_t n_leaves = 0;
     std::vector<uint32_t> groups;
+    // shape-matched voice (jit == true): balanced tree over 2^log2_p leaves of one arbitrary expression shape;
+    // params = [P][k] (the varying constant columns), input_slot unused (shape.input_slots instead)
+    bool jit = false;
+    LeafShape shape;
+    std::vector<bool> varying;
+    std::vector<uint32_t> literal_bits;
+    std::vector<uint32_t> alias;      // alias[c] = first column whose values equal column c's in every leaf (c itself if none)
+    uint32_t k = 0;
 };
 
 class BankMatcher {
 public:
-    BankMatcher(const FlatGraph &g, uint32_t max_log2_p);
+    BankMatcher(const FlatGraph &g, uint32_t max_log2_p, bool allow_jit = false);
     ~BankMatcher();
     BankMatcher(const BankMatcher &) = delete;
     BankMatcher &operator=(const BankMatcher &) = delete;
@@ -39,6 +48,7 @@ private:
     Impl *impl_;
     const FlatGraph &g_;
     uint32_t max_log2_p_;
+    bool allow_jit_;
     std::unordered_map<uint32_t, int64_t> memo_;
     std::vector<VoiceMatch> found_;
 };

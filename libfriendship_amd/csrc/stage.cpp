@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <memory>
+#include <string>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -89,14 +90,21 @@ struct Planner {
 
 // Adds a voice to the launch that shares its kind (balanced: partial count; general: all together), time slot
 // and destination kind.
-void add_voice(std::vector<BankLaunch> &banks, std::unordered_map<uint64_t, size_t> &grp, const VoiceMatch &vm, uint32_t row, bool ring) {
-    uint64_t key = ((uint64_t)(vm.general ? 63u : vm.log2_p) << 34) | ((uint64_t)vm.input_slot << 2) | (vm.general ? 2u : 0u) | (ring ? 1u : 0u);
+void add_voice(std::vector<BankLaunch> &banks, std::unordered_map<std::string, size_t> &grp, const VoiceMatch &vm, uint32_t row, bool ring) {
+    std::string key = std::to_string(vm.general ? 63u : vm.log2_p) + "/" + std::to_string(vm.input_slot) + (vm.general ? "g" : "") + (ring ? "r" : "");
+    if (vm.jit) {   // same generated source (shape, which columns vary, literal values) and same inputs share a launch
+        key += "j" + vm.shape.key();
+        for (uint32_t sl : vm.shape.input_slots) key += "s" + std::to_string(sl);
+        for (size_t c = 0; c < vm.varying.size(); ++c)
+            key += vm.varying[c] ? ("v" + std::to_string(vm.alias[c])) : ("l" + std::to_string(vm.literal_bits[c]));
+    }
     auto gi = grp.find(key);
     if (gi == grp.end()) {
         gi = grp.emplace(key, banks.size()).first;
         BankLaunch bl;
         bl.log2_p = vm.log2_p; bl.input_slot = vm.input_slot; bl.to_ring = ring; bl.general = vm.general;
         if (vm.general) bl.group_off.push_back(0);
+        if (vm.jit) { bl.jit = true; bl.shape = vm.shape; bl.varying = vm.varying; bl.literal_bits = vm.literal_bits; bl.alias = vm.alias; bl.k = vm.k; }
         banks.push_back(std::move(bl));
     }
     BankLaunch &bl = banks[gi->second];
@@ -210,11 +218,11 @@ bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unorde
 
 }  // namespace
 
-StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p) {
+StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p, bool allow_jit) {
     StagedPlan sp;
     const uint32_t n_rows = (uint32_t)g.outputs.size();
     std::unique_ptr<BankMatcher> matcher;
-    if (allow_banks) matcher.reset(new BankMatcher(g, max_log2_p));
+    if (allow_banks) matcher.reset(new BankMatcher(g, max_log2_p, allow_jit));
     Planner P(g, matcher.get());
 
     std::vector<uint32_t> staged_rows;
@@ -249,7 +257,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         // budget exceeded somewhere: keep only rows whose root is itself a bank (direct launches), pull the rest
         StagedPlan fb;
         fb.pull_rows = sp.pull_rows;
-        std::unordered_map<uint64_t, size_t> grp;
+        std::unordered_map<std::string, size_t> grp;
         for (uint32_t row : staged_rows) {
             auto it = P.bank_of.find(g.outputs[row]);
             if (it == P.bank_of.end()) { fb.pull_rows.push_back(row); continue; }
@@ -291,7 +299,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
 
     // bank launches: voices that go straight to one output row, and voices that fill rings
     {
-        std::unordered_map<uint64_t, size_t> grp;
+        std::unordered_map<std::string, size_t> grp;
         std::vector<uint32_t> bank_nodes;
         for (auto &kv : P.bank_of) bank_nodes.push_back(kv.first);
         std::sort(bank_nodes.begin(), bank_nodes.end());

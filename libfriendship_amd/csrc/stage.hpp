@@ -23,6 +23,13 @@ struct BankLaunch {
     std::vector<uint32_t> groups;    // general: group words of all voices, concatenated
     std::vector<uint32_t> group_off; // general: [voices + 1] first group of each voice
     uint32_t max_leaves = 0;
+    // jit == true: leaves of an arbitrary common shape, kernel specialised with hipRTC (jit.hpp); params = [voices][P][k]
+    bool jit = false;
+    LeafShape shape;
+    std::vector<bool> varying;
+    std::vector<uint32_t> literal_bits;
+    std::vector<uint32_t> alias;
+    uint32_t k = 0;
 };
 
 struct StagedPlan {
@@ -42,6 +49,6 @@ struct StagedPlan {
 };
 
 // allow_banks: recognise fused oscillator banks; allow_programs: stage everything else that qualifies.
-StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p);
+StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p, bool allow_jit = false);
 
 }  // namespace fr

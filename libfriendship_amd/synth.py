@@ -121,6 +121,24 @@ def partial_leaves(g, w, amp, time_slot=0):
     return g.binop(K_MUL, C(amp), y, n)
 
 
+def triangle_leaves(g, w, amp, time_slot=0, am_slot=None):
+    """A different partial: triangle wave  amp * (1 - 4*|phase - 0.5|), optionally amplitude-modulated by a second
+    input (leaf * in[am_slot]).  Not the hand-matched template: the engine specialises it with hipRTC (csrc/jit.hpp)."""
+    w = np.asarray(w, dtype=np.float32).ravel()
+    amp = np.asarray(amp, dtype=np.float32).ravel()
+    n = len(w)
+    f = np.float32
+    x = g.binop(K_MUL, IN(time_slot), C(w), n)
+    ph = g.binop(K_MOD, x, C(f(1.0)), n)
+    u = g.binop(K_SUM2, ph, C(f(-0.5)), n)
+    au = g.binop(K_MUL, C(f(-1.0)), g.binop(K_MIN, u, g.binop(K_MUL, C(f(-1.0)), u, n), n), n)
+    tri = g.binop(K_SUM2, C(f(1.0)), g.binop(K_MUL, C(f(-4.0)), au, n), n)
+    leaf = g.binop(K_MUL, C(amp), tri, n)
+    if am_slot is not None:
+        leaf = g.binop(K_MUL, leaf, IN(am_slot), n)
+    return leaf
+
+
 def sum_tree(g, leaves):
     """Balanced binary Sum2 tree per row of `leaves` [V, P]: adjacent pairs level by level (an odd
     element is carried up unchanged).  Returns the root handle per row."""

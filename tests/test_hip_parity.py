@@ -528,3 +528,54 @@ def test_short_device_calls_keep_history(hip_lib, oracle_lib):
             torch.cuda.synchronize()
             exp = ref.fill_buffer(2, k * T, (k + 1) * T, [t[k * T:(k + 1) * T]])
             assert same_bits(d_out.cpu().numpy(), exp), f"call {k}: " + first_diff(d_out.cpu().numpy(), exp)
+
+
+# ---- hipRTC-specialised voices: leaves of a shape the hand-written kernel does not know -------------------------------
+def _triangle_tree(V, P, am=False, delayed=False):
+    g = synth.GraphArrays()
+    p = synth.voice_params(V, P, seed=P + 1, detune=True)
+    leaves = synth.triangle_leaves(g, p["w"], p["amp"], am_slot=1 if am else None).reshape(V, P)
+    roots = synth.sum_tree(g, leaves)
+    g.edge(roots, 0, 0, np.arange(V, dtype=np.uint32))
+    n_out = V
+    if delayed:   # one more output: voice 0 plus itself 37 frames ago (the JIT bank then fills a ring)
+        d = g.binop(synth.K_SUM2, roots[0:1], g.binop(synth.K_DELAY, roots[0:1], synth.C(np.float32(37.0)), 1), 1)
+        g.edge(d, 0, 0, V)
+        n_out += 1
+    return g.finish(n_out)
+
+
+@pytest.mark.parametrize("V,P,T,am,delayed", [(3, 64, 200, False, False), (2, 1024, 130, False, False), (2, 128, 100, True, False),
+                                              (2, 32, 150, True, True), (1, 8192, 70, False, False)])
+def test_jit_specialised_voices(hip_lib, oracle_lib, V, P, T, am, delayed):
+    tree = _triangle_tree(V, P, am, delayed)
+    n_out = tree["n_outputs"]
+    rng = np.random.default_rng(P)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        for k, idx in enumerate([0, T, 2 * T, 50 * T]):   # contiguous calls, then a seek
+            rows = [synth.time_ramp(idx, idx + T), (rng.normal(size=T) * 2).astype(np.float32)]
+            got, exp = hip.fill_buffer(n_out, idx, idx + T, rows), ref.fill_buffer(n_out, idx, idx + T, rows)
+            assert same_bits(got, exp), f"call {k}: " + first_diff(got, exp)
+        plan = hip.plan()
+        assert plan["pull_rows"] == 0 and plan["jit_kernels_compiled"] == 1, plan
+        jb = [b for b in plan["banks"] if b["jit"]]   # (voices that feed a ring launch separately from direct ones)
+        assert sum(b["voices"] for b in jb) == V and all(b["partials"] == P and b["leaf_params"] == 2 for b in jb), plan
+
+
+def test_jit_disabled_gives_the_same_bits(hip_lib, monkeypatch):
+    """FR_JIT=0: the same voices run as stage programs / pull instead of a specialised kernel; identical output."""
+    tree = _triangle_tree(2, 32, am=True)
+    T = 96
+    rows = [synth.time_ramp(0, T), np.linspace(-1, 1, T).astype(np.float32)]
+    with Renderer(hip_lib) as a:
+        synth.install(a, tree)
+        x = a.fill_buffer(2, 0, T, rows)
+        assert any(b["jit"] for b in a.plan()["banks"])
+    monkeypatch.setenv("FR_JIT", "0")
+    with Renderer(hip_lib) as b:
+        synth.install(b, tree)
+        y = b.fill_buffer(2, 0, T, rows)
+        assert not any(bk["jit"] for bk in b.plan()["banks"])
+    assert same_bits(x, y)
