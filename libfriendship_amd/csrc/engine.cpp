@@ -117,6 +117,7 @@ struct fr_renderer {
     bool timing = false;
     uint32_t bank_leaf_variant = 1;
     bool allow_jit = true;               // FR_JIT=0 disables hipRTC specialisation (those voices then run as programs / pull)
+    bool allow_template = true;          // FR_BANK_TEMPLATE=0 (A/B runs): template voices go through the JIT path literally
     JitCache jit_cache;
    // see kernels.hpp BankArgs::leaf_variant; FR_BANK_LEAF env overrides (A/B runs)
     TimerClass t_bank, t_pull, t_stage;
@@ -278,7 +279,7 @@ struct fr_renderer {
         p.n_slots = n_slots;
         p.fg = lower(mirror, n_slots);
         bool use_jit = allow_jit && mode == FR_MODE_AUTO;
-        p.sp = plan_stages(p.fg, mode == FR_MODE_AUTO, mode != FR_MODE_PULL, 20, use_jit);
+        p.sp = plan_stages(p.fg, mode == FR_MODE_AUTO, mode != FR_MODE_PULL, 20, use_jit, allow_template);
         std::vector<std::shared_ptr<JitKernel>> jits(p.sp.banks.size());
         if (use_jit) {
             try {
@@ -621,6 +622,7 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     r->mode = mode;
     if (const char *lv = std::getenv("FR_BANK_LEAF")) r->bank_leaf_variant = (lv[0] == '1') ? 1u : 0u;
     if (const char *jv = std::getenv("FR_JIT")) r->allow_jit = jv[0] != '0';
+    if (const char *tv = std::getenv("FR_BANK_TEMPLATE")) r->allow_template = tv[0] != '0';
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {
         delete r;
         return FR_ERR_DEVICE;

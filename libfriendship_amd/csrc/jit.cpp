@@ -27,6 +27,10 @@ __device__ __forceinline__ float jit_mod(float a, float b) {   // reference.rs:2
     float rem = fmodf(a, b);
     return rem < 0.0f ? rem + b : rem;
 }
+__device__ __forceinline__ float jit_mod1(float a) {           // Modulo(a, 1.0): fmodf(a, 1) == a - trunc(a) exactly for finite a
+    float rem = a - truncf(a);                                  // (inf - inf = NaN, like fmodf); then the same fix-up
+    return rem < 0.0f ? rem + 1.0f : rem;
+}
 __device__ __forceinline__ float jit_min(float a, float b) {   // Rust >= 1.20 f32::min
     return (a < b || b != b) ? a : b;
 }
@@ -106,7 +110,12 @@ std::string JitCache::generate_source(const LeafShape &shape, const std::vector<
         case OP_SUM2: leaf << "v" << o.a << " + v" << o.b; break;
         case OP_MUL: leaf << "v" << o.a << " * v" << o.b; break;
         case OP_DIV: leaf << "v" << o.a << " / v" << o.b; break;
-        case OP_MOD: leaf << "jit_mod(v" << o.a << ", v" << o.b << ")"; break;
+        case OP_MOD: {   // a literal divisor of exactly 1.0 (every oscillator's phase wrap) avoids the generic fmodf routine
+            const LeafShape::Op &d = shape.ops[o.b];
+            if (d.op == OP_CONST && !varying[d.a] && literal_bits[d.a] == 0x3F800000u) leaf << "jit_mod1(v" << o.a << ")";
+            else leaf << "jit_mod(v" << o.a << ", v" << o.b << ")";
+            break;
+        }
         default: leaf << "jit_min(v" << o.a << ", v" << o.b << ")"; break;
         }
         leaf << ";\n";

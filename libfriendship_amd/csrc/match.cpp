@@ -335,8 +335,8 @@ struct BankMatcher::Impl : Matcher {
     }
 };
 
-BankMatcher::BankMatcher(const FlatGraph &g, uint32_t max_log2_p, bool allow_jit)
-    : impl_(new Impl(g)), g_(g), max_log2_p_(max_log2_p), allow_jit_(allow_jit) {}
+BankMatcher::BankMatcher(const FlatGraph &g, uint32_t max_log2_p, bool allow_jit, bool allow_template)
+    : impl_(new Impl(g)), g_(g), max_log2_p_(max_log2_p), allow_jit_(allow_jit), allow_template_(allow_template) {}
 BankMatcher::~BankMatcher() { delete impl_; }
 
 bool BankMatcher::try_voice(uint32_t root, VoiceMatch &out) {
@@ -349,7 +349,7 @@ bool BankMatcher::try_voice(uint32_t root, VoiceMatch &out) {
     // height = number of Sum2 nodes on the leftmost path
     uint32_t h = 0, cur = root;
     while (g_.nodes[cur].op == OP_SUM2 && h <= max_log2_p_) { cur = g_.nodes[cur].a; ++h; }
-    if (h >= 5 && h <= max_log2_p_) {
+    if (allow_template_ && h >= 5 && h <= max_log2_p_) {
         VoiceMatch vm;
         vm.log2_p = h;
         vm.params.reserve((size_t)2 << h);
@@ -362,7 +362,7 @@ bool BankMatcher::try_voice(uint32_t root, VoiceMatch &out) {
             return true;
         }
     }
-    if (g_.nodes[root].op == OP_SUM2) {   // not a balanced power-of-two tree: try the general schedule
+    if (allow_template_ && g_.nodes[root].op == OP_SUM2) {   // not a balanced power-of-two tree: try the general schedule
         VoiceMatch vm;
         vm.general = true;
         if (impl_->emit_general(root, vm)) {

@@ -36,7 +36,7 @@ struct VoiceMatch {
 
 class BankMatcher {
 public:
-    BankMatcher(const FlatGraph &g, uint32_t max_log2_p, bool allow_jit = false);
+    BankMatcher(const FlatGraph &g, uint32_t max_log2_p, bool allow_jit = false, bool allow_template = true);
     ~BankMatcher();
     BankMatcher(const BankMatcher &) = delete;
     BankMatcher &operator=(const BankMatcher &) = delete;
@@ -49,6 +49,7 @@ private:
     const FlatGraph &g_;
     uint32_t max_log2_p_;
     bool allow_jit_;
+    bool allow_template_;   // false (FR_BANK_TEMPLATE=0, A/B runs only): skip the hand-matched partial template
     std::unordered_map<uint32_t, int64_t> memo_;
     std::vector<VoiceMatch> found_;
 };

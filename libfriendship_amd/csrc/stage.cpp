@@ -218,11 +218,11 @@ bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unorde
 
 }  // namespace
 
-StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p, bool allow_jit) {
+StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p, bool allow_jit, bool allow_template) {
     StagedPlan sp;
     const uint32_t n_rows = (uint32_t)g.outputs.size();
     std::unique_ptr<BankMatcher> matcher;
-    if (allow_banks) matcher.reset(new BankMatcher(g, max_log2_p, allow_jit));
+    if (allow_banks) matcher.reset(new BankMatcher(g, max_log2_p, allow_jit, allow_template));
     Planner P(g, matcher.get());
 
     std::vector<uint32_t> staged_rows;

@@ -49,6 +49,7 @@ struct StagedPlan {
 };
 
 // allow_banks: recognise fused oscillator banks; allow_programs: stage everything else that qualifies.
-StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p, bool allow_jit = false);
+StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p, bool allow_jit = false,
+                       bool allow_template = true);
 
 }  // namespace fr
