@@ -71,6 +71,23 @@ def cpu_baseline(tree, V, P, frames_1t, frames_mt):
 
 
 def main():
+    # Exactly ONE line may reach stdout.  Libraries write there too (RCCL prints a version banner at communicator
+    # creation), so the process's stdout is pointed at stderr for the whole run and the JSON line goes to the saved
+    # descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = run()
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+    if line is not None:
+        os.write(real_stdout, (line + "\n").encode())
+    os.close(real_stdout)
+
+
+def run():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -86,6 +103,8 @@ def main():
                     help="additive = BASELINE configs[2] shape (the headline); effects = configs[3] shape (detune + ADSR + "
                          "4-tap delay chain), a diagnostic run: use with --voices 128 --partials 1024 --no-cpu-baseline")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl is RCCL on ROCm (default)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even with one rank and take the partial-shard exchange path (RCCL plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=48)
     args = ap.parse_args()
@@ -103,8 +122,12 @@ def main():
     # (rehearsals on a one-GPU box: several ranks may share device 0 with --backend gloo)
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -113,7 +136,7 @@ def main():
     V, P, T, K, W = args.voices, args.partials, args.frames, args.steps, args.warmup
     t_build = time.perf_counter()
     from libfriendship_amd import shard
-    shard_mode = args.shard if world > 1 else "time"
+    shard_mode = args.shard if use_dist else "time"
     # seeded synthetic tree, ~12 primitive nodes per partial; under voices/partials sharding each rank
     # holds only its sub-graph
     if args.tree == "effects":
@@ -163,7 +186,7 @@ def main():
         return d_out
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     t0 = time.perf_counter()
@@ -180,7 +203,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -210,9 +233,9 @@ def main():
         host_rate = 5 * T / (time.perf_counter() - th) / 1e6
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
-        return
+        return None
 
     frames_total = (world if shard_mode == "time" else 1) * K * T
     value = frames_total / elapsed / 1e6
@@ -293,9 +316,9 @@ def main():
         except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
             result["cpu_baseline"] = {"error": repr(e)}
     result["checksum"] = float(np.abs(last.astype(np.float64)).sum())
-    print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    return json.dumps(result)
 
 
 if __name__ == "__main__":
