@@ -115,11 +115,11 @@ struct fr_renderer {
     DevBuf d_out, d_in_table, d_stack_node, d_stack_time, d_stack_val, d_bank_ws;
     std::vector<float> h_stage;
     bool timing = false;
-    uint32_t bank_leaf_variant = 1;
-    bool allow_jit = true;               // FR_JIT=0 disables hipRTC specialisation (those voices then run as programs / pull)
-    bool allow_template = true;          // FR_BANK_TEMPLATE=0 (A/B runs): template voices go through the JIT path literally
+    // A/B switches (environment, read at create; defaults are the measured best):
+    uint32_t bank_leaf_variant = 1;      // FR_BANK_LEAF=0: product-form leaves (kernels.hpp BankArgs::leaf_variant)
+    bool allow_jit = true;               // FR_JIT=0: no hipRTC specialisation (those voices run as programs / pull)
+    bool allow_template = true;          // FR_BANK_TEMPLATE=0: template voices go through the JIT path literally
     JitCache jit_cache;
-   // see kernels.hpp BankArgs::leaf_variant; FR_BANK_LEAF env overrides (A/B runs)
     TimerClass t_bank, t_pull, t_stage;
     DevBuf d_rings, d_in_table_stage;
     uint64_t ring_cap = 0;               // floats per ring (power of two)
