@@ -552,69 +552,82 @@ hipError_t launch_bank(const BankArgs &a, hipStream_t s) {
 // add is the tree's own add.  One wave per voice tile keeps the schedule sequential; voices x tiles give the
 // parallelism (this path exists for generality, the balanced kernel above is the fast one).
 // ---------------------------------------------------------------------------------------------------
-#define FR_STACK_REGS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+// The evaluation stack lives in LDS as [level][lane] columns (a lane only touches its own column: no barriers, no
+// bank conflicts); its pointer is wave-uniform.  (A first version kept the stack in 16 named registers selected by
+// compare ladders: 32 v_cndmask per group, 4x slower than the balanced kernel; profiles/r01_general_tree.txt.)
+constexpr uint32_t GB_MAX_DEPTH = 16;
 
 template <bool FAST>
-__device__ __forceinline__ float gbank_wave(const float *params, const uint32_t *gmeta, uint32_t ngroups, float t) {
-#define FR_DECL(i) float s##i = 0.0f;
-    FR_STACK_REGS(FR_DECL)
-#undef FR_DECL
+__device__ __forceinline__ float gbank_group(const ParamGroup &pg, uint32_t j, float t) {
+    float l0 = bank_leaf<FAST, false>(t, pg.w[0], pg.A[0]);
+    float v = l0;
+    if (j >= 1u) {
+        float l1 = bank_leaf<FAST, false>(t, pg.w[1], pg.A[1]);
+        v = l0 + l1;
+        if (j >= 2u) {
+            float l2 = bank_leaf<FAST, false>(t, pg.w[2], pg.A[2]);
+            float l3 = bank_leaf<FAST, false>(t, pg.w[3], pg.A[3]);
+            v = v + (l2 + l3);
+            if (j >= 3u) {
+                float l4 = bank_leaf<FAST, false>(t, pg.w[4], pg.A[4]);
+                float l5 = bank_leaf<FAST, false>(t, pg.w[5], pg.A[5]);
+                float l6 = bank_leaf<FAST, false>(t, pg.w[6], pg.A[6]);
+                float l7 = bank_leaf<FAST, false>(t, pg.w[7], pg.A[7]);
+                v = v + ((l4 + l5) + (l6 + l7));
+            }
+        }
+    }
+    return v;
+}
+
+template <bool FAST>
+__device__ __forceinline__ float gbank_wave(const float *params, const uint32_t *gmeta, uint32_t ngroups, float t, float *stack /* [GB_MAX_DEPTH][64] + lane */) {
     uint32_t sp = 0;
     const_f32_ptr p = (const_f32_ptr)params;
     typedef uint32_t __attribute__((address_space(4))) const *const_u32_ptr;
     const_u32_ptr gm = (const_u32_ptr)gmeta;
-    for (uint32_t g = 0; g < ngroups; ++g) {
-        ParamGroup pg;
-        load_group(pg, p, g);
-        const uint32_t meta = gm[g];
-        const uint32_t j = meta & 15u;
-        float l0 = bank_leaf<FAST, false>(t, pg.w[0], pg.A[0]);
-        float v = l0;
-        if (j >= 1u) {
-            float l1 = bank_leaf<FAST, false>(t, pg.w[1], pg.A[1]);
-            v = l0 + l1;
-            if (j >= 2u) {
-                float l2 = bank_leaf<FAST, false>(t, pg.w[2], pg.A[2]);
-                float l3 = bank_leaf<FAST, false>(t, pg.w[3], pg.A[3]);
-                v = v + (l2 + l3);
-                if (j >= 3u) {
-                    float l4 = bank_leaf<FAST, false>(t, pg.w[4], pg.A[4]);
-                    float l5 = bank_leaf<FAST, false>(t, pg.w[5], pg.A[5]);
-                    float l6 = bank_leaf<FAST, false>(t, pg.w[6], pg.A[6]);
-                    float l7 = bank_leaf<FAST, false>(t, pg.w[7], pg.A[7]);
-                    v = v + ((l4 + l5) + (l6 + l7));
-                }
-            }
-        }
+    ParamGroup pa, pb;
+    load_group(pa, p, 0);
+    uint32_t meta_a = gm[0], meta_b = 0;
+    auto finish = [&](float v, uint32_t meta) {
         for (uint32_t m = meta >> 4; m != 0u; --m) {   // v = pop() + v
             --sp;
-            float top = 0.0f;
-#define FR_POP(i) if (sp == i##u) top = s##i;
-            FR_STACK_REGS(FR_POP)
-#undef FR_POP
-            v = top + v;
+            v = stack[sp * 64u] + v;
         }
-#define FR_PUSH(i) if (sp == i##u) s##i = v;
-        FR_STACK_REGS(FR_PUSH)
-#undef FR_PUSH
+        stack[sp * 64u] = v;
         ++sp;
+    };
+    for (uint32_t g = 0; g < ngroups; g += 2) {
+        const bool has_b = g + 1 < ngroups;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (has_b) { load_group(pb, p, g + 1); meta_b = gm[g + 1]; }
+        finish(gbank_group<FAST>(pa, meta_a & 15u, t), meta_a);
+        if (has_b) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (g + 2 < ngroups) { load_group(pa, p, g + 2); meta_a = gm[g + 2]; }
+            finish(gbank_group<FAST>(pb, meta_b & 15u, t), meta_b);
+        }
     }
-    return s0;   // a well-formed schedule leaves exactly the root
+    return stack[0];   // a well-formed schedule leaves exactly the root
 }
 
-__global__ void __launch_bounds__(64) gbank_kernel(BankArgs a, uint32_t tiles, uint32_t nblocks) {
+// 4 independent waves per workgroup, each its own 64-frame tile of the same voice.
+__global__ void __launch_bounds__(256) gbank_kernel(BankArgs a, uint32_t tile_groups, uint32_t nblocks) {
+    __shared__ float stack_mem[4][GB_MAX_DEPTH][64];
     uint32_t b = blockIdx.x;
     uint32_t lid = (nblocks % 8u == 0u) ? (b % 8u) * (nblocks / 8u) + b / 8u : b;
-    const uint32_t voice = lid / tiles;
-    const uint32_t tile = lid - voice * tiles;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t voice = lid / tile_groups;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = (lid - voice * tile_groups) * 4u + wave;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint64_t ti = (uint64_t)tile * 64u + lane;
     const float t = bank_time(a, ti);
     const bool fast = a.fast_ok && __all(t >= 0.0f && t <= 4294967296.0f);
     const uint32_t g0 = a.group_off[voice], ng = a.group_off[voice + 1] - g0;
     const float2 *vparams = a.params + (size_t)g0 * 8u;
-    float r = fast ? gbank_wave<true>((const float *)vparams, a.groups + g0, ng, t)
-                   : gbank_wave<false>((const float *)vparams, a.groups + g0, ng, t);
+    float *stack = &stack_mem[wave][0][lane];
+    float r = fast ? gbank_wave<true>((const float *)vparams, a.groups + g0, ng, t, stack)
+                   : gbank_wave<false>((const float *)vparams, a.groups + g0, ng, t, stack);
     float *orow = a.out + (size_t)a.rows[voice] * a.out_stride;
     const bool live = ti < a.n_times;
     if (live) orow[bank_out_index(a, ti)] = r;
@@ -640,10 +653,10 @@ __global__ void __launch_bounds__(64) gbank_kernel(BankArgs a, uint32_t tiles, u
 
 hipError_t launch_gbank(const BankArgs &a, hipStream_t s) {
     if (!a.groups || !a.group_off) return hipErrorInvalidValue;
-    uint64_t tiles64 = (a.n_times + 63) / 64, nblocks64 = tiles64 * a.n_voices;
+    uint64_t tg64 = ((a.n_times + 63) / 64 + 3) / 4, nblocks64 = tg64 * a.n_voices;   // 4 tiles (waves) per workgroup
     if (nblocks64 == 0) return hipSuccess;
     if (nblocks64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gbank_kernel, dim3((uint32_t)nblocks64), dim3(64), 0, s, a, (uint32_t)tiles64, (uint32_t)nblocks64);
+    hipLaunchKernelGGL(gbank_kernel, dim3((uint32_t)nblocks64), dim3(256), 0, s, a, (uint32_t)tg64, (uint32_t)nblocks64);
     return hipGetLastError();
 }
 
