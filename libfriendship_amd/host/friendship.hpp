@@ -22,8 +22,11 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <set>
 #include <stdexcept>
@@ -745,6 +748,81 @@ struct Client {
     virtual void node_id(const routing::NodeHandle &, const routing::EffectId &) {}
     virtual ~Client() = default;
 };
+// chanclient.rs:11-50: every callback becomes a message on a thread-safe channel (std::sync::mpsc there; a
+// mutex-guarded queue with a condition variable here).  MpscClient::make() returns the client and its receiver.
+struct ClientMessage {
+    enum Kind { AudioRendered, NodeMeta, NodeId } kind;
+    Array2 buffer;                 // AudioRendered
+    uint64_t idx = 0;              // AudioRendered
+    routing::NodeHandle handle;    // NodeMeta / NodeId
+    routing::EffectMeta meta;      // NodeMeta
+    routing::EffectId id;          // NodeId
+};
+class Receiver {
+    friend class MpscClient;
+    struct Chan {
+        std::mutex m;
+        std::condition_variable cv;
+        std::deque<ClientMessage> q;
+    };
+    std::shared_ptr<Chan> ch_ = std::make_shared<Chan>();
+
+public:
+    ClientMessage recv() {   // blocks like Receiver::recv
+        std::unique_lock<std::mutex> lk(ch_->m);
+        ch_->cv.wait(lk, [&] { return !ch_->q.empty(); });
+        ClientMessage msg = std::move(ch_->q.front());
+        ch_->q.pop_front();
+        return msg;
+    }
+    std::optional<ClientMessage> try_recv() {
+        std::lock_guard<std::mutex> lk(ch_->m);
+        if (ch_->q.empty()) return std::nullopt;
+        ClientMessage msg = std::move(ch_->q.front());
+        ch_->q.pop_front();
+        return msg;
+    }
+};
+class MpscClient : public Client {
+    std::shared_ptr<Receiver::Chan> ch_;
+    void send(ClientMessage msg) {
+        {
+            std::lock_guard<std::mutex> lk(ch_->m);
+            ch_->q.push_back(std::move(msg));
+        }
+        ch_->cv.notify_one();
+    }
+
+public:
+    static std::pair<MpscClient, Receiver> make() {
+        Receiver rx;
+        MpscClient c;
+        c.ch_ = rx.ch_;
+        return {std::move(c), std::move(rx)};
+    }
+    void audio_rendered(Array2 buffer, uint64_t idx) override {
+        ClientMessage m{};
+        m.kind = ClientMessage::AudioRendered;
+        m.buffer = std::move(buffer);
+        m.idx = idx;
+        send(std::move(m));
+    }
+    void node_meta(const routing::NodeHandle &handle, const routing::EffectMeta &meta) override {
+        ClientMessage m{};
+        m.kind = ClientMessage::NodeMeta;
+        m.handle = handle;
+        m.meta = meta;
+        send(std::move(m));
+    }
+    void node_id(const routing::NodeHandle &handle, const routing::EffectId &id) override {
+        ClientMessage m{};
+        m.kind = ClientMessage::NodeId;
+        m.handle = handle;
+        m.id = id;
+        send(std::move(m));
+    }
+};
+
 }  // namespace client
 
 namespace dispatch {
@@ -775,6 +853,16 @@ struct OscResMan {
 };
 // dispatch.rs:30-43
 using OscToplevel = std::variant<OscRouteGraph::Msg, OscRenderer::Msg, OscResMan::Msg>;
+
+// The OSC address the reference's #[osc_address] attributes give each message (dispatch.rs:33-85).
+inline std::string osc_address(const OscToplevel &msg) {
+    if (auto *rg = std::get_if<OscRouteGraph::Msg>(&msg)) {
+        static const char *names[] = {"add_node", "add_edge", "del_node", "del_edge", "query_meta", "query_id"};
+        return std::string("/routegraph/") + names[rg->index()];
+    }
+    if (std::get_if<OscRenderer::Msg>(&msg)) return "/renderer/render";
+    return "/resman/add_dir";
+}
 
 // dispatch.rs:89-93
 struct Error : std::runtime_error {

@@ -302,6 +302,35 @@ static void routegraph_validation() {
     dispatch.dispatch(OscRouteGraph::DelNode{a});   // already deleted: Ok(())
 }
 
+// client/chanclient.rs: MpscClient forwards callbacks over a channel that another thread can drain; QueryMeta/QueryId
+// reach the client (dispatch.rs:132-145); messages carry the reference's OSC addresses.
+static void mpsc_client_and_queries() {
+    const char *lib = std::getenv("FRIENDSHIP_RENDERER_LIB");
+    auto [client, rx] = friendship::client::MpscClient::make();
+    std::unique_ptr<render::Renderer> r = std::make_unique<render::PluginRenderer>(lib);
+    Dispatch<std::unique_ptr<render::Renderer>, friendship::client::MpscClient> dispatch(std::move(r), std::move(client));
+    auto h = NodeHandle::make(1);
+    dispatch.dispatch(OscRouteGraph::AddNode{h, const_id()});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::new_to_null(h, EdgeWeight::make(f32_to_bits(0.25f), 0))});
+    dispatch.dispatch(OscRouteGraph::QueryMeta{h});
+    dispatch.dispatch(OscRouteGraph::QueryId{h});
+    dispatch.dispatch(OscRouteGraph::QueryId{NodeHandle::make(99)});   // unknown handle: only a warning, no message
+    dispatch.dispatch(render_range(0, 2, 1));
+    auto m1 = rx.recv(), m2 = rx.recv(), m3 = rx.recv();
+    if (m1.kind != friendship::client::ClientMessage::NodeMeta || m1.meta.id.name != "F32Constant") throw std::runtime_error("NodeMeta");
+    if (m2.kind != friendship::client::ClientMessage::NodeId || !m2.id.is_primitive()) throw std::runtime_error("NodeId");
+    if (m3.kind != friendship::client::ClientMessage::AudioRendered || m3.idx != 0) throw std::runtime_error("AudioRendered");
+    ASSERT_EQ_ARR(m3.buffer, array({0.25f, 0.25f}));
+    if (rx.try_recv()) throw std::runtime_error("unexpected extra message");
+    using friendship::dispatch::OscToplevel;
+    using friendship::dispatch::osc_address;
+    if (osc_address(OscToplevel(OscRouteGraph::Msg(OscRouteGraph::AddNode{h, const_id()}))) != "/routegraph/add_node" ||
+        osc_address(OscToplevel(OscRouteGraph::Msg(OscRouteGraph::QueryId{h}))) != "/routegraph/query_id" ||
+        osc_address(OscToplevel(OscRenderer::Msg(render_range(0, 1, 1)))) != "/renderer/render" ||
+        osc_address(OscToplevel(OscResMan::Msg(OscResMan::AddDir{"x"}))) != "/resman/add_dir")
+        throw std::runtime_error("osc_address");
+}
+
 int main(int argc, char **argv) {
     std::vector<std::pair<const char *, std::function<void()>>> tests = {
         {"render_zeros", render_zeros}, {"render_const", render_const}, {"render_delay", render_delay},
@@ -309,7 +338,7 @@ int main(int argc, char **argv) {
         {"render_mod", render_mod}, {"render_min", render_min},
         {"ext_render_passthrough", ext_render_passthrough}, {"ext_render_delay", ext_render_delay},
         {"load_multby2", load_multby2}, {"effect_desc_json", effect_desc_json},
-        {"routegraph_validation", routegraph_validation}};
+        {"routegraph_validation", routegraph_validation}, {"mpsc_client_and_queries", mpsc_client_and_queries}};
     int failed = 0, ran = 0;
     for (auto &t : tests) {
         if (argc > 1 && std::string(argv[1]) != t.first) continue;

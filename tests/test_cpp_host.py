@@ -14,7 +14,7 @@ HDR = os.path.join(ROOT, "libfriendship_amd", "host", "friendship.hpp")
 def build():
     if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
         os.makedirs(os.path.dirname(BIN), exist_ok=True)
-        subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-o", BIN, SRC, "-ldl"], check=True)
+        subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", "-o", BIN, SRC, "-ldl"], check=True)
     return BIN
 
 
@@ -22,7 +22,7 @@ def run(lib):
     env = dict(os.environ, FRIENDSHIP_RENDERER_LIB=lib)
     p = subprocess.run([build()], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert "13 passed; 0 failed" in p.stdout, p.stdout
+    assert "14 passed; 0 failed" in p.stdout, p.stdout
 
 
 def test_reference_tests_through_cpp_dispatch_on_oracle(oracle_lib):
