@@ -654,6 +654,7 @@ fr_status fr_on_del_edge(fr_renderer *r, const fr_edge *edge) {
 fr_status fr_on_add_nodes(fr_renderer *r, const uint32_t *handles, const fr_effect *const *effects, size_t n) {
     return guarded(r, [&] {
         if (n && (!handles || !effects)) throw Error(FR_ERR_INVALID_ARG, "null array");
+        r->mirror.nodes.reserve(r->mirror.nodes.size() + n);
         for (size_t i = 0; i < n; ++i) r->mirror.add_node(handles[i], effects[i]);
     });
 }

@@ -117,7 +117,7 @@ void Mirror::add_node(uint32_t handle, const fr_effect *e) {  // reference.rs:11
     MNode n;
     n.kind = e->kind;
     if (e->kind == FR_EFFECT_GRAPH) n.sub = intern(e, 0);
-    nodes[handle] = std::move(n);
+    nodes.set(handle, std::move(n));
     ++version;
 }
 
@@ -131,10 +131,9 @@ void Mirror::add_edge(const fr_edge &e) {  // reference.rs:124-126,141-153
     if (e.to == 0) {
         set_slot(outputs, e.to_slot, r);
     } else {
-        auto it = nodes.find(e.to);
-        if (it == nodes.end())
-            throw Error(FR_ERR_NO_SUCH_NODE, "add_edge: destination node " + std::to_string(e.to) + " unknown");
-        set_slot(it->second.inbound, e.to_slot, r);
+        MNode *n = nodes.find(e.to);
+        if (!n) throw Error(FR_ERR_NO_SUCH_NODE, "add_edge: destination node " + std::to_string(e.to) + " unknown");
+        set_slot(n->inbound, e.to_slot, r);
     }
     ++version;
 }
@@ -144,10 +143,9 @@ void Mirror::del_edge(const fr_edge &e) {  // reference.rs:127-136
     if (e.to == 0) {
         inbound = &outputs;
     } else {
-        auto it = nodes.find(e.to);
-        if (it == nodes.end())
-            throw Error(FR_ERR_NO_SUCH_NODE, "Attempt to delete edge, but it was never created!");
-        inbound = &it->second.inbound;
+        MNode *n = nodes.find(e.to);
+        if (!n) throw Error(FR_ERR_NO_SUCH_NODE, "Attempt to delete edge, but it was never created!");
+        inbound = &n->inbound;
     }
     if (e.to_slot < inbound->size()) (*inbound)[e.to_slot] = EdgeRef{};
     ++version;
@@ -184,18 +182,16 @@ uint32_t FlatGraph::push(FlatOp op, uint32_t a, uint32_t b, uint32_t depth) {
 }
 
 uint32_t FlatGraph::konst(uint32_t bits) {
-    auto it = cse_[OP_CONST].find(bits);
-    if (it != cse_[OP_CONST].end()) return it->second;
-    uint32_t id = push(OP_CONST, bits, 0, 0);
-    cse_[OP_CONST].emplace(bits, id);
-    return id;
+    uint64_t &slot = cse_[OP_CONST].get(bits);
+    if (!slot) slot = (uint64_t)push(OP_CONST, bits, 0, 0) + 1;
+    return (uint32_t)(slot - 1);
 }
 
 uint32_t FlatGraph::input(uint32_t slot) {
-    auto it = cse_[OP_INPUT].find(slot);
-    if (it != cse_[OP_INPUT].end()) return it->second;
+    uint64_t &e = cse_[OP_INPUT].get(slot);
+    if (e) return (uint32_t)(e - 1);
     uint32_t id = push(OP_INPUT, slot, 0, 0);
-    cse_[OP_INPUT].emplace(slot, id);
+    cse_[OP_INPUT].get(slot) = (uint64_t)id + 1;   // (push() does not touch this map, but re-fetch the slot anyway)
     if (!has_input || slot > max_input_slot) max_input_slot = slot;
     has_input = true;
     return id;
@@ -217,11 +213,11 @@ uint32_t FlatGraph::make(FlatOp op, uint32_t a, uint32_t b) {
         if ((op == OP_SUM2 || op == OP_MUL) && a > b) std::swap(a, b);
     }
     uint64_t key = ((uint64_t)a << 32) | b;
-    auto it = cse_[op].find(key);
-    if (it != cse_[op].end()) return it->second;
+    uint64_t &e = cse_[op].get(key);
+    if (e) return (uint32_t)(e - 1);
     uint32_t d = 1 + std::max(nodes[a].depth, nodes[b].depth);
     uint32_t id = push(op, a, b, d);
-    cse_[op].emplace(key, id);
+    e = (uint64_t)id + 1;
     return id;
 }
 
@@ -235,17 +231,6 @@ struct Ctx {
     const SubGraph *g;       // null for the root
 };
 
-struct Key {
-    int ctx;
-    const MNode *node;
-    bool operator==(const Key &o) const { return ctx == o.ctx && node == o.node; }
-};
-struct KeyHash {
-    size_t operator()(const Key &k) const {
-        return (size_t)mix((uint64_t)(uintptr_t)k.node, (uint64_t)(uint32_t)k.ctx);
-    }
-};
-
 struct Frame {
     int ctx;
     const MNode *node;
@@ -253,25 +238,27 @@ struct Frame {
     uint32_t vals[2];
 };
 
-constexpr int64_t IN_PROGRESS = -1;
 
 struct Lowerer {
     const Mirror &m;
     FlatGraph fg;
     std::vector<Ctx> ctxs;
-    std::unordered_map<Key, int, KeyHash> child_ctx;
-    std::unordered_map<Key, int64_t, KeyHash> memo;
+    // keyed by (context << 32 | dense position of the node inside its graph): exact, no pointer hashing
+    FlatMap64 child_ctx;   // -> context id + 1
+    FlatMap64 memo;        // -> lowered id + 2; 1 = evaluation in progress
 
     explicit Lowerer(const Mirror &mm) : m(mm) { ctxs.push_back(Ctx{-1, nullptr, nullptr}); }
 
     const MNode *find(int ctx, uint32_t handle) const {
         const SubGraph *g = ctxs[ctx].g;
-        if (!g) {
-            auto it = m.nodes.find(handle);
-            return it == m.nodes.end() ? nullptr : &it->second;
-        }
+        if (!g) return m.nodes.find(handle);
         auto it = g->index.find(handle);
         return it == g->index.end() ? nullptr : &g->nodes[it->second];
+    }
+    uint64_t key(int ctx, const MNode *n) const {
+        const SubGraph *g = ctxs[ctx].g;
+        uint32_t pos = g ? (uint32_t)(n - g->nodes.data()) : m.nodes.position(n);
+        return ((uint64_t)(uint32_t)ctx << 32) | pos;
     }
 
     // Follows an edge through graph inputs and composite outputs until it lands on a value that is
@@ -300,16 +287,12 @@ struct Lowerer {
             if (!n) throw Error(FR_ERR_NO_SUCH_NODE, "edge reads from unknown node " + std::to_string(ref.from));
             ++fg.n_mirror_nodes_visited;
             if (n->kind == FR_EFFECT_GRAPH) {  // reference.rs:188-194
-                Key k{ctx, n};
-                auto it = child_ctx.find(k);
-                int cc;
-                if (it == child_ctx.end()) {
-                    cc = (int)ctxs.size();
+                uint64_t &cc_slot = child_ctx.get(key(ctx, n));
+                if (!cc_slot) {
                     ctxs.push_back(Ctx{ctx, n, n->sub.get()});
-                    child_ctx.emplace(k, cc);
-                } else {
-                    cc = it->second;
+                    cc_slot = ctxs.size();   // id + 1
                 }
+                int cc = (int)(cc_slot - 1);
                 uint32_t slot = ref.from_slot;
                 ref = slot < n->sub->outputs.size() ? n->sub->outputs[slot] : EdgeRef{};
                 ctx = cc;
@@ -322,13 +305,11 @@ struct Lowerer {
             if (ref.from_slot != 0)  // assert!(from_slot == 0), reference.rs:199,223,...
                 throw Error(FR_ERR_BAD_SLOT, "primitive node " + std::to_string(ref.from) + " read through output slot " +
                                                  std::to_string(ref.from_slot));
-            Key k{ctx, n};
-            auto it = memo.find(k);
-            if (it != memo.end()) {
-                if (it->second == IN_PROGRESS)
+            if (const uint64_t *mv = memo.find(key(ctx, n))) {
+                if (*mv == 1)
                     throw Error(FR_ERR_CYCLE, "dependency cycle through node " + std::to_string(ref.from) +
                                                   " (feedback is not evaluable by this engine)");
-                out = (uint32_t)it->second;
+                out = (uint32_t)(*mv - 2);
                 return true;
             }
             need = Frame{ctx, n, 0, {0, 0}};
@@ -353,7 +334,7 @@ struct Lowerer {
         if (resolve(ctx0, root, result, need)) return result;
         std::vector<Frame> stack;
         stack.push_back(need);
-        memo[Key{need.ctx, need.node}] = IN_PROGRESS;
+        memo.get(key(need.ctx, need.node)) = 1;
         while (!stack.empty()) {
             Frame &f = stack.back();
             if (f.next < 2) {
@@ -364,13 +345,13 @@ struct Lowerer {
                 if (resolve(f.ctx, ref, id, child)) {
                     f.vals[f.next++] = id;
                 } else {
-                    memo[Key{child.ctx, child.node}] = IN_PROGRESS;
+                    memo.get(key(child.ctx, child.node)) = 1;
                     stack.push_back(child);  // invalidates f; loop re-reads the top
                 }
                 continue;
             }
             uint32_t id = fg.make(op_of(f.node->kind), f.vals[0], f.vals[1]);
-            memo[Key{f.ctx, f.node}] = id;
+            memo.get(key(f.ctx, f.node)) = (uint64_t)id + 2;
             stack.pop_back();
             if (stack.empty()) {
                 result = id;

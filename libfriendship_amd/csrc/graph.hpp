@@ -13,6 +13,7 @@
 #pragma once
 
 #include <cstdint>
+#include <deque>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -22,6 +23,61 @@
 #include "../../include/friendship_render.h"
 
 namespace fr {
+
+// Open-addressing hash map, u64 -> u64 (linear probing, power-of-two capacity).  Lowering a multi-million-node
+// graph is dominated by hash lookups; this is ~3x faster than the node-based std::unordered_map for that use.
+class FlatMap64 {
+    static constexpr uint64_t EMPTY = ~0ull;   // keys must not be ~0
+    std::vector<uint64_t> keys_, vals_;
+    size_t n_ = 0, mask_ = 0;
+    // Groups of 16 consecutive keys stay adjacent (one or two cache lines) and the groups are scattered by a full
+    // mix: handles and node ids are mostly consecutive, so this keeps lowering cache-friendly without the long runs
+    // that make linear probing degenerate under an identity hash.
+    static uint64_t hash(uint64_t k) {
+        uint64_t g = k >> 4;
+        g ^= g >> 33; g *= 0xff51afd7ed558ccdULL; g ^= g >> 33; g *= 0xc4ceb9fe1a85ec53ULL; g ^= g >> 33;
+        return (g << 4) | (k & 15u);
+    }
+    void grow() {
+        std::vector<uint64_t> ok = std::move(keys_), ov = std::move(vals_);
+        size_t cap = ok.empty() ? 64 : ok.size() * 2;
+        keys_.assign(cap, EMPTY);
+        vals_.assign(cap, 0);
+        mask_ = cap - 1;
+        n_ = 0;
+        for (size_t i = 0; i < ok.size(); ++i)
+            if (ok[i] != EMPTY) *slot(ok[i]) = ov[i];
+    }
+    uint64_t *slot(uint64_t k) {   // existing or fresh slot for k (capacity must allow it)
+        size_t i = hash(k) & mask_;
+        while (keys_[i] != EMPTY && keys_[i] != k) i = (i + 1) & mask_;
+        if (keys_[i] == EMPTY) { keys_[i] = k; ++n_; }
+        return &vals_[i];
+    }
+
+public:
+    size_t size() const { return n_; }
+    void reserve(size_t n) { while (keys_.size() * 3 < n * 4 + 4) grow(); }
+    const uint64_t *find(uint64_t k) const {
+        if (keys_.empty()) return nullptr;
+        size_t i = hash(k) & mask_;
+        while (keys_[i] != EMPTY) {
+            if (keys_[i] == k) return &vals_[i];
+            i = (i + 1) & mask_;
+        }
+        return nullptr;
+    }
+    uint64_t *find(uint64_t k) { return const_cast<uint64_t *>(static_cast<const FlatMap64 *>(this)->find(k)); }
+    // value slot for k, inserted as 0 if absent; `inserted` tells which
+    uint64_t &get(uint64_t k, bool *inserted = nullptr) {
+        if ((n_ + 1) * 4 > keys_.size() * 3) grow();
+        size_t before = n_;
+        uint64_t *v = slot(k);
+        if (inserted) *inserted = n_ != before;
+        return *v;
+    }
+    void clear() { keys_.clear(); vals_.clear(); n_ = 0; mask_ = 0; }
+};
 
 struct Error : std::runtime_error {
     fr_status code;
@@ -39,6 +95,7 @@ struct SubGraph;
 
 struct MNode {
     int32_t kind = 0;                          // FR_PRIM_* or FR_EFFECT_GRAPH
+    uint32_t pos = 0;                          // dense position inside the owning table (top level only)
     std::shared_ptr<const SubGraph> sub;       // composite definition (interned)
     std::vector<EdgeRef> inbound;              // by to_slot
 };
@@ -60,7 +117,42 @@ public:
     void add_edge(const fr_edge &e);
     void del_edge(const fr_edge &e);
 
-    std::unordered_map<uint32_t, MNode> nodes;   // top level, mutable
+    // top-level nodes: handle -> MNode (stable storage + flat index; deleted entries are recycled)
+    class NodeTable {
+        std::deque<MNode> store_;                // stable addresses, no element moves on growth
+        std::vector<uint32_t> free_;
+        FlatMap64 index_;                        // handle -> position + 1 (0 = deleted)
+    public:
+        const MNode *find(uint32_t handle) const {
+            const uint64_t *p = index_.find(handle);
+            return (p && *p) ? &store_[*p - 1] : nullptr;
+        }
+        MNode *find(uint32_t handle) { return const_cast<MNode *>(static_cast<const NodeTable *>(this)->find(handle)); }
+        const MNode &at(uint32_t handle) const {
+            const MNode *n = find(handle);
+            if (!n) throw std::out_of_range("no such node");
+            return *n;
+        }
+        void set(uint32_t handle, MNode &&n) {   // HashMap::insert: replaces an existing entry
+            uint64_t &pos = index_.get(handle);
+            if (!pos) {
+                if (!free_.empty()) { pos = free_.back() + 1; free_.pop_back(); }
+                else { store_.emplace_back(); pos = store_.size(); }
+            }
+            n.pos = (uint32_t)(pos - 1);
+            store_[pos - 1] = std::move(n);
+        }
+        void erase(uint32_t handle) {
+            uint64_t *p = index_.find(handle);
+            if (p && *p) { store_[*p - 1] = MNode{}; free_.push_back((uint32_t)(*p - 1)); *p = 0; }
+        }
+        size_t size() const { return store_.size() - free_.size(); }
+        void reserve(size_t n) { index_.reserve(n); }   // batch inserts: one table allocation instead of repeated regrowth
+        // position of a node inside the table (a dense id for per-node side tables)
+        uint32_t position(const MNode *n) const { return n->pos; }
+        size_t capacity_positions() const { return store_.size(); }
+    };
+    NodeTable nodes;
     std::vector<EdgeRef> outputs;
     uint64_t version = 0;                        // bumped by every edit
 
@@ -101,7 +193,7 @@ struct FlatGraph {
     float const_val(uint32_t id) const;
 
 private:
-    std::unordered_map<uint64_t, uint32_t> cse_[8];
+    FlatMap64 cse_[8];   // (a << 32 | b) -> node id + 1
     uint32_t push(FlatOp op, uint32_t a, uint32_t b, uint32_t depth);
 };
 
