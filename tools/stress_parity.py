@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""One-off parity stress on an MI355X: many seeded random graphs (all 7 primitives, nested composites, constant and
+signal-driven delays) through every engine mode against the CPU oracle, with contiguous calls, short rows, seeks.
+Not part of the default test suite (minutes, not seconds).   usage: python tools/stress_parity.py [n_seeds]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import randgraph  # noqa: E402
+from kat_replay import same_bits  # noqa: E402
+import libfriendship_amd  # noqa: E402
+from libfriendship_amd import synth  # noqa: E402
+from libfriendship_amd.capi import RenderError, Renderer, RendererLib  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    hip = libfriendship_amd.hip_lib()
+    oracle = RendererLib(os.path.join(ROOT, "oracle", "_build", "libfr_oracle.so"))
+    bad = 0
+    for seed in range(n):
+        rng = np.random.default_rng(seed)
+        steps, n_out = randgraph.random_graph(10_000 + seed, n_nodes=int(rng.integers(3, 70)), n_inputs=2, n_outputs=3,
+                                              signal_delays=bool(seed % 3))
+        T = int(rng.integers(1, 200))
+        calls = [(0, T), (T, 2 * T), (2 * T, 3 * T), (int(rng.integers(4 * T, 10**6)), None)]
+        with Renderer(oracle) as ref:
+            randgraph.install_steps(ref, steps)
+            modes = {m: Renderer(hip, mode=m) for m in ("auto", "staged", "pull")}
+            for r in modes.values():
+                randgraph.install_steps(r, steps)
+            for k, (s, e) in enumerate(calls):
+                e = e if e is not None else s + T
+                n_t = e - s
+                rows = [synth.time_ramp(s, e)[: n_t if k != 1 else int(rng.integers(0, n_t + 1))],
+                        (rng.normal(size=n_t) * 3).astype(np.float32)]
+                try:
+                    exp = ref.fill_buffer(n_out, s, e, rows)
+                except RenderError as err:
+                    for m, r in modes.items():
+                        try:
+                            r.fill_buffer(n_out, s, e, rows)
+                            print(f"seed {seed} mode {m}: oracle raised {err.status}, engine did not")
+                            bad += 1
+                        except RenderError as e2:
+                            if e2.status != err.status:
+                                print(f"seed {seed} mode {m}: status {e2.status} != {err.status}")
+                                bad += 1
+                    break
+                for m, r in modes.items():
+                    got = r.fill_buffer(n_out, s, e, rows)
+                    if not same_bits(got, exp):
+                        print(f"seed {seed} mode {m} call {k}: MISMATCH")
+                        bad += 1
+            for r in modes.values():
+                r.close()
+        if seed % 50 == 49:
+            print(f"{seed + 1} graphs, {bad} problems", flush=True)
+    print(f"done: {n} graphs x 3 modes, {bad} problems")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
