@@ -673,6 +673,16 @@ __device__ __forceinline__ float stage_input(const StageArgs &a, uint32_t slot, 
     return s.data[t - s.base];
 }
 
+__device__ __forceinline__ float stage_load(const StageArgs &a, const StageInstr &in, uint64_t t) {
+    switch (in.op) {
+    case S_CONST: return __uint_as_float(in.imm);
+    case S_INPUT: return stage_input(a, in.imm, t);
+    case S_READ: return t >= in.d_lo ? a.rings[(size_t)in.buf * (a.ring_mask + 1) + ((t - in.d_lo) & a.ring_mask)] : 0.0f;
+    case S_READ_INPUT: return t >= in.d_lo ? stage_input(a, in.imm, t - in.d_lo) : 0.0f;
+    default: return t >= in.d_lo ? __uint_as_float(in.imm) : 0.0f;   // S_STEP
+    }
+}
+
 __global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
     __shared__ float tmp[STAGE_REGS][256];
     const uint64_t wi = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -680,21 +690,30 @@ __global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
     const uint64_t t = a.w0 + wi;
     const StageProg pg = a.progs[blockIdx.y];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = 0; i < pg.n_instr; ++i) {
-        const StageInstr in = a.instrs[pg.first_instr + i];
+    const StageInstr *gins = a.instrs + pg.first_instr;
+    auto fetch = [&](uint32_t i) -> StageInstr { return gins[i]; };
+    // 1. the program's loads (ring reads at t - d, inputs, constants), all in flight together
+    {
+        float ld[STAGE_MAX_HOISTED];
+#pragma unroll
+        for (uint32_t i = 0; i < STAGE_MAX_HOISTED; ++i)
+            if (i < pg.n_loads) ld[i] = stage_load(a, fetch(i), t);
+#pragma unroll
+        for (uint32_t i = 0; i < STAGE_MAX_HOISTED; ++i)
+            if (i < pg.n_loads) tmp[fetch(i).dst][tid] = ld[i];
+    }
+    // 2. everything else in program order
+    for (uint32_t i = pg.n_loads; i < pg.n_instr; ++i) {
+        const StageInstr in = fetch(i);
         float v;
         switch (in.op) {
-        case S_CONST: v = __uint_as_float(in.imm); break;
-        case S_INPUT: v = stage_input(a, in.imm, t); break;
-        case S_READ: v = t >= in.d_lo ? a.rings[(size_t)in.buf * (a.ring_mask + 1) + ((t - in.d_lo) & a.ring_mask)] : 0.0f; break;
-        case S_READ_INPUT: v = t >= in.d_lo ? stage_input(a, in.imm, t - in.d_lo) : 0.0f; break;
-        case S_STEP: v = t >= in.d_lo ? __uint_as_float(in.imm) : 0.0f; break;
         case S_SUM2: v = tmp[in.a][tid] + tmp[in.b][tid]; break;
         case S_MUL: v = tmp[in.a][tid] * tmp[in.b][tid]; break;
         case S_DIV: v = tmp[in.a][tid] / tmp[in.b][tid]; break;
         case S_MOD: v = prim_mod(tmp[in.a][tid], tmp[in.b][tid]); break;
+        case S_MIN: v = prim_min(tmp[in.a][tid], tmp[in.b][tid]); break;
         case S_STORE: a.rings[(size_t)in.buf * (a.ring_mask + 1) + (t & a.ring_mask)] = tmp[in.a][tid]; continue;
-        default: v = prim_min(tmp[in.a][tid], tmp[in.b][tid]); break;
+        default: v = stage_load(a, in, t); break;   // a load that was not hoisted (register budget)
         }
         tmp[in.dst][tid] = v;
     }

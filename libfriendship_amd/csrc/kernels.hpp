@@ -97,10 +97,13 @@ struct StageProg {
     uint32_t result_reg;
     uint32_t dst_ring;     // ring to store into, or 0xFFFFFFFF
     int32_t out_row;       // output row to store into (frames >= idx), or -1
-    uint32_t pad[3];
+    uint32_t n_loads;      // the first n_loads instructions are loads/constants with no register operands: the kernel
+                           // issues them back to back so their memory latencies overlap (<= STAGE_MAX_HOISTED)
+    uint32_t pad[2];
 };
 constexpr int STAGE_REGS = 48;
 constexpr uint32_t STAGE_INLINE_INPUTS = 8;
+constexpr uint32_t STAGE_MAX_HOISTED = 24;
 struct StageArgs {
     const StageInstr *instrs;
     const StageProg *progs;    // programs of this level

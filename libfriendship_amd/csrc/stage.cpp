@@ -121,6 +121,7 @@ void add_voice(std::vector<BankLaunch> &banks, std::unordered_map<std::string, s
 struct ProgBuild {
     std::vector<StageInstr> instrs;   // `buf` holds the cut NODE id until rings are assigned
     uint32_t result_reg = 0;
+    uint32_t n_loads = 0;             // leading instructions without register operands (hoisted loads)
     std::vector<std::pair<uint32_t, uint64_t>> reads;   // (cut node, delay)
 };
 
@@ -156,6 +157,20 @@ bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unorde
             ++uses[x.b];
             st.push_back({x.b, 0});
             st.push_back({x.a, 0});
+        }
+    }
+    // Loads first (they have no register operands), so the kernel can overlap their latencies; only when that does
+    // not inflate register pressure beyond the hoisting window.
+    {
+        auto is_load = [&](uint32_t n) {
+            const FlatNode &x = g.nodes[n];
+            return is_boundary(n) || x.op == OP_CONST || x.op == OP_INPUT || x.op == OP_DELAY;
+        };
+        size_t n_loads = 0;
+        for (uint32_t n : order) n_loads += is_load(n) ? 1 : 0;
+        if (n_loads <= STAGE_MAX_HOISTED) {
+            std::stable_partition(order.begin(), order.end(), is_load);
+            out.n_loads = (uint32_t)n_loads;
         }
     }
     std::vector<uint8_t> free_regs;
@@ -213,6 +228,11 @@ bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unorde
         }
     }
     out.result_reg = reg_of.at(m);
+    // the hoisted prefix is whatever leading run of loads the final instruction list has (an S_STORE of an inlined
+    // Delay-rooted cut node may sit among them and ends the prefix)
+    uint32_t lead = 0;
+    while (lead < out.instrs.size() && lead < out.n_loads && out.instrs[lead].op <= S_STEP) ++lead;
+    out.n_loads = lead;
     return true;
 }
 
@@ -348,6 +368,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         pg.result_reg = pd.pb->result_reg;
         pg.dst_ring = pd.dst_ring;
         pg.out_row = pd.out_row;
+        pg.n_loads = pd.pb->n_loads;
         for (StageInstr in : pd.pb->instrs) {
             if (in.op == S_READ) in.buf = ring_of.at(in.buf);
             sp.instrs.push_back(in);
@@ -375,6 +396,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
             pg.result_reg = pb.result_reg;
             pg.dst_ring = dst_ring;
             pg.out_row = out_row;
+            pg.n_loads = pb.n_loads;
             for (StageInstr in : pb.instrs) {
                 if (in.op == S_READ || in.op == S_STORE) in.buf = ring_of.at(in.buf);
                 finstrs.push_back(in);
