@@ -82,6 +82,9 @@ struct Plan {
     std::vector<BankStage> banks;
     StagedPlan sp;                       // programs / levels / rings (banks moved into `banks`)
     DevBuf d_instrs, d_progs;
+    std::shared_ptr<JitKernel> stage_jit;   // compiled form of the programs (null: interpreted by stage_kernel)
+    DevBuf d_jprogs, d_ptab;
+    uint32_t stage_shapes = 0;
     bool stage_valid = false;            // rings hold [stage_end - lmax, stage_end) of the current graph + history
     uint64_t stage_end = 0;
     std::vector<uint32_t> pull_rows;     // output rows evaluated by the pull interpreter
@@ -119,6 +122,8 @@ struct fr_renderer {
     uint32_t bank_leaf_variant = 1;      // FR_BANK_LEAF=0: product-form leaves (kernels.hpp BankArgs::leaf_variant)
     bool allow_jit = true;               // FR_JIT=0: no hipRTC specialisation (those voices run as programs / pull)
     bool allow_template = true;          // FR_BANK_TEMPLATE=0: template voices go through the JIT path literally
+    int stage_jit_mode = 1;              // FR_STAGE_JIT=0: programs always interpreted; 1: compiled when >= 4 programs share
+                                         // a skeleton on average; 2 ("force"): compiled whenever they fit one kernel
     JitCache jit_cache;
     TimerClass t_bank, t_pull, t_stage;
     DevBuf d_rings, d_in_table_stage;
@@ -314,6 +319,22 @@ struct fr_renderer {
             p.d_progs.ensure(p.sp.progs.size() * sizeof(StageProg));
             HIP_CHECK(hipMemcpyAsync(p.d_instrs.p, p.sp.instrs.data(), p.sp.instrs.size() * sizeof(StageInstr), hipMemcpyHostToDevice, st));
             HIP_CHECK(hipMemcpyAsync(p.d_progs.p, p.sp.progs.data(), p.sp.progs.size() * sizeof(StageProg), hipMemcpyHostToDevice, st));
+            StageJitPlan sj;
+            if (allow_jit && stage_jit_mode != 0 && plan_stage_jit(p.sp.progs, p.sp.instrs, 32, stage_jit_mode == 2, sj)) {
+                try {
+                    p.stage_jit = jit_cache.get_source(sj.source, "jit_stage");
+                    p.stage_shapes = sj.n_shapes;
+                    p.d_jprogs.ensure(sj.progs.size() * sizeof(JitStageProg));
+                    p.d_ptab.ensure(std::max<size_t>(sj.ptab.size(), 1) * sizeof(uint32_t));
+                    HIP_CHECK(hipMemcpyAsync(p.d_jprogs.p, sj.progs.data(), sj.progs.size() * sizeof(JitStageProg), hipMemcpyHostToDevice, st));
+                    if (!sj.ptab.empty())
+                        HIP_CHECK(hipMemcpyAsync(p.d_ptab.p, sj.ptab.data(), sj.ptab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+                    HIP_CHECK(hipStreamSynchronize(st));   // `sj` goes out of scope
+                } catch (const Error &e) {   // keep the interpreter
+                    jit_error = e.what();
+                    p.stage_jit = nullptr;
+                }
+            }
         }
         p.pull_rows = p.sp.pull_rows;
         if (!p.pull_rows.empty()) {
@@ -353,6 +374,7 @@ struct fr_renderer {
         js << "],\"stage_programs\":" << (p.sp.progs.size() - p.sp.fused_count) << ",\"stage_instrs\":" << p.sp.instrs.size()
            << ",\"fused_programs\":" << p.sp.fused_count << ",\"fused_max_frames\":" << p.sp.fused_max_frames
            << ",\"stage_levels\":" << (p.sp.level_first.empty() ? 0 : p.sp.level_first.size() - 1)
+           << ",\"stage_jit\":" << (p.stage_jit ? "true" : "false") << ",\"stage_shapes\":" << p.stage_shapes
            << ",\"rings\":" << p.sp.n_rings << ",\"max_lookback\":" << p.sp.lmax
            << ",\"jit_kernels_compiled\":" << jit_cache.compiled() << ",\"jit_compile_ms\":" << jit_cache.compile_ms()
            << ",\"pull_rows\":" << p.pull_rows.size() << "}";
@@ -484,7 +506,25 @@ struct fr_renderer {
             const uint64_t n_sub = sp.fused_count ? (n_times + sp.fused_max_frames - 1) / sp.fused_max_frames : 0;
             const bool fused = sp.fused_count != 0 && w0 == idx && plan.stage_valid && n_sub < n_levels;
             auto launch_range = [&](uint32_t first, uint32_t count, uint64_t s0, uint64_t slen) {
-                for (uint32_t off = 0; off < count; off += 65535u) {   // grid.y limit
+                for (uint32_t off = 0; off < count && plan.stage_jit; off += 65535u) {   // grid.y limit
+                    JitStageArgs a{};
+                    a.ptab = plan.d_ptab.as<uint32_t>();
+                    a.progs = plan.d_jprogs.as<JitStageProg>() + first + off;
+                    a.rings = d_rings.as<float>();
+                    a.ring_mask = ring_cap ? ring_cap - 1 : 0;
+                    a.inputs = reinterpret_cast<const JitInput *>(d_in_table_stage.as<DevInput>());
+                    a.n_inputs = (uint32_t)tab.size();
+                    for (size_t i = 0; i < tab.size() && i < STAGE_INLINE_INPUTS; ++i) a.inline_inputs[i] = JitInput{tab[i].data, tab[i].base, tab[i].len};
+                    a.out = d_dst;
+                    a.n_times = n_times;
+                    a.idx = idx;
+                    a.w0 = s0;
+                    a.w_len = slen;
+                    Scope sc(this, &t_stage, st);
+                    HIP_CHECK(launch_jit_stage(*plan.stage_jit, a, std::min<uint32_t>(count - off, 65535u), st));
+                    sc.done();
+                }
+                for (uint32_t off = 0; off < count && !plan.stage_jit; off += 65535u) {
                     StageArgs a{};
                     a.instrs = plan.d_instrs.as<StageInstr>();
                     a.progs = plan.d_progs.as<StageProg>() + first + off;
@@ -623,6 +663,7 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     if (const char *lv = std::getenv("FR_BANK_LEAF")) r->bank_leaf_variant = (lv[0] == '1') ? 1u : 0u;
     if (const char *jv = std::getenv("FR_JIT")) r->allow_jit = jv[0] != '0';
     if (const char *tv = std::getenv("FR_BANK_TEMPLATE")) r->allow_template = tv[0] != '0';
+    if (const char *sv = std::getenv("FR_STAGE_JIT")) r->stage_jit_mode = sv[0] == '0' ? 0 : (sv[0] == '1' ? 1 : 2);
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {
         delete r;
         return FR_ERR_DEVICE;

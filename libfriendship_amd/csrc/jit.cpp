@@ -5,14 +5,12 @@
 
 #include <chrono>
 #include <cstdio>
+#include <map>
 #include <sstream>
 
 #include "graph.hpp"
 
 namespace fr {
-
-#define FR_STR2(...) #__VA_ARGS__
-#define FR_STR(...) FR_STR2(__VA_ARGS__)
 
 JitKernel::~JitKernel() {
     if (module) (void)hipModuleUnload(module);
@@ -140,7 +138,13 @@ std::string JitCache::generate_source(const LeafShape &shape, const std::vector<
 
 std::shared_ptr<JitKernel> JitCache::get(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
                                          const std::vector<uint32_t> &alias) {
-    std::string src = generate_source(shape, varying, literal_bits, alias);
+    std::shared_ptr<JitKernel> jk = get_source(generate_source(shape, varying, literal_bits, alias), "jit_bank");
+    if (!jk->k)
+        for (size_t c = 0; c < varying.size(); ++c) jk->k += (varying[c] && alias[c] == c) ? 1 : 0;
+    return jk;
+}
+
+std::shared_ptr<JitKernel> JitCache::get_source(const std::string &src, const char *fn_name) {
     auto it = cache_.find(src);
     if (it != cache_.end()) return it->second;
     auto t0 = std::chrono::steady_clock::now();
@@ -150,7 +154,7 @@ std::shared_ptr<JitKernel> JitCache::get(const LeafShape &shape, const std::vect
         throw Error(FR_ERR_DEVICE, "jit: cannot query the device");
     std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
     hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "fr_jit_bank.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+    if (hiprtcCreateProgram(&prog, src.c_str(), "fr_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         throw Error(FR_ERR_DEVICE, "jit: hiprtcCreateProgram failed");
     const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
                           "-fno-slp-vectorize", "-mllvm", "-simplifycfg-sink-common=false"};
@@ -169,12 +173,11 @@ std::shared_ptr<JitKernel> JitCache::get(const LeafShape &shape, const std::vect
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
     auto jk = std::make_shared<JitKernel>();
-    for (size_t c = 0; c < varying.size(); ++c) jk->k += (varying[c] && alias[c] == c) ? 1 : 0;
     if (hipModuleLoadData(&jk->module, code.data()) != hipSuccess) throw Error(FR_ERR_DEVICE, "jit: hipModuleLoadData failed");
-    if (hipModuleGetFunction(&jk->fn, jk->module, "jit_bank") != hipSuccess) throw Error(FR_ERR_DEVICE, "jit: kernel symbol missing");
+    if (hipModuleGetFunction(&jk->fn, jk->module, fn_name) != hipSuccess) throw Error(FR_ERR_DEVICE, "jit: kernel symbol missing");
     compile_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ++compiled_;
-    cache_.emplace(std::move(src), jk);
+    cache_.emplace(src, jk);
     return jk;
 }
 
@@ -183,6 +186,13 @@ hipError_t launch_jit_bank(const JitKernel &k, const JitBankArgs &a, hipStream_t
     JitBankArgs copy = a;
     void *args[] = {&copy};
     return hipModuleLaunchKernel(k.fn, a.nblocks, 1, 1, 256, 1, 1, 0, s, args, nullptr);
+}
+
+hipError_t launch_jit_stage(const JitKernel &k, const JitStageArgs &a, uint32_t n_progs, hipStream_t s) {
+    if (n_progs == 0 || a.w_len == 0) return hipSuccess;
+    JitStageArgs copy = a;
+    void *args[] = {&copy};
+    return hipModuleLaunchKernel(k.fn, (uint32_t)((a.w_len + 255) / 256), n_progs, 1, 256, 1, 1, 0, s, args, nullptr);
 }
 
 }  // namespace fr

@@ -19,9 +19,13 @@
 #include <string>
 #include <vector>
 
+#include "kernels.hpp"
 #include "leafshape.hpp"
 
 namespace fr {
+
+#define FR_STR2(...) #__VA_ARGS__
+#define FR_STR(...) FR_STR2(__VA_ARGS__)
 
 // Device-side argument block of a JIT bank kernel (kept in sync with the generated source by construction: the
 // struct's text below is compiled into both).
@@ -44,6 +48,39 @@ namespace fr {
     };
 FR_JIT_ARGS_TEXT
 
+// ---- stage programs ----------------------------------------------------------------------------------
+// The staged evaluator's register programs (stage.hpp) compiled instead of interpreted: programs with the same
+// instruction skeleton (ops + register wiring; the usual case is one skeleton per voice position in an effects
+// chain) share one straight-line function; what differs between them -- constants, ring ids, delays, input slots --
+// comes from a per-program parameter row read through the scalar cache.  One kernel per plan, blockIdx.y = program.
+#define FR_JIT_STAGE_ARGS_TEXT                                                                                 \
+    struct JitInput { const float *data; unsigned long long base; unsigned long long len; };                   \
+    struct JitStageProg { unsigned int shape, param_off, dst_ring; int out_row; };                            \
+    struct JitStageArgs {                                                                                      \
+        const unsigned int *ptab;       /* parameter rows */                                                   \
+        const JitStageProg *progs;      /* programs of this launch (blockIdx.y) */                             \
+        float *rings;                   /* [n_rings][ring_mask + 1] */                                         \
+        unsigned long long ring_mask;                                                                          \
+        const JitInput *inputs;         /* used when n_inputs > 8 */                                           \
+        JitInput inline_inputs[8];                                                                             \
+        unsigned int n_inputs;                                                                                 \
+        float *out;                     /* [n_slots][n_times] of the call */                                   \
+        unsigned long long n_times, idx, w0, w_len;                                                            \
+    };
+FR_JIT_STAGE_ARGS_TEXT
+static_assert(sizeof(JitInput) == sizeof(DevInput), "JitInput mirrors DevInput");
+
+struct StageJitPlan {
+    std::vector<JitStageProg> progs;    // parallel to StagedPlan::progs
+    std::vector<uint32_t> ptab;
+    std::string source;
+    uint32_t n_shapes = 0;
+};
+// Groups the programs by skeleton and writes the kernel source.  Returns false when specialisation is not worth a
+// compile: more than `max_shapes` skeletons, or (unless `force`) fewer than 4 programs per skeleton on average.
+bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<StageInstr> &instrs, uint32_t max_shapes, bool force,
+                    StageJitPlan &out);
+
 // One compiled specialisation.
 struct JitKernel {
     hipModule_t module = nullptr;
@@ -59,6 +96,8 @@ public:
     // alias[c]: the column whose parameter column c shares (c itself if none).
     std::shared_ptr<JitKernel> get(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
                                    const std::vector<uint32_t> &alias);
+    // any generated source with one extern "C" kernel `fn_name` (cached by source text)
+    std::shared_ptr<JitKernel> get_source(const std::string &src, const char *fn_name);
     static std::string generate_source(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
                                        const std::vector<uint32_t> &alias);
     size_t compiled() const { return compiled_; }
@@ -71,5 +110,6 @@ private:
 };
 
 hipError_t launch_jit_bank(const JitKernel &k, const JitBankArgs &a, hipStream_t s);
+hipError_t launch_jit_stage(const JitKernel &k, const JitStageArgs &a, uint32_t n_progs, hipStream_t s);
 
 }  // namespace fr

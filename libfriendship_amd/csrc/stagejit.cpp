@@ -1,0 +1,191 @@
+// stagejit.cpp -- source generation for compiled stage programs (see jit.hpp).  No HIP runtime calls in this file:
+// tests/cpp/plan_tests.cpp builds it for the CPU and runs the generated functions against the oracle.
+#include <cstdio>
+#include <map>
+#include <sstream>
+
+#include "jit.hpp"
+
+namespace fr {
+
+// ---- stage programs ----------------------------------------------------------------------------------
+static const char *kStageSkeleton = R"JIT(
+typedef unsigned int __attribute__((address_space(4))) const *cu32;
+typedef unsigned long long u64;
+
+__device__ __forceinline__ float jit_mod(float a, float b) {   // reference.rs:254-261
+    float rem = fmodf(a, b);
+    return rem < 0.0f ? rem + b : rem;
+}
+__device__ __forceinline__ float jit_mod1(float a) {           // Modulo(a, 1.0), see the bank skeleton
+    float rem = a - truncf(a);
+    return rem < 0.0f ? rem + 1.0f : rem;
+}
+__device__ __forceinline__ float jit_min(float a, float b) {   // Rust >= 1.20 f32::min
+    return (a < b || b != b) ? a : b;
+}
+__device__ __forceinline__ float f32(unsigned int bits) { return __builtin_bit_cast(float, bits); }
+__device__ __forceinline__ float in_at(const JitStageArgs &a, unsigned int slot, u64 t) {
+    if (slot >= a.n_inputs) return 0.0f;
+    JitInput s = a.n_inputs <= 8u ? a.inline_inputs[slot] : a.inputs[slot];
+    if (t < s.base || t >= s.len) return 0.0f;
+    return s.data[t - s.base];
+}
+__device__ __forceinline__ float in_delayed(const JitStageArgs &a, unsigned int slot, unsigned int d, u64 t) {
+    return t >= d ? in_at(a, slot, t - d) : 0.0f;
+}
+__device__ __forceinline__ float ring_read(const JitStageArgs &a, unsigned int buf, unsigned int d, u64 t) {
+    return t >= d ? a.rings[(size_t)buf * (a.ring_mask + 1) + ((t - d) & a.ring_mask)] : 0.0f;
+}
+__device__ __forceinline__ void ring_store(const JitStageArgs &a, unsigned int buf, u64 t, float v) {
+    a.rings[(size_t)buf * (a.ring_mask + 1) + (t & a.ring_mask)] = v;
+}
+__device__ __forceinline__ float step(unsigned int bits, unsigned int d, u64 t) { return t >= d ? f32(bits) : 0.0f; }
+
+SHAPE_FUNCTIONS
+
+extern "C" __global__ void __launch_bounds__(256) jit_stage(JitStageArgs a) {
+    const u64 wi = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (wi >= a.w_len) return;
+    const u64 t = a.w0 + wi;
+    const JitStageProg pg = a.progs[blockIdx.y];
+    cu32 P = (cu32)(a.ptab + pg.param_off);
+    float r;
+    switch (pg.shape) {
+SHAPE_CASES
+    default: r = 0.0f; break;
+    }
+    if (pg.dst_ring != 0xFFFFFFFFu) ring_store(a, pg.dst_ring, t, r);
+    if (pg.out_row >= 0 && t >= a.idx) a.out[(size_t)pg.out_row * a.n_times + (t - a.idx)] = r;
+}
+)JIT";
+
+namespace {
+// constants worth baking into the source: they enable peepholes (x mod 1.0, sign flips) and never come from a knob
+bool literal_worthy(uint32_t bits) {
+    switch (bits & 0x7FFFFFFFu) {
+    case 0x00000000u: case 0x3F800000u: case 0x3F000000u: case 0x40000000u: return true;   // 0, 1, 0.5, 2 (either sign)
+    default: return false;
+    }
+}
+}  // namespace
+
+bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<StageInstr> &instrs, uint32_t max_shapes, bool force,
+                    StageJitPlan &out) {
+    if (progs.empty()) return false;
+    struct Shape { uint32_t first; std::vector<uint32_t> members; std::vector<bool> literal; };
+    std::map<std::string, uint32_t> ids;
+    std::vector<Shape> shapes;
+    std::vector<uint32_t> shape_of(progs.size());
+    for (size_t p = 0; p < progs.size(); ++p) {
+        const StageProg &pg = progs[p];
+        std::string key;
+        key.reserve(pg.n_instr * 4 + 8);
+        for (uint32_t i = 0; i < pg.n_instr; ++i) {
+            const StageInstr &in = instrs[pg.first_instr + i];
+            key.push_back((char)in.op); key.push_back((char)in.dst); key.push_back((char)in.a); key.push_back((char)in.b);
+        }
+        key.push_back((char)pg.result_reg);
+        auto it = ids.emplace(std::move(key), (uint32_t)shapes.size());
+        if (it.second) {
+            if (shapes.size() >= max_shapes) return false;
+            shapes.push_back(Shape{(uint32_t)p, {}, {}});
+        }
+        shape_of[p] = it.first->second;
+        shapes[it.first->second].members.push_back((uint32_t)p);
+    }
+    if (!force && progs.size() < 4 * shapes.size()) return false;
+
+    // literal constants: same bits in every member and a peephole-enabling value
+    for (Shape &s : shapes) {
+        const StageProg &p0 = progs[s.first];
+        s.literal.assign(p0.n_instr, false);
+        for (uint32_t i = 0; i < p0.n_instr; ++i) {
+            const StageInstr &i0 = instrs[p0.first_instr + i];
+            if (i0.op != S_CONST || !literal_worthy(i0.imm)) continue;
+            bool same = true;
+            for (uint32_t m : s.members) same = same && instrs[progs[m].first_instr + i].imm == i0.imm;
+            s.literal[i] = same;
+        }
+    }
+
+    // source
+    std::ostringstream fns, cases;
+    for (size_t si = 0; si < shapes.size(); ++si) {
+        const Shape &s = shapes[si];
+        const StageProg &p0 = progs[s.first];
+        fns << "__device__ __forceinline__ float shape" << si << "(const JitStageArgs &a, cu32 P, u64 t) {\n    (void)a; (void)P; (void)t;\n";
+        int var_of[256];
+        for (int &x : var_of) x = -1;
+        std::vector<bool> is_one(p0.n_instr, false);
+        uint32_t k = 0;
+        for (uint32_t i = 0; i < p0.n_instr; ++i) {
+            const StageInstr &in = instrs[p0.first_instr + i];
+            char buf[96];
+            if (in.op == S_STORE) {
+                fns << "    ring_store(a, P[" << k << "], t, v" << var_of[in.a] << ");\n";
+                k += 1;
+                continue;
+            }
+            fns << "    float v" << i << " = ";
+            switch (in.op) {
+            case S_CONST:
+                if (s.literal[i]) {
+                    std::snprintf(buf, sizeof buf, "f32(0x%08xu)", in.imm);
+                    fns << buf;
+                    is_one[i] = in.imm == 0x3F800000u;
+                } else { fns << "f32(P[" << k << "])"; k += 1; }
+                break;
+            case S_INPUT: fns << "in_at(a, P[" << k << "], t)"; k += 1; break;
+            case S_READ: fns << "ring_read(a, P[" << k << "], P[" << k + 1 << "], t)"; k += 2; break;
+            case S_READ_INPUT: fns << "in_delayed(a, P[" << k << "], P[" << k + 1 << "], t)"; k += 2; break;
+            case S_STEP: fns << "step(P[" << k << "], P[" << k + 1 << "], t)"; k += 2; break;
+            case S_SUM2: fns << "v" << var_of[in.a] << " + v" << var_of[in.b]; break;
+            case S_MUL: fns << "v" << var_of[in.a] << " * v" << var_of[in.b]; break;
+            case S_DIV: fns << "v" << var_of[in.a] << " / v" << var_of[in.b]; break;
+            case S_MOD:
+                if (is_one[var_of[in.b]]) fns << "jit_mod1(v" << var_of[in.a] << ")";
+                else fns << "jit_mod(v" << var_of[in.a] << ", v" << var_of[in.b] << ")";
+                break;
+            default: fns << "jit_min(v" << var_of[in.a] << ", v" << var_of[in.b] << ")"; break;
+            }
+            fns << ";\n";
+            var_of[in.dst] = (int)i;
+        }
+        fns << "    return v" << var_of[p0.result_reg] << ";\n}\n";
+        cases << "    case " << si << ": r = shape" << si << "(a, P, t); break;\n";
+    }
+    std::ostringstream src;
+    src << "#pragma clang fp contract(off)\n" << FR_STR(FR_JIT_STAGE_ARGS_TEXT) << "\n";
+    std::string body = kStageSkeleton;
+    auto put = [&](const std::string &tag, const std::string &text) { body.replace(body.find(tag), tag.size(), text); };
+    put("SHAPE_FUNCTIONS", fns.str());
+    put("SHAPE_CASES", cases.str());
+    src << body;
+    out.source = src.str();
+    out.n_shapes = (uint32_t)shapes.size();
+
+    // parameter rows, in the order the functions above consume them
+    out.progs.resize(progs.size());
+    out.ptab.clear();
+    for (size_t p = 0; p < progs.size(); ++p) {
+        const StageProg &pg = progs[p];
+        const Shape &s = shapes[shape_of[p]];
+        JitStageProg jp{shape_of[p], (uint32_t)out.ptab.size(), pg.dst_ring, pg.out_row};
+        for (uint32_t i = 0; i < pg.n_instr; ++i) {
+            const StageInstr &in = instrs[pg.first_instr + i];
+            switch (in.op) {
+            case S_CONST: if (!s.literal[i]) out.ptab.push_back(in.imm); break;
+            case S_INPUT: out.ptab.push_back(in.imm); break;
+            case S_READ: out.ptab.push_back(in.buf); out.ptab.push_back(in.d_lo); break;
+            case S_READ_INPUT: case S_STEP: out.ptab.push_back(in.imm); out.ptab.push_back(in.d_lo); break;
+            case S_STORE: out.ptab.push_back(in.buf); break;
+            default: break;
+            }
+        }
+        out.progs[p] = jp;
+    }
+    return true;
+}
+
+}  // namespace fr

@@ -6,6 +6,7 @@
 //
 // Build: g++ -std=c++17 -O1 -ffp-contract=off -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -o plan_tests plan_tests.cpp -ldl
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdio>
@@ -13,11 +14,13 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <random>
 
 #include "../../libfriendship_amd/csrc/graph.cpp"
 #include "../../libfriendship_amd/csrc/match.cpp"
 #include "../../libfriendship_amd/csrc/stage.cpp"
+#include "../../libfriendship_amd/csrc/stagejit.cpp"
 
 using namespace fr;
 
@@ -466,12 +469,200 @@ static void composite_instances_are_interned() {
     for (uint64_t t = 0; t < 3; ++t) CHECK(flat_eval(fg, fg.outputs[0], t, in) == 25.0f * (t + 1));
 }
 
+
+// ---- compiled stage programs (stagejit.cpp) on the CPU -------------------------------------------------------------
+// The generated kernel source is plain C++ apart from a few HIP keywords: with those defined away it compiles with
+// g++ and jit_stage() can be driven thread by thread.  This checks the code generator (skeleton grouping, parameter
+// rows, SSA wiring, literal peepholes) against the oracle without a GPU; the GPU tests check hipRTC's build of it.
+static const char *kCpuPrelude = R"CPU(
+#include <cmath>
+#include <cstddef>
+#define __device__
+#define __forceinline__ inline
+#define __global__
+#define __launch_bounds__(x)
+struct Idx3 { unsigned x, y, z; };
+static Idx3 blockIdx, threadIdx;
+extern "C" void set_thread(unsigned bx, unsigned by, unsigned tx) { blockIdx = Idx3{bx, by, 0}; threadIdx = Idx3{tx, 0, 0}; }
+)CPU";
+
+struct CpuJit {
+    void *so = nullptr;
+    void (*set_thread)(unsigned, unsigned, unsigned) = nullptr;
+    void (*kernel)(JitStageArgs) = nullptr;
+    explicit CpuJit(const std::string &source) {
+        static int serial = 0;
+        std::string base = "/tmp/fr_stagejit_" + std::to_string((long)getpid()) + "_" + std::to_string(serial++);
+        FILE *f = std::fopen((base + ".cpp").c_str(), "w");
+        CHECK(f != nullptr);
+        std::fputs(kCpuPrelude, f);
+        std::fputs(source.c_str(), f);
+        std::fclose(f);
+        std::string cmd = "g++ -std=c++20 -O1 -ffp-contract=off -w -shared -fPIC -o " + base + ".so " + base + ".cpp";
+        CHECK(std::system(cmd.c_str()) == 0);
+        so = dlopen((base + ".so").c_str(), RTLD_NOW | RTLD_LOCAL);
+        CHECK(so != nullptr);
+        set_thread = (void (*)(unsigned, unsigned, unsigned))dlsym(so, "set_thread");
+        kernel = (void (*)(JitStageArgs))dlsym(so, "jit_stage");
+        CHECK(set_thread && kernel);
+        std::remove((base + ".cpp").c_str());
+        std::remove((base + ".so").c_str());
+    }
+    ~CpuJit() { if (so) dlclose(so); }
+};
+
+// engine.cpp's execute() for the compiled form: real ring arrays (power-of-two capacity, indexed t & mask).
+struct JitSim {
+    const StagedPlan &sp;
+    StageJitPlan sj;
+    std::unique_ptr<CpuJit> jit;
+    uint64_t cap = 0;
+    std::vector<float> rings;
+    bool valid = false;
+    uint64_t end = 0;
+    JitSim(const StagedPlan &p, uint64_t T) : sp(p) {
+        CHECK(plan_stage_jit(sp.progs, sp.instrs, 64, true, sj));
+        jit.reset(new CpuJit(sj.source));
+        cap = 1024;
+        while (cap < sp.lmax + T) cap <<= 1;
+        rings.assign((size_t)std::max<uint32_t>(sp.n_rings, 1) * cap, -55.0f);
+    }
+    void launch(uint32_t first, uint32_t count, uint64_t w0, uint64_t wlen, uint64_t idx, uint64_t T, const Inputs &in, std::vector<float> &out) {
+        JitStageArgs a{};
+        a.ptab = sj.ptab.data();
+        a.progs = sj.progs.data() + first;
+        a.rings = rings.data();
+        a.ring_mask = cap - 1;
+        a.n_inputs = (uint32_t)sp.input_slots.size();
+        CHECK(a.n_inputs <= 8);
+        for (uint32_t i = 0; i < a.n_inputs; ++i) {
+            uint32_t slot = sp.input_slots[i];
+            if (slot < in.size()) a.inline_inputs[i] = JitInput{in[slot].data(), 0, in[slot].size()};
+        }
+        a.out = out.data();
+        a.n_times = T; a.idx = idx; a.w0 = w0; a.w_len = wlen;
+        for (uint32_t y = 0; y < count; ++y)
+            for (uint32_t bx = 0; bx < (wlen + 255) / 256; ++bx)
+                for (uint32_t tx = 0; tx < 256; ++tx) { jit->set_thread(bx, y, tx); jit->kernel(a); }
+    }
+    void call(uint64_t idx, uint64_t T, const Inputs &in, std::vector<float> &out) {
+        uint64_t w0 = idx;
+        if (sp.uses_rings() && !(valid && end == idx)) w0 = idx > sp.lmax ? idx - sp.lmax : 0;
+        uint64_t wlen = idx + T - w0;
+        for (const BankLaunch &bl : sp.banks)
+            for (size_t v = 0; v < bl.rows.size(); ++v) {
+                uint64_t b0 = bl.to_ring ? w0 : idx, blen = bl.to_ring ? wlen : T;
+                for (uint64_t t = b0; t < b0 + blen; ++t) {
+                    float val = bank_voice_host(bl, v, in_at(in, bl.input_slot, t));
+                    if (bl.to_ring) rings[(size_t)bl.rows[v] * cap + (t & (cap - 1))] = val;
+                    else out[(size_t)bl.rows[v] * T + (t - idx)] = val;
+                }
+            }
+        size_t n_levels = sp.level_first.empty() ? 0 : sp.level_first.size() - 1;
+        uint64_t n_sub = sp.fused_count ? (T + sp.fused_max_frames - 1) / sp.fused_max_frames : 0;
+        bool fused = sp.fused_count && w0 == idx && valid && n_sub < n_levels;
+        if (fused) {
+            for (uint64_t s0 = idx; s0 < idx + T; s0 += sp.fused_max_frames)
+                launch(sp.fused_first, sp.fused_count, s0, std::min<uint64_t>(sp.fused_max_frames, idx + T - s0), idx, T, in, out);
+        } else {
+            for (size_t l = 0; l < n_levels; ++l)
+                launch(sp.level_first[l], sp.level_first[l + 1] - sp.level_first[l], w0, wlen, idx, T, in, out);
+        }
+        if (sp.uses_rings()) { valid = true; end = idx + T; }
+    }
+};
+
+static void check_compiled_programs(const Build &b, uint32_t n_slots, uint64_t T, const std::vector<uint64_t> &starts, const char *what,
+                                    std::function<void(const StageJitPlan &)> inspect = nullptr) {
+    Mirror m;
+    b.apply(m);
+    FlatGraph fg = lower(m, n_slots);
+    StagedPlan sp = plan_stages(fg, true, true, 20);
+    CHECK(!sp.progs.empty());
+    JitSim sim(sp, T);
+    if (std::getenv("FR_TEST_VERBOSE")) std::fprintf(stderr, "%s: progs %zu fused %u levels %zu shapes %u\n", what, sp.progs.size(), sp.fused_count, sp.level_first.size() - 1, sim.sj.n_shapes);
+    if (inspect) inspect(sim.sj);
+    fr_renderer *ref = b.apply_oracle();
+    Inputs hist(2);
+    std::mt19937 rng(11);
+    std::normal_distribution<float> nd(0.0f, 3.0f);
+    for (uint64_t idx : starts) {
+        std::vector<float> row0(T), row1(T);
+        for (uint64_t i = 0; i < T; ++i) { row0[i] = (float)(idx + i); row1[i] = nd(rng); }
+        for (auto &h : hist) h.resize(idx, 0.0f);   // a seek leaves zeros behind (reference.rs:52-60); starts only grow here
+        hist[0].insert(hist[0].end(), row0.begin(), row0.end());
+        hist[1].insert(hist[1].end(), row1.begin(), row1.end());
+        std::vector<float> data(row0);
+        data.insert(data.end(), row1.begin(), row1.end());
+        uint64_t offs[3] = {0, T, 2 * T};
+        std::vector<float> exp((size_t)n_slots * T), got((size_t)n_slots * T, -77.0f);
+        CHECK(oracle().fill(ref, exp.data(), n_slots, T, idx, data.data(), offs, 2) == FR_OK);
+        sim.call(idx, T, hist, got);
+        for (uint32_t s = 0; s < n_slots; ++s) {
+            if (std::find(sp.pull_rows.begin(), sp.pull_rows.end(), s) != sp.pull_rows.end()) continue;
+            for (uint64_t i = 0; i < T; ++i)
+                if (!same_bits(got[(size_t)s * T + i], exp[(size_t)s * T + i])) {
+                    std::fprintf(stderr, "%s: compiled programs differ from oracle at slot %u t %llu: %a vs %a\n", what, s,
+                                 (unsigned long long)(idx + i), got[(size_t)s * T + i], exp[(size_t)s * T + i]);
+                    throw std::runtime_error("mismatch");
+                }
+        }
+    }
+    oracle().destroy(ref);
+}
+
+static void stage_programs_compile_to_source() {
+    // 6 voices through the same chain: one skeleton per chain position (level form) + the fused form's
+    std::mt19937 rng(13);
+    Build b;
+    const uint32_t V = 6;
+    for (uint32_t v = 0; v < V; ++v) {
+        uint32_t mix = voice(b, 16, 55.0f * (v + 1), rng);
+        uint32_t lfo = b.op(FR_PRIM_MODULO, N(b.op(FR_PRIM_MULTIPLY, In(0), Cf(0.01f * (v + 1)))), Cf(1.0f));   // x mod 1.0 peephole
+        uint32_t a = b.op(FR_PRIM_MINIMUM, N(b.op(FR_PRIM_DIVIDE, In(0), Cf(20.0f + v))), N(lfo));
+        uint32_t x = b.op(FR_PRIM_MULTIPLY, N(a), N(mix));
+        for (int j = 0; j < 3; ++j) {
+            uint32_t dl = b.op(FR_PRIM_DELAY, N(x), Cf(70.0f * (j + 1) + v));
+            x = b.op(FR_PRIM_SUM2, N(x), N(b.op(FR_PRIM_MULTIPLY, Cf(-1.0f), N(dl))));
+        }
+        b.out(N(x), v);
+    }
+    uint32_t dn = b.op(FR_PRIM_DELAY, In(1), Cf(5.0f));
+    b.out(N(b.op(FR_PRIM_MODULO, N(b.op(FR_PRIM_SUM2, N(dn), N(b.op(FR_PRIM_DELAY, Cf(2.0f), Cf(3.0f))))), Cf(0.75f))), V);
+    check_compiled_programs(b, V + 1, 90, {0, 90, 180, 270, 2000, 2090}, "compiled effects chain", [&](const StageJitPlan &sj) {
+        CHECK(sj.n_shapes == 4);                                            // x0, x1..x3 (one skeleton), the fused sink, the odd row
+        CHECK(sj.source.find("jit_mod1(") != std::string::npos);            // Modulo(x, 1.0) was recognised
+        CHECK(sj.source.find("jit_mod(") != std::string::npos);             // Modulo(x, 0.75) was not
+        CHECK(sj.source.find("f32(0xbf800000u)") != std::string::npos);     // -1.0 shared by all members: a literal
+    });
+    check_compiled_programs(b, V + 1, 30, {0, 30, 60, 90, 120}, "compiled effects chain, calls shorter than the delays");
+    // random graphs: every program its own skeleton
+    for (int seed = 0; seed < 12; ++seed) {
+        std::mt19937 r2(400 + seed);
+        Build g;
+        std::vector<uint32_t> pool;
+        auto pick = [&]() -> Operand {
+            uint32_t k = r2() % 10;
+            if (k < 2 || pool.empty()) return k % 2 ? In(r2() % 2) : Cf((float)((int)(r2() % 41) - 20) * 0.25f);
+            return N(pool[r2() % pool.size()]);
+        };
+        const int kinds[5] = {FR_PRIM_SUM2, FR_PRIM_MULTIPLY, FR_PRIM_DIVIDE, FR_PRIM_MODULO, FR_PRIM_MINIMUM};
+        for (int i = 0; i < 30; ++i) {
+            if (r2() % 5 == 0) pool.push_back(g.op(FR_PRIM_DELAY, pick(), Cf((float)(r2() % 50))));
+            else pool.push_back(g.op(kinds[r2() % 5], pick(), pick()));
+        }
+        for (uint32_t s = 0; s < 3; ++s) g.out(N(pool[pool.size() - 1 - s]), s);
+        check_compiled_programs(g, 3, 64, {0, 64, 128, 900}, "compiled random graph");
+    }
+}
+
 int main(int argc, char **argv) {
     std::vector<std::pair<const char *, std::function<void()>>> tests = {
         {"lowering_folds_constants", lowering_folds_constants}, {"lowering_errors", lowering_errors},
         {"random_graphs_lower_correctly", random_graphs_lower_correctly}, {"banks_are_recognised", banks_are_recognised},
         {"effects_chain_is_staged", effects_chain_is_staged}, {"dynamic_delay_goes_to_pull", dynamic_delay_goes_to_pull},
-        {"composite_instances_are_interned", composite_instances_are_interned}};
+        {"composite_instances_are_interned", composite_instances_are_interned},
+        {"stage_programs_compile_to_source", stage_programs_compile_to_source}};
     int failed = 0, ran = 0;
     for (auto &t : tests) {
         if (argc > 1 && std::string(argv[1]) != t.first) continue;

@@ -327,9 +327,7 @@ def test_staged_matches_pull_on_larger_chain(hip_lib):
         assert a.plan()["stage_programs"] > 0 and b.plan()["stage_programs"] == 0
 
 
-@pytest.mark.parametrize("seed", range(24))
-def test_random_graphs_staged_mode(hip_lib, oracle_lib, seed):
-    """Random graphs with constant delays only, forced through the staged evaluator (no fused banks)."""
+def _random_staged_case(hip_lib, oracle_lib, seed, expect_jit=None):
     rng = np.random.default_rng(5000 + seed)
     steps, n_out = randgraph.random_graph(100 + seed, n_nodes=int(rng.integers(4, 40)), n_inputs=2, n_outputs=3,
                                           signal_delays=False)
@@ -351,6 +349,42 @@ def test_random_graphs_staged_mode(hip_lib, oracle_lib, seed):
                 return
             got = hip.fill_buffer(n_out, start, start + T, rows)
             assert same_bits(got, exp), f"seed {seed} call {k}: " + first_diff(got, exp)
+        plan = hip.plan()
+        if expect_jit is not None and plan["stage_programs"] > 0:
+            assert plan["stage_jit"] is expect_jit, plan
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_graphs_staged_mode(hip_lib, oracle_lib, seed):
+    """Random graphs with constant delays only, forced through the staged evaluator (no fused banks).  Every program
+    has its own skeleton here, so they are interpreted (stage_kernel)."""
+    _random_staged_case(hip_lib, oracle_lib, seed, expect_jit=False)
+
+
+@pytest.mark.parametrize("seed", range(0, 24, 2))
+def test_random_graphs_compiled_stage_programs(hip_lib, oracle_lib, seed, monkeypatch):
+    """The same graphs with FR_STAGE_JIT=force: every program goes through source generation + hipRTC (jit_stage)."""
+    monkeypatch.setenv("FR_STAGE_JIT", "force")
+    _random_staged_case(hip_lib, oracle_lib, seed, expect_jit=True)
+
+
+@pytest.mark.parametrize("V,P,taps,delay,T", [(16, 32, 3, 50.0, 128), (24, 16, 4, 7.0, 33)])
+def test_effects_chain_compiled_stage_programs(hip_lib, oracle_lib, V, P, taps, delay, T, monkeypatch):
+    """Many voices through the same effects chain: the programs share skeletons, so the default plan compiles them
+    (level form on the first call / after the seek, fused form in steady state).  FR_STAGE_JIT=0 gives the same bits."""
+    tree = synth.effects_tree(V, P, taps=taps, base_delay=delay)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        _effects_sequence(hip, ref, V, T, calls=5, seek_to=10 * T + 3)
+        plan = hip.plan()
+        assert plan["stage_jit"] is True and 0 < plan["stage_shapes"] <= 2 * (taps + 2), plan
+    monkeypatch.setenv("FR_STAGE_JIT", "0")
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        _effects_sequence(hip, ref, V, T, calls=3)
+        assert hip.plan()["stage_jit"] is False
 
 
 def test_graph_edit_rebuilds_delay_state(hip_lib, oracle_lib):
