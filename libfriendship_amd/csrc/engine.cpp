@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <sstream>
 #include <string>
@@ -78,7 +79,7 @@ struct Plan {
     bool valid = false;
     uint64_t version = 0;
     uint32_t n_slots = 0;
-    FlatGraph fg;
+    uint32_t max_depth = 0;              // of the lowered graph (pull stack sizing)
     std::vector<BankStage> banks;
     StagedPlan sp;                       // programs / levels / rings (banks moved into `banks`)
     DevBuf d_instrs, d_progs;
@@ -125,6 +126,10 @@ struct fr_renderer {
     int stage_jit_mode = 1;              // FR_STAGE_JIT=0: programs always interpreted; 1: compiled when >= 4 programs share
                                          // a skeleton on average; 2 ("force"): compiled whenever they fit one kernel
     JitCache jit_cache;
+    Lowering lowering;                   // lowered graph, kept up to date across edits
+    std::unique_ptr<BankMatcher> matcher;   // voice recognition memo over lowering's graph (same generation)
+    uint64_t matcher_gen = 0;
+    uint64_t plans_built = 0, plans_incremental = 0;
     TimerClass t_bank, t_pull, t_stage;
     DevBuf d_rings, d_in_table_stage;
     uint64_t ring_cap = 0;               // floats per ring (power of two)
@@ -282,9 +287,16 @@ struct fr_renderer {
         Plan p;
         p.version = mirror.version;
         p.n_slots = n_slots;
-        p.fg = lower(mirror, n_slots);
+        const auto t_begin = std::chrono::steady_clock::now();
+        const FlatGraph &fg = lowering.update(mirror, n_slots);
+        const double lower_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        p.max_depth = fg.max_depth;
         bool use_jit = allow_jit && mode == FR_MODE_AUTO;
-        p.sp = plan_stages(p.fg, mode == FR_MODE_AUTO, mode != FR_MODE_PULL, 20, use_jit, allow_template);
+        if (!matcher || matcher_gen != lowering.generation()) {
+            matcher.reset(new BankMatcher(fg, 20, use_jit, allow_template));
+            matcher_gen = lowering.generation();
+        }
+        p.sp = plan_stages(fg, mode == FR_MODE_AUTO, mode != FR_MODE_PULL, 20, use_jit, allow_template, matcher.get());
         std::vector<std::shared_ptr<JitKernel>> jits(p.sp.banks.size());
         if (use_jit) {
             try {
@@ -292,7 +304,7 @@ struct fr_renderer {
                     if (p.sp.banks[i].jit) jits[i] = jit_cache.get(p.sp.banks[i].shape, p.sp.banks[i].varying, p.sp.banks[i].literal_bits, p.sp.banks[i].alias);
             } catch (const Error &e) {   // hipRTC unavailable or the generated source did not compile: plan without it
                 jit_error = e.what();
-                p.sp = plan_stages(p.fg, true, true, 20, false);
+                p.sp = plan_stages(fg, true, true, 20, false);
                 jits.assign(p.sp.banks.size(), nullptr);
             }
         }
@@ -339,10 +351,10 @@ struct fr_renderer {
         p.pull_rows = p.sp.pull_rows;
         if (!p.pull_rows.empty()) {
             // dense input table: OP_INPUT.a becomes an index into input_slots
-            std::vector<DevNode> dn(p.fg.nodes.size());
+            std::vector<DevNode> dn(fg.nodes.size());
             std::unordered_map<uint32_t, uint32_t> dense;
             for (size_t i = 0; i < dn.size(); ++i) {
-                const FlatNode &n = p.fg.nodes[i];
+                const FlatNode &n = fg.nodes[i];
                 dn[i] = DevNode{n.op, n.a, n.b, n.depth};
                 if (n.op == OP_INPUT) {
                     auto it = dense.emplace(n.a, (uint32_t)p.input_slots.size());
@@ -351,7 +363,7 @@ struct fr_renderer {
                 }
             }
             std::vector<uint32_t> roots(n_slots);
-            for (uint32_t r = 0; r < n_slots; ++r) roots[r] = p.fg.outputs[r];
+            for (uint32_t r = 0; r < n_slots; ++r) roots[r] = fg.outputs[r];
             p.d_nodes.ensure(dn.size() * sizeof(DevNode));
             p.d_roots.ensure(roots.size() * sizeof(uint32_t));
             HIP_CHECK(hipMemcpyAsync(p.d_nodes.p, dn.data(), dn.size() * sizeof(DevNode), hipMemcpyHostToDevice, st));
@@ -361,7 +373,9 @@ struct fr_renderer {
         // description
         std::ostringstream js;
         js << "{\"backend\":\"hip-gfx950\",\"mode\":" << mode << ",\"n_slots\":" << n_slots
-           << ",\"lowered_nodes\":" << p.fg.nodes.size() << ",\"max_depth\":" << p.fg.max_depth << ",\"banks\":[";
+           << ",\"lowered_nodes\":" << fg.nodes.size() << ",\"max_depth\":" << fg.max_depth
+           << ",\"lowering\":\"" << (lowering.last_was_full() ? "full" : "incremental") << "\",\"relowered_nodes\":" << lowering.last_relowered()
+           << ",\"lower_ms\":" << lower_ms << ",\"plans_built\":" << plans_built + 1 << ",\"banks\":[";
         for (size_t i = 0; i < p.banks.size(); ++i) {
             const BankLaunch &g = p.banks[i].grp;
             js << (i ? "," : "") << "{\"voices\":" << g.rows.size() << ",\"partials\":" << (g.general ? g.max_leaves : (1u << g.log2_p))
@@ -377,7 +391,9 @@ struct fr_renderer {
            << ",\"stage_jit\":" << (p.stage_jit ? "true" : "false") << ",\"stage_shapes\":" << p.stage_shapes
            << ",\"rings\":" << p.sp.n_rings << ",\"max_lookback\":" << p.sp.lmax
            << ",\"jit_kernels_compiled\":" << jit_cache.compiled() << ",\"jit_compile_ms\":" << jit_cache.compile_ms()
-           << ",\"pull_rows\":" << p.pull_rows.size() << "}";
+           << ",\"pull_rows\":" << p.pull_rows.size()
+           << ",\"build_ms\":" << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count() << "}";
+        ++plans_built;
         p.json = js.str();
         p.valid = true;
         plan = std::move(p);
@@ -568,7 +584,7 @@ struct fr_renderer {
             HIP_CHECK(hipMemcpyAsync(d_in_table.p, tab.data(), tab.size() * sizeof(DevInput), hipMemcpyHostToDevice, st));
             HIP_CHECK(hipStreamSynchronize(st));
         }
-        const uint64_t depth = std::max<uint32_t>(plan.fg.max_depth, 1);
+        const uint64_t depth = std::max<uint32_t>(plan.max_depth, 1);
         // pull rows are processed as contiguous runs of rows; stack workspace bounded to ~1 GiB
         const uint64_t budget = 1ull << 30;
         uint64_t chunk = std::max<uint64_t>(budget / (depth * 16), 256);

@@ -117,11 +117,20 @@ void Mirror::add_node(uint32_t handle, const fr_effect *e) {  // reference.rs:11
     MNode n;
     n.kind = e->kind;
     if (e->kind == FR_EFFECT_GRAPH) n.sub = intern(e, 0);
+    // readers of an F32Constant node are not tracked one by one (its value rides on the edges): replacing it is a
+    // from-scratch lowering
+    if (const MNode *old = nodes.find(handle))
+        if (old->kind == FR_PRIM_F32CONSTANT) journal_overflow = true;
     nodes.set(handle, std::move(n));
+    note(nodes.find(handle)->pos | JOURNAL_NODE);
     ++version;
 }
 
 void Mirror::del_node(uint32_t handle) {  // reference.rs:121-123
+    if (const MNode *old = nodes.find(handle)) {
+        if (old->kind == FR_PRIM_F32CONSTANT) journal_overflow = true;
+        note(old->pos | JOURNAL_NODE);
+    }
     nodes.erase(handle);
     ++version;
 }
@@ -134,6 +143,7 @@ void Mirror::add_edge(const fr_edge &e) {  // reference.rs:124-126,141-153
         MNode *n = nodes.find(e.to);
         if (!n) throw Error(FR_ERR_NO_SUCH_NODE, "add_edge: destination node " + std::to_string(e.to) + " unknown");
         set_slot(n->inbound, e.to_slot, r);
+        note(n->pos);
     }
     ++version;
 }
@@ -146,6 +156,7 @@ void Mirror::del_edge(const fr_edge &e) {  // reference.rs:127-136
         MNode *n = nodes.find(e.to);
         if (!n) throw Error(FR_ERR_NO_SUCH_NODE, "Attempt to delete edge, but it was never created!");
         inbound = &n->inbound;
+        note(n->pos);
     }
     if (e.to_slot < inbound->size()) (*inbound)[e.to_slot] = EdgeRef{};
     ++version;
@@ -239,32 +250,96 @@ struct Frame {
 };
 
 
-struct Lowerer {
-    const Mirror &m;
+struct UserCell {
+    uint64_t user;
+    uint32_t next;   // cell index + 1, 0 = end
+};
+
+}  // namespace
+
+struct Lowering::Impl {
+    const Mirror *m = nullptr;
     FlatGraph fg;
     std::vector<Ctx> ctxs;
     // keyed by (context << 32 | dense position of the node inside its graph): exact, no pointer hashing
-    FlatMap64 child_ctx;   // -> context id + 1
-    FlatMap64 memo;        // -> lowered id + 2; 1 = evaluation in progress
+    FlatMap64 child_ctx;   // -> context id + 1 (0: forget, the instance was replaced)
+    FlatMap64 memo;        // -> lowered id + 2; 1 = evaluation in progress; 0 = invalidated
+    // readers: key -> list of keys whose lowering looked at `key` (as an operand, or -- for a top-level composite
+    // instance -- by following one of its inbound edges or outputs)
+    FlatMap64 readers_head;   // -> cell index + 1
+    std::vector<UserCell> cells;
+    std::vector<uint32_t> free_cells;
+    bool valid = false;
+    uint64_t generation = 0, relowered = 0;
+    bool was_full = true;
+    size_t base_nodes = 0, base_ctxs = 0, base_cells = 0;
 
-    explicit Lowerer(const Mirror &mm) : m(mm) { ctxs.push_back(Ctx{-1, nullptr, nullptr}); }
+    static constexpr uint64_t NOBODY = ~0ull;
+
+    void reset(const Mirror &mm) {
+        m = &mm;
+        fg = FlatGraph();
+        ctxs.clear();
+        ctxs.push_back(Ctx{-1, nullptr, nullptr});
+        child_ctx.clear();
+        memo.clear();
+        readers_head.clear();
+        cells.clear();
+        free_cells.clear();
+        fg.konst(0);   // node 0 is always +0.0
+        ++generation;
+    }
+
+    void add_reader(uint64_t of, uint64_t reader) {
+        if (reader == NOBODY) return;
+        uint64_t &head = readers_head.get(of);
+        if (head && cells[head - 1].user == reader) return;   // both operands the same node
+        uint32_t c;
+        if (!free_cells.empty()) { c = free_cells.back(); free_cells.pop_back(); }
+        else { c = (uint32_t)cells.size(); cells.push_back(UserCell{}); }
+        cells[c] = UserCell{reader, (uint32_t)head};
+        head = (uint64_t)c + 1;
+    }
+
+    // `k` changed: forget its lowering and that of everything that read it, transitively.  A reader whose entry is
+    // already invalid was handled when it became invalid (nothing can have read it since), so the walk stops there.
+    void invalidate(uint64_t k0) {
+        std::vector<uint64_t> work{k0};
+        while (!work.empty()) {
+            uint64_t k = work.back();
+            work.pop_back();
+            if (uint64_t *mv = memo.find(k)) *mv = 0;
+            uint64_t *head = readers_head.find(k);
+            if (!head) continue;
+            uint32_t c = (uint32_t)*head;
+            *head = 0;   // the readers re-register when they are lowered again
+            while (c) {
+                UserCell cell = cells[c - 1];
+                free_cells.push_back(c - 1);
+                const uint64_t *rv = memo.find(cell.user);
+                if (rv && *rv >= 2) work.push_back(cell.user);
+                c = cell.next;
+            }
+        }
+    }
 
     const MNode *find(int ctx, uint32_t handle) const {
         const SubGraph *g = ctxs[ctx].g;
-        if (!g) return m.nodes.find(handle);
+        if (!g) return m->nodes.find(handle);
         auto it = g->index.find(handle);
         return it == g->index.end() ? nullptr : &g->nodes[it->second];
     }
     uint64_t key(int ctx, const MNode *n) const {
         const SubGraph *g = ctxs[ctx].g;
-        uint32_t pos = g ? (uint32_t)(n - g->nodes.data()) : m.nodes.position(n);
+        uint32_t pos = g ? (uint32_t)(n - g->nodes.data()) : m->nodes.position(n);
         return ((uint64_t)(uint32_t)ctx << 32) | pos;
     }
 
     // Follows an edge through graph inputs and composite outputs until it lands on a value that is
     // already known (returns true, id in `out`) or on a primitive node still to be evaluated
-    // (returns false, `need` filled).  Mirrors the dispatch at reference.rs:178-195.
-    bool resolve(int ctx, EdgeRef ref, uint32_t &out, Frame &need) {
+    // (returns false, `need` filled).  Mirrors the dispatch at reference.rs:178-195.  `reader` is the node on
+    // whose behalf the edge is followed: it is registered with every mutable thing the walk depends on.
+    bool resolve(int ctx, EdgeRef ref, uint32_t &out, Frame &need, uint64_t reader) {
         for (uint64_t hops = 0;; ++hops) {
             if (hops > (1u << 20)) throw Error(FR_ERR_CYCLE, "edge chain through composite I/O never reaches a node");
             if (!ref.present) {  // get_maybe_edge_value: missing edge is 0f32 (reference.rs:164-173)
@@ -278,6 +353,7 @@ struct Lowerer {
                     return true;
                 }
                 // closure of reference.rs:189-193: the instance's inbound[slot] in the parent graph
+                if (c.parent == 0) add_reader(key(0, c.inst), reader);   // a top-level instance: its inbound edges can change
                 uint32_t slot = ref.from_slot;
                 ref = slot < c.inst->inbound.size() ? c.inst->inbound[slot] : EdgeRef{};
                 ctx = c.parent;
@@ -287,6 +363,7 @@ struct Lowerer {
             if (!n) throw Error(FR_ERR_NO_SUCH_NODE, "edge reads from unknown node " + std::to_string(ref.from));
             ++fg.n_mirror_nodes_visited;
             if (n->kind == FR_EFFECT_GRAPH) {  // reference.rs:188-194
+                if (ctx == 0) add_reader(key(0, n), reader);             // the instance can be replaced or deleted
                 uint64_t &cc_slot = child_ctx.get(key(ctx, n));
                 if (!cc_slot) {
                     ctxs.push_back(Ctx{ctx, n, n->sub.get()});
@@ -305,12 +382,16 @@ struct Lowerer {
             if (ref.from_slot != 0)  // assert!(from_slot == 0), reference.rs:199,223,...
                 throw Error(FR_ERR_BAD_SLOT, "primitive node " + std::to_string(ref.from) + " read through output slot " +
                                                  std::to_string(ref.from_slot));
-            if (const uint64_t *mv = memo.find(key(ctx, n))) {
+            const uint64_t k = key(ctx, n);
+            add_reader(k, reader);
+            if (const uint64_t *mv = memo.find(k)) {
                 if (*mv == 1)
                     throw Error(FR_ERR_CYCLE, "dependency cycle through node " + std::to_string(ref.from) +
                                                   " (feedback is not evaluable by this engine)");
-                out = (uint32_t)(*mv - 2);
-                return true;
+                if (*mv >= 2) {
+                    out = (uint32_t)(*mv - 2);
+                    return true;
+                }
             }
             need = Frame{ctx, n, 0, {0, 0}};
             return false;
@@ -331,50 +412,90 @@ struct Lowerer {
     uint32_t eval(int ctx0, EdgeRef root) {
         uint32_t result = 0;
         Frame need;
-        if (resolve(ctx0, root, result, need)) return result;
+        if (resolve(ctx0, root, result, need, NOBODY)) return result;
         std::vector<Frame> stack;
         stack.push_back(need);
         memo.get(key(need.ctx, need.node)) = 1;
-        while (!stack.empty()) {
-            Frame &f = stack.back();
-            if (f.next < 2) {
-                const MNode *n = f.node;
-                EdgeRef ref = (size_t)f.next < n->inbound.size() ? n->inbound[f.next] : EdgeRef{};
-                uint32_t id;
-                Frame child;
-                if (resolve(f.ctx, ref, id, child)) {
-                    f.vals[f.next++] = id;
-                } else {
-                    memo.get(key(child.ctx, child.node)) = 1;
-                    stack.push_back(child);  // invalidates f; loop re-reads the top
+        try {
+            while (!stack.empty()) {
+                Frame &f = stack.back();
+                if (f.next < 2) {
+                    const MNode *n = f.node;
+                    EdgeRef ref = (size_t)f.next < n->inbound.size() ? n->inbound[f.next] : EdgeRef{};
+                    uint32_t id;
+                    Frame child;
+                    if (resolve(f.ctx, ref, id, child, key(f.ctx, n))) {
+                        f.vals[f.next++] = id;
+                    } else {
+                        memo.get(key(child.ctx, child.node)) = 1;
+                        stack.push_back(child);  // invalidates f; loop re-reads the top
+                    }
+                    continue;
                 }
-                continue;
+                uint32_t id = fg.make(op_of(f.node->kind), f.vals[0], f.vals[1]);
+                memo.get(key(f.ctx, f.node)) = (uint64_t)id + 2;
+                ++relowered;
+                stack.pop_back();
+                if (stack.empty()) {
+                    result = id;
+                } else {
+                    Frame &p = stack.back();
+                    p.vals[p.next++] = id;
+                }
             }
-            uint32_t id = fg.make(op_of(f.node->kind), f.vals[0], f.vals[1]);
-            memo.get(key(f.ctx, f.node)) = (uint64_t)id + 2;
-            stack.pop_back();
-            if (stack.empty()) {
-                result = id;
-            } else {
-                Frame &p = stack.back();
-                p.vals[p.next++] = id;
-            }
+        } catch (...) {   // nothing half-evaluated may stay marked: the next update() must fail the same way
+            for (const Frame &f : stack) memo.get(key(f.ctx, f.node)) = 0;
+            throw;
         }
         return result;
     }
+
+    // journal == nullptr: from scratch
+    const FlatGraph &update(const Mirror &mm, uint32_t n_slots, const std::vector<uint32_t> *journal) {
+        const bool garbage = fg.nodes.size() > 2 * base_nodes + (1u << 16) || ctxs.size() > 2 * base_ctxs + (1u << 16) ||
+                             cells.size() > 2 * base_cells + (1u << 20);
+        const bool full = !valid || m != &mm || !journal || garbage;
+        relowered = 0;
+        was_full = full;
+        if (full) {
+            reset(mm);
+        } else {
+            for (uint32_t entry : *journal) {
+                const uint64_t k = entry & ~Mirror::JOURNAL_NODE;   // context 0
+                if (entry & Mirror::JOURNAL_NODE)
+                    if (uint64_t *cc = child_ctx.find(k)) *cc = 0;
+                invalidate(k);
+            }
+        }
+        valid = true;   // from here on the state matches the mirror even if an output fails to lower
+        fg.outputs.assign(n_slots, 0);
+        for (uint32_t s = 0; s < n_slots; ++s) {
+            EdgeRef ref = s < mm.outputs.size() ? mm.outputs[s] : EdgeRef{};  // reference.rs:158-161
+            fg.outputs[s] = eval(0, ref);
+        }
+        if (full) { base_nodes = fg.nodes.size(); base_ctxs = ctxs.size(); base_cells = cells.size(); }
+        return fg;
+    }
 };
 
-}  // namespace
+Lowering::Lowering() : impl_(new Impl) {}
+Lowering::~Lowering() = default;
+const FlatGraph &Lowering::update(Mirror &m, uint32_t n_slots) {
+    std::vector<uint32_t> journal;
+    journal.swap(m.journal);
+    const bool usable = m.journal_on && !m.journal_overflow;
+    m.journal_on = true;        // the invalidations below are applied before anything can throw
+    m.journal_overflow = false;
+    return impl_->update(m, n_slots, usable ? &journal : nullptr);
+}
+uint64_t Lowering::generation() const { return impl_->generation; }
+bool Lowering::last_was_full() const { return impl_->was_full; }
+uint64_t Lowering::last_relowered() const { return impl_->relowered; }
 
 FlatGraph lower(const Mirror &m, uint32_t n_slots) {
-    Lowerer L(m);
-    L.fg.konst(0);  // node 0 is always +0.0
-    L.fg.outputs.resize(n_slots);
-    for (uint32_t s = 0; s < n_slots; ++s) {
-        EdgeRef ref = s < m.outputs.size() ? m.outputs[s] : EdgeRef{};  // reference.rs:158-161
-        L.fg.outputs[s] = L.eval(0, ref);
-    }
-    return std::move(L.fg);
+    Lowering::Impl one_shot;
+    one_shot.update(m, n_slots, nullptr);
+    return std::move(one_shot.fg);
 }
 
 }  // namespace fr

@@ -156,7 +156,20 @@ public:
     std::vector<EdgeRef> outputs;
     uint64_t version = 0;                        // bumped by every edit
 
+    // Edit journal for incremental lowering (class Lowering).  While `journal_on`, every edit appends the dense
+    // position of the top-level node it touched (| JOURNAL_NODE when the node itself was added, replaced or deleted).
+    // `journal_overflow` means the journal does not describe every edit since it was cleared: lower from scratch.
+    static constexpr uint32_t JOURNAL_NODE = 0x80000000u;
+    static constexpr size_t JOURNAL_LIMIT = 1u << 16;
+    bool journal_on = false;
+    bool journal_overflow = true;
+    std::vector<uint32_t> journal;
+
 private:
+    void note(uint32_t entry) {
+        if (!journal_on || journal.size() >= JOURNAL_LIMIT) journal_overflow = true;
+        else journal.push_back(entry);
+    }
     std::shared_ptr<const SubGraph> intern(const fr_effect *e, int depth);
     std::unordered_multimap<uint64_t, std::weak_ptr<const SubGraph>> interned_;
 };
@@ -195,6 +208,36 @@ struct FlatGraph {
 private:
     FlatMap64 cse_[8];   // (a << 32 | b) -> node id + 1
     uint32_t push(FlatOp op, uint32_t a, uint32_t b, uint32_t depth);
+};
+
+// The lowered graph kept up to date across edits.  The first update() lowers everything reachable from the outputs;
+// later ones re-lower only what the journalled edits can have changed: each lowered node remembers which nodes read
+// it (and which composite instances' inbound edges were followed to reach it), an edit invalidates the touched node
+// and, transitively, its readers, and evaluation of the outputs recomputes exactly those.  The FlatGraph is
+// append-only and hash-consed, so an unchanged sub-expression keeps its id across updates (plans cache per id);
+// superseded nodes stay behind as garbage until it outweighs the live graph, then everything is rebuilt.
+class Mirror;
+struct FlatGraph;
+FlatGraph lower(const Mirror &m, uint32_t n_slots);
+
+class Lowering {
+public:
+    Lowering();
+    ~Lowering();
+    Lowering(const Lowering &) = delete;
+    Lowering &operator=(const Lowering &) = delete;
+    // Brings the lowered form of the first n_slots outputs up to date and consumes the mirror's journal.
+    // Throws fr::Error like lower(); the state stays consistent and the next update() throws again until the
+    // graph is fixed.  The returned reference is stable for the life of this object.
+    const FlatGraph &update(Mirror &m, uint32_t n_slots);
+    uint64_t generation() const;        // bumped by every from-scratch rebuild: ids of different generations are unrelated
+    bool last_was_full() const;
+    uint64_t last_relowered() const;    // nodes lowered by the last update()
+
+private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+    friend FlatGraph lower(const Mirror &m, uint32_t n_slots);
 };
 
 // Lowers the first n_slots output slots of the mirror.  Throws fr::Error (NO_SUCH_NODE, BAD_SLOT,

@@ -339,7 +339,26 @@ BankMatcher::BankMatcher(const FlatGraph &g, uint32_t max_log2_p, bool allow_jit
     : impl_(new Impl(g)), g_(g), max_log2_p_(max_log2_p), allow_jit_(allow_jit), allow_template_(allow_template) {}
 BankMatcher::~BankMatcher() { delete impl_; }
 
+void BankMatcher::begin_plan() { used_.clear(); }
+
+void BankMatcher::retain_used() {
+    size_t live = 0;
+    for (auto &kv : memo_) live += used_.count(kv.first) ? 1 : 0;
+    if (memo_.size() <= 2 * live + 64) return;
+    std::unordered_map<uint32_t, int64_t> memo;
+    std::vector<VoiceMatch> found;
+    for (auto &kv : memo_) {
+        if (!used_.count(kv.first)) continue;
+        if (kv.second < 0) { memo.emplace(kv.first, -1); continue; }
+        memo.emplace(kv.first, (int64_t)found.size());
+        found.push_back(std::move(found_[(size_t)kv.second]));
+    }
+    memo_.swap(memo);
+    found_.swap(found);
+}
+
 bool BankMatcher::try_voice(uint32_t root, VoiceMatch &out) {
+    used_[root] = true;
     auto it = memo_.find(root);
     if (it != memo_.end()) {
         if (it->second < 0) return false;

@@ -42,6 +42,12 @@ public:
     BankMatcher &operator=(const BankMatcher &) = delete;
     // Is the expression rooted at `root` a voice?  Results (including failures) are memoised per node.
     bool try_voice(uint32_t root, VoiceMatch &out);
+    // A matcher kept across plans of the same (append-only, hash-consed) FlatGraph answers repeated roots from its
+    // memo.  begin_plan() .. retain_used() bracket one plan: entries no plan has asked for since are dropped once
+    // they outnumber the live ones.
+    void begin_plan();
+    void retain_used();
+    size_t cached_voices() const { return found_.size(); }
 
 private:
     struct Impl;
@@ -50,8 +56,9 @@ private:
     uint32_t max_log2_p_;
     bool allow_jit_;
     bool allow_template_;   // false (FR_BANK_TEMPLATE=0, A/B runs only): skip the hand-matched partial template
-    std::unordered_map<uint32_t, int64_t> memo_;
+    std::unordered_map<uint32_t, int64_t> memo_;   // root -> index into found_, or -1
     std::vector<VoiceMatch> found_;
+    std::unordered_map<uint32_t, bool> used_;      // roots asked for since begin_plan()
 };
 
 }  // namespace fr

@@ -238,12 +238,19 @@ bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unorde
 
 }  // namespace
 
-StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p, bool allow_jit, bool allow_template) {
+StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p, bool allow_jit, bool allow_template,
+                       BankMatcher *reuse) {
     StagedPlan sp;
     const uint32_t n_rows = (uint32_t)g.outputs.size();
-    std::unique_ptr<BankMatcher> matcher;
-    if (allow_banks) matcher.reset(new BankMatcher(g, max_log2_p, allow_jit, allow_template));
-    Planner P(g, matcher.get());
+    std::unique_ptr<BankMatcher> own;
+    BankMatcher *matcher = nullptr;
+    if (allow_banks) {
+        if (reuse) matcher = reuse;
+        else { own.reset(new BankMatcher(g, max_log2_p, allow_jit, allow_template)); matcher = own.get(); }
+        matcher->begin_plan();
+    }
+    struct Retain { BankMatcher *m; ~Retain() { if (m) m->retain_used(); } } retain{reuse ? matcher : nullptr};
+    Planner P(g, matcher);
 
     std::vector<uint32_t> staged_rows;
     for (uint32_t row = 0; row < n_rows; ++row) {

@@ -49,7 +49,10 @@ struct StagedPlan {
 };
 
 // allow_banks: recognise fused oscillator banks; allow_programs: stage everything else that qualifies.
+// `reuse`: a matcher built over this same FlatGraph object with the same limits, kept by the caller across plans
+// (incremental re-planning after a graph edit: unchanged voices are answered from its memo).
+class BankMatcher;
 StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p, bool allow_jit = false,
-                       bool allow_template = true);
+                       bool allow_template = true, BankMatcher *reuse = nullptr);
 
 }  // namespace fr

@@ -656,13 +656,161 @@ static void stage_programs_compile_to_source() {
     }
 }
 
+// ---- incremental lowering (graph.hpp Lowering) ----------------------------------------------------------------------
+// A Lowering kept across random edit sequences must describe the same function as lowering the mirror from scratch
+// after every batch of edits: same error (if the graph is broken at that point), else bit-identical output values.
+static void incremental_lowering_equals_from_scratch() {
+    const int kinds[6] = {FR_PRIM_DELAY, FR_PRIM_SUM2, FR_PRIM_MULTIPLY, FR_PRIM_DIVIDE, FR_PRIM_MODULO, FR_PRIM_MINIMUM};
+    const float consts[8] = {0.0f, 1.0f, -1.0f, 0.5f, 2.0f, 3.0f, -3.5f, 7.25f};
+    // composite: out0 = in0 * C(5) + in1, out1 = in1 (a pure pass-through: readers reach the instance's inbound edge directly)
+    fr_effect mul{}, add{}, cst{};
+    mul.kind = FR_PRIM_MULTIPLY; add.kind = FR_PRIM_SUM2; cst.kind = FR_PRIM_F32CONSTANT;
+    uint32_t ch[3] = {1, 2, 3};
+    const fr_effect *ce[3] = {&mul, &cst, &add};
+    fr_edge cedges[6] = {{0, 1, 0, 0}, {2, 1, f32_to_bits(5.0f), 1}, {1, 3, 0, 0}, {0, 3, 1, 1}, {3, 0, 0, 0}, {0, 0, 1, 1}};
+    fr_effect comp{};
+    comp.kind = FR_EFFECT_GRAPH;
+    comp.n_nodes = 3; comp.node_handles = ch; comp.node_effects = ce; comp.n_edges = 6; comp.edges = cedges;
+    // a second definition for "replace the instance by another effect under the same handle": out0 = in0 + in1
+    fr_edge c2edges[3] = {{0, 3, 0, 0}, {0, 3, 1, 1}, {3, 0, 0, 0}};
+    uint32_t c2h[1] = {3};
+    const fr_effect *c2e[1] = {&add};
+    fr_effect comp2{};
+    comp2.kind = FR_EFFECT_GRAPH;
+    comp2.n_nodes = 1; comp2.node_handles = c2h; comp2.node_effects = c2e; comp2.n_edges = 3; comp2.edges = c2edges;
+
+    const uint32_t CONST = 100000, N_OUT = 3;
+    uint64_t n_incremental = 0, n_full = 0, n_errors = 0;
+    for (unsigned seed = 0; seed < 30; ++seed) {
+        std::mt19937 rng(900 + seed);
+        Mirror m;
+        Lowering low;
+        fr_effect prim{};
+        prim.kind = FR_PRIM_F32CONSTANT;
+        m.add_node(CONST, &prim);
+        std::vector<uint32_t> live;          // handles in creation order; edges only go from earlier to later handles
+        std::map<uint32_t, bool> is_comp;
+        uint32_t next = 1;
+        auto source = [&](uint32_t before_handle, uint32_t &from, uint32_t &from_slot) {
+            unsigned r = rng() % 10;
+            std::vector<uint32_t> cand;
+            for (uint32_t h : live) if (h < before_handle) cand.push_back(h);
+            if (r < 2 || cand.empty()) {
+                if (rng() % 2) { from = 0; from_slot = rng() % 2; }
+                else { from = CONST; from_slot = f32_to_bits(consts[rng() % 8]); }
+                return;
+            }
+            from = cand[rng() % cand.size()];
+            from_slot = is_comp[from] ? rng() % 2 : 0;
+        };
+        auto connect = [&](uint32_t h, uint32_t slot) {
+            uint32_t from, fs;
+            source(h, from, fs);
+            if (!is_comp[h] && slot == 1 && rng() % 3 == 0) { from = CONST; fs = f32_to_bits((float)(rng() % 7)); }   // constant delay amounts etc.
+            m.add_edge(fr_edge{from, h, fs, slot});
+        };
+        auto edit = [&]() {
+            unsigned r = rng() % 12;
+            if (live.size() < 4) r = 0;
+            if (r < 3) {                                   // new primitive node
+                uint32_t h = next++;
+                prim.kind = kinds[rng() % 6];
+                m.add_node(h, &prim);
+                is_comp[h] = false;
+                connect(h, 0); connect(h, 1);
+                live.push_back(h);
+            } else if (r < 4) {                            // new composite instance
+                uint32_t h = next++;
+                m.add_node(h, &comp);
+                is_comp[h] = true;
+                connect(h, 0); connect(h, 1);
+                live.push_back(h);
+            } else if (r < 7) {                            // rewire one inbound edge
+                uint32_t h = live[rng() % live.size()];
+                connect(h, rng() % 2);
+            } else if (r < 8) {                            // drop one inbound edge
+                uint32_t h = live[rng() % live.size()];
+                m.del_edge(fr_edge{0, h, 0, (uint32_t)(rng() % 2)});
+            } else if (r < 9 && rng() % 3 == 0) {          // delete a node (its readers now dangle), sometimes bring the handle back
+                size_t i = rng() % live.size();
+                uint32_t h = live[i];
+                m.del_node(h);
+                if (rng() % 2) {
+                    bool c = rng() % 3 == 0;
+                    prim.kind = kinds[rng() % 6];
+                    m.add_node(h, c ? (rng() % 2 ? &comp : &comp2) : &prim);
+                    is_comp[h] = c;
+                    connect(h, 0); connect(h, 1);
+                } else {
+                    live.erase(live.begin() + i);
+                }
+            } else if (r < 10) {                           // replace a node in place (HashMap::insert semantics), inbound edges start empty
+                uint32_t h = live[rng() % live.size()];
+                for (int tries = 0; tries < 4 && !is_comp[h]; ++tries) h = live[rng() % live.size()];   // prefer instances:
+                bool c = is_comp[h] ? rng() % 4 != 0 : rng() % 3 == 0;                                  // swap their definition
+                prim.kind = kinds[rng() % 6];
+                m.add_node(h, c ? (rng() % 2 ? &comp : &comp2) : &prim);
+                is_comp[h] = c;
+                connect(h, 0);
+                if (rng() % 2) connect(h, 1);
+            } else {                                       // output edge
+                uint32_t from, fs;
+                source(~0u, from, fs);
+                m.add_edge(fr_edge{from, 0, fs, (uint32_t)(rng() % N_OUT)});
+            }
+        };
+        Inputs in(2);
+        std::normal_distribution<float> nd(0.0f, 3.0f);
+        for (int t = 0; t < 48; ++t) { in[0].push_back((float)t); in[1].push_back(nd(rng)); }
+        for (int step = 0; step < 60; ++step) {
+            int n_edits = 1 + (int)(rng() % 3);
+            if (step == 0) n_edits = 12;
+            for (int e = 0; e < n_edits; ++e) edit();
+            bool expect_full = step == 0;
+            if (seed % 4 == 3 && step == 30) {             // the constant node itself is replaced: not journalled per reader
+                expect_full = true;
+                m.del_node(CONST);
+                prim.kind = FR_PRIM_F32CONSTANT;
+                m.add_node(CONST, &prim);
+            }
+            if (seed % 4 == 0 && step == 30) {             // more edits than the journal holds
+                expect_full = true;
+                for (unsigned i = 0; i < Mirror::JOURNAL_LIMIT + 10; ++i) connect(live[i % live.size()], i % 2);
+            }
+            int code_inc = 0, code_fresh = 0;
+            const FlatGraph *inc = nullptr;
+            FlatGraph fresh;
+            try { inc = &low.update(m, N_OUT); } catch (const Error &e) { code_inc = e.code; }
+            try { fresh = lower(m, N_OUT); } catch (const Error &e) { code_fresh = e.code; }
+            if (code_inc != code_fresh) {
+                std::fprintf(stderr, "seed %u step %d: incremental lowering status %d, from scratch %d\n", seed, step, code_inc, code_fresh);
+                throw std::runtime_error("status mismatch");
+            }
+            if (code_inc) { ++n_errors; continue; }
+            (low.last_was_full() ? n_full : n_incremental) += 1;
+            CHECK(low.last_was_full() == expect_full);
+            for (uint32_t s = 0; s < N_OUT; ++s)
+                for (uint64_t t : {0ull, 1ull, 5ull, 17ull, 40ull}) {
+                    float a = flat_eval(*inc, inc->outputs[s], t, in), b = flat_eval(fresh, fresh.outputs[s], t, in);
+                    if (!same_bits(a, b)) {
+                        std::fprintf(stderr, "seed %u step %d slot %u t %llu: incremental %a, from scratch %a\n", seed, step, s, (unsigned long long)t, a, b);
+                        throw std::runtime_error("mismatch");
+                    }
+                }
+        }
+    }
+    if (std::getenv("FR_TEST_VERBOSE")) std::fprintf(stderr, "incremental %llu, full %llu, failing graphs %llu\n", (unsigned long long)n_incremental, (unsigned long long)n_full, (unsigned long long)n_errors);
+    CHECK(n_incremental > 20 * n_full && n_full > 30 && n_errors > 0 && n_errors < n_incremental);
+}
+
 int main(int argc, char **argv) {
     std::vector<std::pair<const char *, std::function<void()>>> tests = {
         {"lowering_folds_constants", lowering_folds_constants}, {"lowering_errors", lowering_errors},
         {"random_graphs_lower_correctly", random_graphs_lower_correctly}, {"banks_are_recognised", banks_are_recognised},
         {"effects_chain_is_staged", effects_chain_is_staged}, {"dynamic_delay_goes_to_pull", dynamic_delay_goes_to_pull},
         {"composite_instances_are_interned", composite_instances_are_interned},
-        {"stage_programs_compile_to_source", stage_programs_compile_to_source}};
+        {"stage_programs_compile_to_source", stage_programs_compile_to_source},
+        {"incremental_lowering_equals_from_scratch", incremental_lowering_equals_from_scratch}};
     int failed = 0, ran = 0;
     for (auto &t : tests) {
         if (argc > 1 && std::string(argv[1]) != t.first) continue;

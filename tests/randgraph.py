@@ -1,7 +1,7 @@
 """Seeded random graphs of the seven primitives (+ nested composites) for parity tests."""
 import numpy as np
 
-from libfriendship_amd.capi import Effect, f32_bits
+from libfriendship_amd.capi import PRIMITIVES, Effect, f32_bits
 
 OPS = ["Delay", "Sum2", "Multiply", "Divide", "Modulo", "Minimum"]
 SPECIAL = [0.0, -0.0, 1.0, -1.0, 0.5, 2.0, 3.0, 1e-30, -3.5, 7.25, 1e20, float("inf"), float("nan"), 1.8446744e19, 4.0e19]
@@ -98,8 +98,72 @@ def install_steps(r, steps):
     for s in steps:
         if s[0] == "node":
             r.on_add_node(s[1], s[2])
+        elif s[0] == "deledge":
+            r.on_del_edge(*s[1:])
         else:
             r.on_add_edge(*s[1:])
+
+
+def random_edits(rng, steps, n_edits, n_inputs=2, n_outputs=3, signal_delays=False):
+    """`n_edits` further steps that edit the graph `steps` built (and earlier edits extended): rewire an inbound edge,
+    delete one, add a primitive node reading existing ones, or repoint an output.  Edges only run from lower to higher
+    handles, so the graph stays acyclic.  Returns the new steps (also appended to `steps`)."""
+    prim = {}          # handle -> kind of primitive nodes (composites are left alone as sources)
+    inbound = {}       # (to, to_slot) -> edge step
+    for s in steps:
+        if s[0] == "node":
+            prim[s[1]] = PRIMITIVES[s[2].kind] if s[2].kind < len(PRIMITIVES) else None
+        elif s[0] == "edge":
+            inbound[(s[2], s[4])] = s
+        elif s[0] == "deledge":
+            inbound.pop((s[2], s[4]), None)
+    handles = sorted(h for h in prim if h != 1)
+    is_prim = {h for h in handles if prim[h] in OPS}
+    out = []
+
+    def source(before):
+        cand = [h for h in is_prim if h < before]
+        r = rng.random()
+        if r < 0.3 or not cand:
+            if rng.random() < 0.5:
+                return 0, int(rng.integers(n_inputs))
+            return 1, f32_bits(_const(rng))
+        return cand[rng.integers(len(cand))], 0
+
+    def connect(h, slot):
+        if prim.get(h) == "Delay" and slot == 1 and not (signal_delays and rng.random() < 0.4):
+            f, fs = 1, f32_bits(float(rng.integers(0, 9)))
+        else:
+            f, fs = source(h)
+        st = ("edge", f, h, fs, slot)
+        inbound[(h, slot)] = st
+        out.append(st)
+
+    for _ in range(n_edits):
+        r = rng.random()
+        if r < 0.45 and handles:
+            connect(handles[rng.integers(len(handles))], int(rng.integers(2)))
+        elif r < 0.55 and inbound:
+            keys = [k for k in inbound if k[0] != 0]
+            if keys:
+                e = inbound.pop(keys[rng.integers(len(keys))])
+                out.append(("deledge",) + e[1:])
+        elif r < 0.8:
+            h = (max(handles) if handles else 1) + 1
+            kind = OPS[rng.integers(len(OPS))]
+            out.append(("node", h, Effect.primitive(kind)))
+            prim[h] = kind
+            handles.append(h)
+            is_prim.add(h)
+            connect(h, 0)
+            connect(h, 1)
+            if rng.random() < 0.5:
+                out.append(("edge", h, 0, 0, int(rng.integers(n_outputs))))
+        else:
+            f, fs = source(1 << 30)
+            out.append(("edge", f, 0, fs, int(rng.integers(n_outputs))))
+    steps.extend(out)
+    return out
 
 
 def random_inputs(rng, n_inputs, n_times, kind="mixed"):
