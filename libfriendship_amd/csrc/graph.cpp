@@ -262,11 +262,30 @@ struct Lowering::Impl {
     FlatGraph fg;
     std::vector<Ctx> ctxs;
     // keyed by (context << 32 | dense position of the node inside its graph): exact, no pointer hashing
-    FlatMap64 child_ctx;   // -> context id + 1 (0: forget, the instance was replaced)
-    FlatMap64 memo;        // -> lowered id + 2; 1 = evaluation in progress; 0 = invalidated
+    // Context 0 (the top-level graph, where almost all nodes of a big patch live) is indexed directly by position;
+    // the hash maps serve the contexts of composite instances.
+    struct Table {
+        std::vector<uint64_t> top;
+        FlatMap64 rest;
+        uint64_t *find(uint64_t k) {
+            if (!(k >> 32)) return (uint32_t)k < top.size() ? &top[(uint32_t)k] : nullptr;
+            return rest.find(k);
+        }
+        uint64_t &get(uint64_t k) {
+            if (!(k >> 32)) {
+                const size_t p = (uint32_t)k;
+                if (p >= top.size()) top.resize(std::max(p + 1, top.size() + top.size() / 2), 0);
+                return top[p];
+            }
+            return rest.get(k);
+        }
+        void clear() { top.clear(); rest.clear(); }
+    };
+    Table child_ctx;   // -> context id + 1 (0: forget, the instance was replaced)
+    Table memo;        // -> lowered id + 2; 1 = evaluation in progress; 0 = invalidated / never lowered
     // readers: key -> list of keys whose lowering looked at `key` (as an operand, or -- for a top-level composite
     // instance -- by following one of its inbound edges or outputs)
-    FlatMap64 readers_head;   // -> cell index + 1
+    Table readers_head;   // -> cell index + 1
     std::vector<UserCell> cells;
     std::vector<uint32_t> free_cells;
     bool valid = false;
@@ -284,6 +303,8 @@ struct Lowering::Impl {
         child_ctx.clear();
         memo.clear();
         readers_head.clear();
+        memo.top.reserve(mm.nodes.capacity_positions());
+        readers_head.top.reserve(mm.nodes.capacity_positions());
         cells.clear();
         free_cells.clear();
         fg.konst(0);   // node 0 is always +0.0
@@ -316,7 +337,7 @@ struct Lowering::Impl {
             while (c) {
                 UserCell cell = cells[c - 1];
                 free_cells.push_back(c - 1);
-                const uint64_t *rv = memo.find(cell.user);
+                uint64_t *rv = memo.find(cell.user);
                 if (rv && *rv >= 2) work.push_back(cell.user);
                 c = cell.next;
             }
@@ -384,7 +405,7 @@ struct Lowering::Impl {
                                                  std::to_string(ref.from_slot));
             const uint64_t k = key(ctx, n);
             add_reader(k, reader);
-            if (const uint64_t *mv = memo.find(k)) {
+            if (uint64_t *mv = memo.find(k)) {
                 if (*mv == 1)
                     throw Error(FR_ERR_CYCLE, "dependency cycle through node " + std::to_string(ref.from) +
                                                   " (feedback is not evaluable by this engine)");

@@ -28,9 +28,10 @@ namespace fr {
 // graph is dominated by hash lookups; this is ~3x faster than the node-based std::unordered_map for that use.
 class FlatMap64 {
     static constexpr uint64_t EMPTY = ~0ull;   // keys must not be ~0
-    std::vector<uint64_t> keys_, vals_;
+    struct Slot { uint64_t key, val; };        // key and value share a cache line: one miss per probe
+    std::vector<Slot> slots_;
     size_t n_ = 0, mask_ = 0;
-    // Groups of 16 consecutive keys stay adjacent (one or two cache lines) and the groups are scattered by a full
+    // Groups of 16 consecutive keys stay adjacent (a few cache lines) and the groups are scattered by a full
     // mix: handles and node ids are mostly consecutive, so this keeps lowering cache-friendly without the long runs
     // that make linear probing degenerate under an identity hash.
     static uint64_t hash(uint64_t k) {
@@ -39,30 +40,29 @@ class FlatMap64 {
         return (g << 4) | (k & 15u);
     }
     void grow() {
-        std::vector<uint64_t> ok = std::move(keys_), ov = std::move(vals_);
-        size_t cap = ok.empty() ? 64 : ok.size() * 2;
-        keys_.assign(cap, EMPTY);
-        vals_.assign(cap, 0);
+        std::vector<Slot> old = std::move(slots_);
+        size_t cap = old.empty() ? 64 : old.size() * 2;
+        slots_.assign(cap, Slot{EMPTY, 0});
         mask_ = cap - 1;
         n_ = 0;
-        for (size_t i = 0; i < ok.size(); ++i)
-            if (ok[i] != EMPTY) *slot(ok[i]) = ov[i];
+        for (const Slot &s : old)
+            if (s.key != EMPTY) *slot(s.key) = s.val;
     }
     uint64_t *slot(uint64_t k) {   // existing or fresh slot for k (capacity must allow it)
         size_t i = hash(k) & mask_;
-        while (keys_[i] != EMPTY && keys_[i] != k) i = (i + 1) & mask_;
-        if (keys_[i] == EMPTY) { keys_[i] = k; ++n_; }
-        return &vals_[i];
+        while (slots_[i].key != EMPTY && slots_[i].key != k) i = (i + 1) & mask_;
+        if (slots_[i].key == EMPTY) { slots_[i].key = k; ++n_; }
+        return &slots_[i].val;
     }
 
 public:
     size_t size() const { return n_; }
-    void reserve(size_t n) { while (keys_.size() * 3 < n * 4 + 4) grow(); }
+    void reserve(size_t n) { while (slots_.size() * 3 < n * 4 + 4) grow(); }
     const uint64_t *find(uint64_t k) const {
-        if (keys_.empty()) return nullptr;
+        if (slots_.empty()) return nullptr;
         size_t i = hash(k) & mask_;
-        while (keys_[i] != EMPTY) {
-            if (keys_[i] == k) return &vals_[i];
+        while (slots_[i].key != EMPTY) {
+            if (slots_[i].key == k) return &slots_[i].val;
             i = (i + 1) & mask_;
         }
         return nullptr;
@@ -70,13 +70,13 @@ public:
     uint64_t *find(uint64_t k) { return const_cast<uint64_t *>(static_cast<const FlatMap64 *>(this)->find(k)); }
     // value slot for k, inserted as 0 if absent; `inserted` tells which
     uint64_t &get(uint64_t k, bool *inserted = nullptr) {
-        if ((n_ + 1) * 4 > keys_.size() * 3) grow();
+        if ((n_ + 1) * 4 > slots_.size() * 3) grow();
         size_t before = n_;
         uint64_t *v = slot(k);
         if (inserted) *inserted = n_ != before;
         return *v;
     }
-    void clear() { keys_.clear(); vals_.clear(); n_ = 0; mask_ = 0; }
+    void clear() { slots_.clear(); n_ = 0; mask_ = 0; }
 };
 
 struct Error : std::runtime_error {
