@@ -50,6 +50,7 @@ struct Planner {
             if (supported_memo.count(n)) { st.pop_back(); continue; }
             const FlatNode &x = g.nodes[n];
             if (x.op == OP_CONST || x.op == OP_INPUT) { supported_memo[n] = 1; st.pop_back(); continue; }
+            if (is_voice(n)) { supported_memo[n] = 1; st.pop_back(); continue; }   // a bank computes it: nothing below matters
             uint64_t fr_;
             if (x.op == OP_DELAY && !delay_frames_ok(g, x, fr_)) { supported_memo[n] = 0; st.pop_back(); continue; }
             bool need_a = !supported_memo.count(x.a);
@@ -65,6 +66,15 @@ struct Planner {
 
     bool is_leaf(uint32_t n) const { return g.nodes[n].op == OP_CONST || g.nodes[n].op == OP_INPUT; }
 
+    bool is_voice(uint32_t n) {
+        if (!matcher || g.nodes[n].op != OP_SUM2) return false;
+        if (bank_of.count(n)) return true;
+        VoiceMatch vm;
+        if (!matcher->try_voice(n, vm)) return false;
+        bank_of.emplace(n, std::move(vm));
+        return true;
+    }
+
     // marks banks and cut nodes under a root
     void explore(uint32_t root) {
         std::vector<uint32_t> st{root};
@@ -73,10 +83,7 @@ struct Planner {
             st.pop_back();
             if (is_leaf(n) || !visited.insert(n).second) continue;
             const FlatNode &x = g.nodes[n];
-            if (matcher && x.op == OP_SUM2) {
-                VoiceMatch vm;
-                if (matcher->try_voice(n, vm)) { bank_of.emplace(n, std::move(vm)); continue; }
-            }
+            if (is_voice(n)) continue;
             if (x.op == OP_DELAY) {
                 if (!is_leaf(x.a)) cut.insert(x.a);
                 st.push_back(x.a);
@@ -255,8 +262,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
     std::vector<uint32_t> staged_rows;
     for (uint32_t row = 0; row < n_rows; ++row) {
         uint32_t root = g.outputs[row];
-        VoiceMatch vm;
-        bool root_is_bank = matcher && g.nodes[root].op == OP_SUM2 && matcher->try_voice(root, vm);
+        bool root_is_bank = P.is_voice(root);
         if (root_is_bank || (allow_programs && P.supported(root))) staged_rows.push_back(row);
         else sp.pull_rows.push_back(row);
     }

@@ -1,0 +1,67 @@
+"""Edit-during-playback latency: wall time of the fill_buffer call that follows a graph edit vs a steady-state call.
+
+    python tools/edit_latency.py [--voices 64 --partials 4096 --frames 4800]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from libfriendship_amd import hip_lib, synth  # noqa: E402
+from libfriendship_amd.capi import Renderer, f32_bits  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--voices", type=int, default=64)
+    ap.add_argument("--partials", type=int, default=4096)
+    ap.add_argument("--frames", type=int, default=4800)
+    ap.add_argument("--tree", default="additive", choices=["additive", "effects"])
+    a = ap.parse_args()
+    V, P, T = a.voices, a.partials, a.frames
+    tree = synth.additive_tree(V, P) if a.tree == "additive" else synth.effects_tree(V, P)
+    e = tree["edges"]
+    amp = tree["params"]["amp"]
+    rows = np.nonzero((e[:, 0] == synth.CONST_HANDLE) & (e[:, 3] == 0) & (e[:, 2] == f32_bits(amp[0, 100 % P])))[0]
+    with Renderer(hip_lib()) as r:
+        t0 = time.perf_counter()
+        synth.install(r, tree)
+        t_install = time.perf_counter() - t0
+        idx = 0
+
+        def call():
+            nonlocal idx
+            t = synth.time_ramp(idx, idx + T)
+            t0 = time.perf_counter()
+            r.fill_buffer(V, idx, idx + T, [t])
+            idx += T
+            return (time.perf_counter() - t0) * 1e3
+
+        first = call()
+        plan = r.plan()
+        steady = [call() for _ in range(20)]
+        after = []
+        for i in range(8):
+            row = rows[i % len(rows)]
+            to, slot, old = int(e[row, 1]), int(e[row, 3]), int(e[row, 2])
+            new = f32_bits(np.float32(0.2 + 0.01 * i))
+            t0 = time.perf_counter()
+            r.on_del_edge(synth.CONST_HANDLE, to, old, slot)
+            r.on_add_edge(synth.CONST_HANDLE, to, new, slot)
+            t_edit = (time.perf_counter() - t0) * 1e3
+            e[row, 2] = new
+            after.append((t_edit, call(), r.plan()))
+        print(f"{a.tree} tree {V} x {P}, {T} frames per call (host-buffer API)")
+        print(f"  install (mirror build)        {t_install * 1e3:9.1f} ms")
+        print(f"  first call (lower+plan+run)   {first:9.1f} ms   lower {plan['lower_ms']:.1f} ms, build {plan['build_ms']:.1f} ms")
+        print(f"  steady call                   {np.median(steady):9.3f} ms")
+        for t_edit, ms, p in after:
+            print(f"  call after an edit            {ms:9.3f} ms   edit msgs {t_edit:.3f} ms, {p['lowering']}, "
+                  f"{p['relowered_nodes']} nodes re-lowered, build {p['build_ms']:.2f} ms")
+
+
+if __name__ == "__main__":
+    main()

@@ -4,10 +4,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <string>
 
 #include "../libfriendship_amd/csrc/graph.cpp"
 #include "../libfriendship_amd/csrc/match.cpp"
 #include "../libfriendship_amd/csrc/stage.cpp"
+#include "../libfriendship_amd/csrc/stagejit.cpp"
 
 using namespace fr;
 using Clock = std::chrono::steady_clock;
@@ -15,6 +17,7 @@ static double ms(Clock::time_point a) { return std::chrono::duration<double, std
 
 int main(int argc, char **argv) {
     uint32_t V = argc > 1 ? atoi(argv[1]) : 64, P = argc > 2 ? atoi(argv[2]) : 4096;
+    const bool effects = argc > 3 && std::string(argv[3]) == "effects";
     Mirror m;
     uint32_t next = 1;
     fr_effect prim[8]{};
@@ -51,7 +54,24 @@ int main(int argc, char **argv) {
             }
             cur = nxt;
         }
-        m.add_edge({cur[0], 0, 0, v});
+        uint32_t x = cur[0];
+        if (effects) {   // config D's per-voice chain: ADSR-like envelope, then 4 feed-forward delay taps
+            auto bin = [&](int kind) { return node(kind); };
+            uint32_t a = bin(FR_PRIM_DIVIDE); m.add_edge({0, a, 0, 0}); cst(a, 480.0f, 1);
+            uint32_t rem = bin(FR_PRIM_SUM2); cst(rem, 48000.0f, 0);
+            uint32_t nt = bin(FR_PRIM_MULTIPLY); cst(nt, -1.0f, 0); m.add_edge({0, nt, 0, 1}); m.add_edge({nt, rem, 0, 1});
+            uint32_t rr = bin(FR_PRIM_DIVIDE); m.add_edge({rem, rr, 0, 0}); cst(rr, 4800.0f, 1);
+            uint32_t mn = bin(FR_PRIM_MINIMUM); m.add_edge({a, mn, 0, 0}); m.add_edge({rr, mn, 0, 1});
+            uint32_t en = bin(FR_PRIM_MULTIPLY); m.add_edge({mn, en, 0, 0}); m.add_edge({x, en, 0, 1});
+            x = en;
+            for (int j = 0; j < 4; ++j) {
+                uint32_t dl = bin(FR_PRIM_DELAY); m.add_edge({x, dl, 0, 0}); cst(dl, 2400.0f * (j + 1), 1);
+                uint32_t g = bin(FR_PRIM_MULTIPLY); cst(g, 0.5f, 0); m.add_edge({dl, g, 0, 1});
+                uint32_t s = bin(FR_PRIM_SUM2); m.add_edge({x, s, 0, 0}); m.add_edge({g, s, 0, 1});
+                x = s;
+            }
+        }
+        m.add_edge({x, 0, 0, v});
     }
     std::printf("mirror build: %.1f ms (%u nodes)\n", ms(t0), next - 1);
     Lowering low;
@@ -71,6 +91,11 @@ int main(int argc, char **argv) {
         auto t2 = Clock::now();
         StagedPlan sp = plan_stages(fg, true, true, 20, false, true, matcher.get());
         double t_plan = ms(t2);
+        auto t3 = Clock::now();
+        StageJitPlan sj;
+        bool jit = plan_stage_jit(sp.progs, sp.instrs, 32, false, sj);
+        double t_sj = ms(t3);
+        if (!sp.progs.empty()) std::printf("   stage programs %zu, instrs %zu, codegen %.2f ms (%s, %u shapes, %zu source bytes)\n", sp.progs.size(), sp.instrs.size(), t_sj, jit ? "jit" : "interp", sj.n_shapes, sj.source.size());
         size_t pbytes = 0;
         for (auto &b : sp.banks) pbytes += b.params.size() * 4;
         std::printf("%s %d: lowering %s %.2f ms (%llu nodes re-lowered, %zu flat nodes), plan_stages %.2f ms (%zu banks, %zu param bytes)\n",
