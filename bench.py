@@ -232,6 +232,22 @@ def run():
             hip.fill_buffer(V_local, stripe0 + k * T, stripe0 + (k + 1) * T, [ramp_row(k)])
         host_rate = 5 * T / (time.perf_counter() - th) / 1e6
 
+    # short blocks ("also report T in {64, 512}"): latency of one call through the device entry point
+    short_blocks = None
+    if rank == 0 and world == 1:
+        short_blocks = {}
+        for tb in (64, 512):
+            base = stripe0 + (n_calls + 8) * T
+            for k in range(220):
+                if k == 20:
+                    torch.cuda.synchronize()
+                    tb0 = time.perf_counter()
+                row = d_time[(k * tb) % (T - tb + 1):][:tb]   # any resident f32 row of the right length will do for timing
+                hip.fill_buffer_device(d_out.data_ptr(), V_local, tb, base + k * tb, row.data_ptr(), [0, tb], stream)
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - tb0) / 200 * 1e6
+            short_blocks[str(tb)] = {"us_per_call": us, "msamples_per_s": tb / us}
+
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -288,6 +304,7 @@ def run():
         "partial_frames_per_s": K * T * float(V) * P * (world if shard_mode == "time" else 1) / elapsed,
         "roofline": roofline,
         "host_buffer_api_msamples_per_s": host_rate,
+        "short_blocks": short_blocks,
     }
     # HBM traffic per launch from PMC counters: rocprofv3 cannot wrap a process from inside it, so the figure is
     # read from the committed summary of the separate --pmc passes of this same command (profiles/).

@@ -713,6 +713,16 @@ __global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
         case S_MOD: v = prim_mod(tmp[in.a][tid], tmp[in.b][tid]); break;
         case S_MIN: v = prim_min(tmp[in.a][tid], tmp[in.b][tid]); break;
         case S_STORE: a.rings[(size_t)in.buf * (a.ring_mask + 1) + (t & a.ring_mask)] = tmp[in.a][tid]; continue;
+        case S_READ_DYN: case S_READ_INPUT_DYN: case S_STEP_DYN: {   // Delay by a signal amount (reference.rs:200-215)
+            uint64_t fr;
+            v = 0.0f;
+            if (delay_frames(tmp[in.a][tid], fr) && t >= fr) {
+                if (in.op == S_READ_DYN) v = a.rings[(size_t)in.buf * (a.ring_mask + 1) + ((t - fr) & a.ring_mask)];
+                else if (in.op == S_READ_INPUT_DYN) v = stage_input(a, in.imm, t - fr);
+                else v = __uint_as_float(in.imm);
+            }
+            break;
+        }
         default: v = stage_load(a, in, t); break;   // a load that was not hoisted (register budget)
         }
         tmp[in.dst][tid] = v;

@@ -85,6 +85,11 @@ enum StageOp : uint8_t {
     S_STEP = 4,        // dst = t >= d ? bits(imm) : 0                           Delay of a constant
     S_SUM2 = 5, S_MUL = 6, S_DIV = 7, S_MOD = 8, S_MIN = 9,   // dst = a op b
     S_STORE = 10,      // ring[buf][t & mask] = a        (fused form: an inlined cut node still feeds its ring)
+    // Delay with a signal amount (register a, evaluated at t): frames = amount -> u64 as reference.rs:200-211
+    // (>= 2^64 -> output 0; negative/NaN -> 0 frames; else floor), then as the constant forms.  d_lo = proven bound.
+    S_READ_DYN = 11,        // dst = ring[buf] at t - frames
+    S_READ_INPUT_DYN = 12,  // dst = input[imm] at t - frames
+    S_STEP_DYN = 13,        // dst = t >= frames ? bits(imm) : 0
 };
 struct StageInstr {    // 16 bytes
     uint8_t op, dst, a, b;

@@ -13,6 +13,7 @@
 #include "stage.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -42,6 +43,92 @@ struct Planner {
         return true;
     }
 
+    // ---- value ranges -------------------------------------------------------------------------------------
+    // A Delay whose amount is a signal can still be staged when the amount is provably bounded: the source is
+    // materialised in a ring as for a constant delay, the look-back is the bound, and the program computes the
+    // frame offset per sample.  Bounds come from interval arithmetic over the amount's expression (doubles, widened
+    // outward after every step so that f32 rounding cannot escape them).  `nan` = the value may also be NaN (which
+    // as a delay amount means 0 frames, reference.rs:206-211).  Infinite bounds make everything downstream unbounded.
+    struct Range { double lo, hi; bool nan; };
+    std::unordered_map<uint32_t, Range> range_memo;
+    std::unordered_map<uint32_t, uint64_t> dyn_max;   // Delay node with a signal amount -> bound on the delay in frames
+
+    static Range unbounded() { return Range{-HUGE_VAL, HUGE_VAL, true}; }
+    static bool finite(const Range &r) { return std::isfinite(r.lo) && std::isfinite(r.hi); }
+    static Range widened(double lo, double hi, bool nan) {
+        if (std::isnan(lo) || std::isnan(hi)) return unbounded();
+        const double FMAX = 3.4028234663852886e38;
+        lo -= std::fabs(lo) * 1e-6 + 1e-30;
+        hi += std::fabs(hi) * 1e-6 + 1e-30;
+        if (lo < -FMAX) lo = -HUGE_VAL;
+        if (hi > FMAX) hi = HUGE_VAL;
+        return Range{lo, hi, nan};
+    }
+    static Range combine(uint32_t op, const Range &a, const Range &b) {
+        const bool nan = a.nan || b.nan;
+        switch (op) {
+        case OP_SUM2:
+            if (!finite(a) || !finite(b)) return unbounded();
+            return widened(a.lo + b.lo, a.hi + b.hi, nan);
+        case OP_MUL: {
+            if (!finite(a) || !finite(b)) return unbounded();
+            double p[4] = {a.lo * b.lo, a.lo * b.hi, a.hi * b.lo, a.hi * b.hi};
+            return widened(*std::min_element(p, p + 4), *std::max_element(p, p + 4), nan);
+        }
+        case OP_DIV: {
+            if (!finite(a) || !finite(b) || (b.lo <= 0.0 && b.hi >= 0.0)) return unbounded();
+            double q[4] = {a.lo / b.lo, a.lo / b.hi, a.hi / b.lo, a.hi / b.hi};
+            return widened(*std::min_element(q, q + 4), *std::max_element(q, q + 4), nan);
+        }
+        case OP_MOD: {   // rem = fmod(a, b); rem < 0 ? rem + b : rem.  Any dividend (inf, NaN give NaN); |rem| < |b|
+            if (!finite(b)) return unbounded();
+            if (b.lo > 0.0) return widened(0.0, b.hi, true);              // [0, b] (the sum can round up to b itself)
+            const double B = std::max(std::fabs(b.lo), std::fabs(b.hi));
+            return widened(-2.0 * B, B, true);                            // a non-positive divisor: (-2|b|, |b|)
+        }
+        default: {        // Minimum = (a < b || isnan(b)) ? a : b: NaN only if both are; a NaN on one side selects the other side
+            double hi = (!a.nan && !b.nan) ? std::min(a.hi, b.hi) : !a.nan ? a.hi : !b.nan ? b.hi : std::max(a.hi, b.hi);
+            return Range{std::min(a.lo, b.lo), hi, a.nan && b.nan};
+        }
+        }
+    }
+    Range range(uint32_t root) {
+        std::vector<uint32_t> st{root};
+        while (!st.empty()) {
+            uint32_t n = st.back();
+            if (range_memo.count(n)) { st.pop_back(); continue; }
+            const FlatNode &x = g.nodes[n];
+            if (x.op == OP_CONST) {
+                float c = g.const_val(n);
+                range_memo[n] = c != c ? Range{0.0, 0.0, true} : Range{(double)c, (double)c, false};
+                st.pop_back();
+                continue;
+            }
+            if (x.op == OP_INPUT) { range_memo[n] = unbounded(); st.pop_back(); continue; }
+            bool need_a = !range_memo.count(x.a);
+            bool need_b = x.op != OP_DELAY && !range_memo.count(x.b);
+            if (need_a) st.push_back(x.a);
+            if (need_b) st.push_back(x.b);
+            if (need_a || need_b) continue;
+            if (x.op == OP_DELAY) {   // the source at some other time, or 0
+                Range s = range_memo[x.a];
+                range_memo[n] = Range{std::min(s.lo, 0.0), std::max(s.hi, 0.0), s.nan};
+            } else {
+                range_memo[n] = combine(x.op, range_memo[x.a], range_memo[x.b]);
+            }
+            st.pop_back();
+        }
+        return range_memo[root];
+    }
+    // Delay node n with a non-constant amount: can it be staged, and with what bound?
+    bool dynamic_delay_ok(uint32_t n) {
+        if (dyn_max.count(n)) return true;
+        Range r = range(g.nodes[n].b);
+        if (!(r.hi < 2147483648.0)) return false;   // unbounded (or NaN bound)
+        dyn_max[n] = r.hi <= 0.0 ? 0 : (uint64_t)r.hi;
+        return true;
+    }
+
     // iterative post-order "is everything under n stageable"
     bool supported(uint32_t root) {
         std::vector<uint32_t> st{root};
@@ -52,13 +139,14 @@ struct Planner {
             if (x.op == OP_CONST || x.op == OP_INPUT) { supported_memo[n] = 1; st.pop_back(); continue; }
             if (is_voice(n)) { supported_memo[n] = 1; st.pop_back(); continue; }   // a bank computes it: nothing below matters
             uint64_t fr_;
-            if (x.op == OP_DELAY && !delay_frames_ok(g, x, fr_)) { supported_memo[n] = 0; st.pop_back(); continue; }
+            const bool const_delay = x.op == OP_DELAY && delay_frames_ok(g, x, fr_);
+            if (x.op == OP_DELAY && !const_delay && (g.is_const(x.b) || !dynamic_delay_ok(n))) { supported_memo[n] = 0; st.pop_back(); continue; }
             bool need_a = !supported_memo.count(x.a);
-            bool need_b = x.op != OP_DELAY && !supported_memo.count(x.b);
+            bool need_b = !const_delay && !supported_memo.count(x.b);   // a signal amount is computed by the program
             if (need_a) st.push_back(x.a);
             if (need_b) st.push_back(x.b);
             if (need_a || need_b) continue;
-            supported_memo[n] = supported_memo[x.a] && (x.op == OP_DELAY || supported_memo[x.b]);
+            supported_memo[n] = supported_memo[x.a] && (const_delay || supported_memo[x.b]);
             st.pop_back();
         }
         return supported_memo[root] != 0;
@@ -87,6 +175,7 @@ struct Planner {
             if (x.op == OP_DELAY) {
                 if (!is_leaf(x.a)) cut.insert(x.a);
                 st.push_back(x.a);
+                if (dyn_max.count(n)) st.push_back(x.b);   // the amount's own expression
             } else {
                 st.push_back(x.a);
                 st.push_back(x.b);
@@ -129,7 +218,8 @@ struct ProgBuild {
     std::vector<StageInstr> instrs;   // `buf` holds the cut NODE id until rings are assigned
     uint32_t result_reg = 0;
     uint32_t n_loads = 0;             // leading instructions without register operands (hoisted loads)
-    std::vector<std::pair<uint32_t, uint64_t>> reads;   // (cut node, delay)
+    std::vector<std::pair<uint32_t, uint64_t>> reads;   // (cut node, delay -- for a signal amount its upper bound)
+    std::unordered_set<uint32_t> dynamic_reads;         // cut nodes read with a signal amount (possibly 0 frames back)
 };
 
 // Emits the program computing cut node `m`.  Returns false if it does not fit the budgets.
@@ -159,7 +249,11 @@ bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unorde
             if (!seen.insert(n).second) continue;
             st.push_back({n, 1});
             const FlatNode &x = g.nodes[n];
-            if (is_boundary(n) || x.op == OP_CONST || x.op == OP_INPUT || x.op == OP_DELAY) continue;   // leaves of the program
+            if (is_boundary(n) || x.op == OP_CONST || x.op == OP_INPUT) continue;   // leaves of the program
+            if (x.op == OP_DELAY) {   // the source is read from a ring / input row; a signal amount is computed here, at t
+                if (P.dyn_max.count(n)) { ++uses[x.b]; st.push_back({x.b, 0}); }
+                continue;
+            }
             ++uses[x.a];
             ++uses[x.b];
             st.push_back({x.b, 0});
@@ -171,7 +265,7 @@ bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unorde
     {
         auto is_load = [&](uint32_t n) {
             const FlatNode &x = g.nodes[n];
-            return is_boundary(n) || x.op == OP_CONST || x.op == OP_INPUT || x.op == OP_DELAY;
+            return is_boundary(n) || x.op == OP_CONST || x.op == OP_INPUT || (x.op == OP_DELAY && !P.dyn_max.count(n));
         };
         size_t n_loads = 0;
         for (uint32_t n : order) n_loads += is_load(n) ? 1 : 0;
@@ -199,6 +293,21 @@ bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unorde
             in.op = S_CONST; in.imm = x.a;
         } else if (x.op == OP_INPUT) {
             in.op = S_INPUT; in.imm = dense(x.a);
+        } else if (x.op == OP_DELAY && P.dyn_max.count(n)) {
+            const uint64_t bound = P.dyn_max.at(n);
+            const FlatNode &src = g.nodes[x.a];
+            in.a = reg_of.at(x.b);
+            in.d_lo = (uint32_t)bound;   // (informational: the proven bound)
+            if (src.op == OP_CONST) { in.op = S_STEP_DYN; in.imm = src.a; }
+            else if (src.op == OP_INPUT) { in.op = S_READ_INPUT_DYN; in.imm = dense(src.a); }
+            else {
+                in.op = S_READ_DYN; in.buf = x.a;
+                out.reads.push_back({x.a, bound});
+                out.dynamic_reads.insert(x.a);
+                // the offset can be anything in [0, bound]: a ring filled by this very launch is not safe to read
+                if (min_delay && !P.bank_of.count(x.a)) *min_delay = 0;
+            }
+            if (--uses[x.b] == 0) free_regs.push_back(reg_of.at(x.b));
         } else if (x.op == OP_DELAY) {
             uint64_t d;
             Planner::delay_frames_ok(g, x, d);
@@ -383,7 +492,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         pg.out_row = pd.out_row;
         pg.n_loads = pd.pb->n_loads;
         for (StageInstr in : pd.pb->instrs) {
-            if (in.op == S_READ) in.buf = ring_of.at(in.buf);
+            if (in.op == S_READ || in.op == S_READ_DYN) in.buf = ring_of.at(in.buf);
             sp.instrs.push_back(in);
         }
         sp.progs.push_back(pg);
@@ -397,7 +506,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         std::unordered_set<uint32_t> same_frame_used;
         for (auto &kv : built)
             for (auto &rd : kv.second.reads)
-                if (rd.second == 0 && !P.bank_of.count(rd.first)) same_frame_used.insert(rd.first);
+                if ((rd.second == 0 || kv.second.dynamic_reads.count(rd.first)) && !P.bank_of.count(rd.first)) same_frame_used.insert(rd.first);
         uint64_t min_delay = ~0ull;
         bool fits = true;
         std::vector<StageInstr> finstrs;
@@ -411,7 +520,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
             pg.out_row = out_row;
             pg.n_loads = pb.n_loads;
             for (StageInstr in : pb.instrs) {
-                if (in.op == S_READ || in.op == S_STORE) in.buf = ring_of.at(in.buf);
+                if (in.op == S_READ || in.op == S_STORE || in.op == S_READ_DYN) in.buf = ring_of.at(in.buf);
                 finstrs.push_back(in);
             }
             fprogs.push_back(pg);

@@ -41,6 +41,25 @@ __device__ __forceinline__ void ring_store(const JitStageArgs &a, unsigned int b
     a.rings[(size_t)buf * (a.ring_mask + 1) + (t & a.ring_mask)] = v;
 }
 __device__ __forceinline__ float step(unsigned int bits, unsigned int d, u64 t) { return t >= d ? f32(bits) : 0.0f; }
+// Delay by a signal amount (reference.rs:200-215): >= 2^64 -> the output is 0; negative / NaN -> 0 frames; else floor
+__device__ __forceinline__ bool dyn_frames(float d, u64 t, u64 &at) {
+    if (d >= 18446744073709551616.0f) return false;
+    u64 fr = (d < 0.0f || d != d) ? 0ull : (u64)d;
+    at = t - fr;
+    return t >= fr;
+}
+__device__ __forceinline__ float ring_read_dyn(const JitStageArgs &a, unsigned int buf, float d, u64 t) {
+    u64 at;
+    return dyn_frames(d, t, at) ? a.rings[(size_t)buf * (a.ring_mask + 1) + (at & a.ring_mask)] : 0.0f;
+}
+__device__ __forceinline__ float in_delayed_dyn(const JitStageArgs &a, unsigned int slot, float d, u64 t) {
+    u64 at;
+    return dyn_frames(d, t, at) ? in_at(a, slot, at) : 0.0f;
+}
+__device__ __forceinline__ float step_dyn(unsigned int bits, float d, u64 t) {
+    u64 at;
+    return dyn_frames(d, t, at) ? f32(bits) : 0.0f;
+}
 
 SHAPE_FUNCTIONS
 
@@ -140,6 +159,9 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
             case S_READ: fns << "ring_read(a, P[" << k << "], P[" << k + 1 << "], t)"; k += 2; break;
             case S_READ_INPUT: fns << "in_delayed(a, P[" << k << "], P[" << k + 1 << "], t)"; k += 2; break;
             case S_STEP: fns << "step(P[" << k << "], P[" << k + 1 << "], t)"; k += 2; break;
+            case S_READ_DYN: fns << "ring_read_dyn(a, P[" << k << "], v" << var_of[in.a] << ", t)"; k += 1; break;
+            case S_READ_INPUT_DYN: fns << "in_delayed_dyn(a, P[" << k << "], v" << var_of[in.a] << ", t)"; k += 1; break;
+            case S_STEP_DYN: fns << "step_dyn(P[" << k << "], v" << var_of[in.a] << ", t)"; k += 1; break;
             case S_SUM2: fns << "v" << var_of[in.a] << " + v" << var_of[in.b]; break;
             case S_MUL: fns << "v" << var_of[in.a] << " * v" << var_of[in.b]; break;
             case S_DIV: fns << "v" << var_of[in.a] << " / v" << var_of[in.b]; break;
@@ -179,7 +201,8 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
             case S_INPUT: out.ptab.push_back(in.imm); break;
             case S_READ: out.ptab.push_back(in.buf); out.ptab.push_back(in.d_lo); break;
             case S_READ_INPUT: case S_STEP: out.ptab.push_back(in.imm); out.ptab.push_back(in.d_lo); break;
-            case S_STORE: out.ptab.push_back(in.buf); break;
+            case S_STORE: case S_READ_DYN: out.ptab.push_back(in.buf); break;
+            case S_READ_INPUT_DYN: case S_STEP_DYN: out.ptab.push_back(in.imm); break;
             default: break;
             }
         }

@@ -228,6 +228,30 @@ def effects_tree(n_voices, n_partials, seed=0x5EED0003, detune=True, envelope=Tr
     return t
 
 
+def chorus_tree(n_voices, n_partials, seed=0x5EED0004, depth=300.0, base=400.0, rate_hz=0.7, taps=0, base_delay=2400.0,
+                sr=48000.0, time_slot=0):
+    """Voices through a chorus: y = Sum2(x, Multiply(C(0.5), Delay(x, amount(t)))) with the delay amount a SIGNAL,
+    amount = base + depth * lfo(t), lfo = Modulo(t * rate/sr * (v+1), 1) in [0, 1] -- the `Delay` amount evaluated
+    at the undelayed t, floor to frames (reference src/render/reference.rs:197-216).  Optionally followed by the
+    constant-delay chain of config D."""
+    p = voice_params(n_voices, n_partials, seed, False, sr)
+    g = GraphArrays()
+    f = np.float32
+    leaves = partial_leaves(g, p["w"], p["amp"], time_slot).reshape(n_voices, n_partials)
+    x = sum_tree(g, leaves)
+    rates = (f(rate_hz) / f(sr) * np.arange(1, n_voices + 1, dtype=np.float32)).astype(np.float32)
+    lfo = g.binop(K_MOD, g.binop(K_MUL, IN(time_slot), C(rates), n_voices), C(f(1.0)), n_voices)
+    amount = g.binop(K_SUM2, C(f(base)), g.binop(K_MUL, C(f(depth)), lfo, n_voices), n_voices)
+    wet = g.binop(K_DELAY, x, amount, n_voices)
+    x = g.binop(K_SUM2, x, g.binop(K_MUL, C(f(0.5)), wet, n_voices), n_voices)
+    if taps:
+        x = delay_chain(g, x, taps, base_delay)
+    g.edge(x, 0, 0, np.arange(n_voices, dtype=np.uint32))
+    t = g.finish(n_voices)
+    t["params"] = p
+    return t
+
+
 def partial_effect():
     """The partial oscillator as ONE composite effect `Partial(t, w, amp) -> leaf` (what a `.fnd` effect file would
     hold): inputs 0,1,2 = time, w, amp as signals; per instance the host feeds w and amp through F32Constant edges.

@@ -198,6 +198,18 @@ struct StagedSim {
                     case S_READ_INPUT: v = t >= x.d_lo ? in_at(in, sp.input_slots[x.imm], t - x.d_lo) : 0.0f; break;
                     case S_STEP: v = t >= x.d_lo ? f32_from_bits(x.imm) : 0.0f; break;
                     case S_STORE: rings[x.buf][t] = tmp[x.a]; continue;
+                    case S_READ_DYN: case S_READ_INPUT_DYN: case S_STEP_DYN: {
+                        float d = tmp[x.a];
+                        v = 0.0f;
+                        if (d >= 18446744073709551616.0f) break;
+                        uint64_t fr_ = (d < 0.0f || d != d) ? 0 : (uint64_t)d;
+                        CHECK(fr_ <= x.d_lo);   // the planner's bound holds
+                        if (t < fr_) break;
+                        if (x.op == S_READ_DYN) { CHECK(rings[x.buf].count(t - fr_)); v = rings[x.buf][t - fr_]; }
+                        else if (x.op == S_READ_INPUT_DYN) v = in_at(in, sp.input_slots[x.imm], t - fr_);
+                        else v = f32_from_bits(x.imm);
+                        break;
+                    }
                     case S_SUM2: v = host_binop(OP_SUM2, tmp[x.a], tmp[x.b]); break;
                     case S_MUL: v = host_binop(OP_MUL, tmp[x.a], tmp[x.b]); break;
                     case S_DIV: v = host_binop(OP_DIV, tmp[x.a], tmp[x.b]); break;
@@ -435,7 +447,7 @@ static void effects_chain_is_staged() {
 
 static void dynamic_delay_goes_to_pull() {
     Build b;
-    uint32_t amt = b.op(FR_PRIM_MODULO, In(0), Cf(5.0f));
+    uint32_t amt = b.op(FR_PRIM_MULTIPLY, In(0), Cf(0.25f));   // no bound can be proven for this amount
     uint32_t d = b.op(FR_PRIM_DELAY, In(1), N(amt));
     b.out(N(d), 0);
     b.out(N(b.op(FR_PRIM_SUM2, In(1), Cf(1.0f))), 1);
@@ -803,6 +815,95 @@ static void incremental_lowering_equals_from_scratch() {
     CHECK(n_incremental > 20 * n_full && n_full > 30 && n_errors > 0 && n_errors < n_incremental);
 }
 
+static void bounded_signal_delays_are_staged() {
+    // chorus / flanger shapes: Delay(x, amount(t)) with a provably bounded amount
+    std::mt19937 rng(21);
+    Build b;
+    const uint32_t V = 3;
+    for (uint32_t v = 0; v < V; ++v) {
+        uint32_t mix = voice(b, 32, 110.0f * (v + 1), rng);
+        uint32_t lfo = b.op(FR_PRIM_MODULO, N(b.op(FR_PRIM_MULTIPLY, In(0), Cf(0.013f * (v + 1)))), Cf(1.0f));       // [0, 1]
+        uint32_t amt = b.op(FR_PRIM_SUM2, Cf(3.0f + v), N(b.op(FR_PRIM_MULTIPLY, Cf(40.0f), N(lfo))));                // [3, 43+]
+        uint32_t wet = b.op(FR_PRIM_DELAY, N(mix), N(amt));                                                          // bank ring, signal amount
+        uint32_t x = b.op(FR_PRIM_SUM2, N(mix), N(b.op(FR_PRIM_MULTIPLY, Cf(0.5f), N(wet))));
+        uint32_t echo = b.op(FR_PRIM_DELAY, N(x), Cf(70.0f));                                                        // + a constant tap on top
+        // a second modulated tap whose source is a program cut node (x), amount clamped by Minimum: may be 0 frames
+        uint32_t amt2 = b.op(FR_PRIM_MINIMUM, Cf(25.0f), N(b.op(FR_PRIM_MULTIPLY, In(1), In(1))));                    // min(25, noise^2): [.., 25]
+        uint32_t wob = b.op(FR_PRIM_DELAY, N(x), N(amt2));
+        b.out(N(b.op(FR_PRIM_SUM2, N(b.op(FR_PRIM_SUM2, N(x), N(echo))), N(wob))), v);
+    }
+    // delayed input and delayed constant with signal amounts; an amount that can be negative / NaN (-> 0 frames)
+    uint32_t a3 = b.op(FR_PRIM_MODULO, In(1), Cf(9.0f));                                                              // [0, 9], NaN when the input is inf
+    uint32_t din = b.op(FR_PRIM_DELAY, In(1), N(a3));
+    uint32_t dct = b.op(FR_PRIM_DELAY, Cf(2.5f), N(b.op(FR_PRIM_MODULO, In(0), Cf(7.0f))));
+    uint32_t neg = b.op(FR_PRIM_DELAY, In(0), N(b.op(FR_PRIM_SUM2, Cf(-4.0f), N(a3))));                               // [-4, 5]
+    b.out(N(b.op(FR_PRIM_SUM2, N(din), N(b.op(FR_PRIM_SUM2, N(dct), N(neg))))), V);
+    // unbounded amount: stays with the pull interpreter
+    b.out(N(b.op(FR_PRIM_DELAY, In(1), N(b.op(FR_PRIM_MULTIPLY, In(0), Cf(0.5f))))), V + 1);
+    auto inspect = [&](const FlatGraph &, const StagedPlan &sp) {
+        CHECK(sp.pull_rows.size() == 1 && sp.pull_rows[0] == V + 1);
+        CHECK(sp.lmax >= 70 + 43 && sp.lmax <= 70 + 50);
+        CHECK(sp.fused_count == 0);        // a signal-delayed read of a program's ring can land inside the current launch
+        size_t dyn = 0;
+        for (const StageInstr &in : sp.instrs) dyn += (in.op == S_READ_DYN || in.op == S_READ_INPUT_DYN || in.op == S_STEP_DYN) ? 1 : 0;
+        CHECK(dyn == 2 * V + 3);
+    };
+    check_graph(b, V + 2, 100, 5, true, "bounded signal delays", inspect);
+    check_graph(b, V + 2, 17, 9, true, "bounded signal delays, short calls");
+    check_compiled_programs(b, V + 2, 64, {0, 64, 128, 192, 5000, 5064}, "bounded signal delays, compiled");
+}
+
+static void value_ranges_are_sound() {
+    // Planner::range (the interval analysis that licenses staging a signal-amount Delay) against brute-force evaluation
+    const int kinds[6] = {FR_PRIM_DELAY, FR_PRIM_SUM2, FR_PRIM_MULTIPLY, FR_PRIM_DIVIDE, FR_PRIM_MODULO, FR_PRIM_MINIMUM};
+    const float consts[14] = {0.0f, -0.0f, 1.0f, -1.0f, 0.5f, 2.0f, 3.0f, -3.5f, 7.25f, 1e-30f, 1e30f, -1e30f, 48000.0f, NAN};
+    const float specials[12] = {0.0f, -0.0f, 1.0f, -2.5f, 1e30f, -1e30f, INFINITY, -INFINITY, NAN, 3.5f, 1e-40f, 16777216.0f};
+    uint64_t bounded_nodes = 0, checked = 0;
+    for (unsigned seed = 0; seed < 150; ++seed) {
+        std::mt19937 rng(3000 + seed);
+        Build b;
+        std::vector<uint32_t> avail;
+        int n = 6 + (int)(rng() % 30);
+        for (int i = 0; i < n; ++i) {
+            int k = kinds[rng() % 6];
+            auto pick = [&]() -> Operand {
+                unsigned r = rng() % 10;
+                if (r < 4 || avail.empty()) return (rng() % 3 == 0) ? In(rng() % 2) : Cf(consts[rng() % 14]);
+                return N(avail[rng() % avail.size()]);
+            };
+            Operand a = pick(), bb = pick();
+            if (k == FR_PRIM_DELAY) bb = Cf((float)(rng() % 5));
+            avail.push_back(b.op(k, a, bb));
+        }
+        for (uint32_t s = 0; s < 4; ++s) b.out(N(avail[avail.size() - 1 - (rng() % std::min<size_t>(avail.size(), 8))]), s);
+        Mirror m;
+        b.apply(m);
+        FlatGraph fg = lower(m, 4);
+        Planner P(fg, nullptr);
+        Inputs in(2);
+        for (int t = 0; t < 40; ++t) {
+            in[0].push_back(t % 7 == 6 ? specials[rng() % 12] : (float)t * 1000.0f);
+            in[1].push_back(rng() % 3 ? specials[rng() % 12] : (float)((int)(rng() % 2001) - 1000) * 0.01f);
+        }
+        for (uint32_t id = 0; id < fg.nodes.size(); ++id) {
+            Planner::Range r = P.range(id);
+            if (std::isfinite(r.hi) || std::isfinite(r.lo)) ++bounded_nodes;
+            for (uint64_t t = 0; t < 40; ++t) {
+                float val = flat_eval(fg, id, t, in);
+                ++checked;
+                bool ok = val != val ? r.nan : ((double)val >= r.lo && (double)val <= r.hi);
+                if (!ok) {
+                    std::fprintf(stderr, "seed %u node %u (op %u) t %llu: value %a outside [%g, %g] nan=%d\n", seed, id, fg.nodes[id].op,
+                                 (unsigned long long)t, val, r.lo, r.hi, (int)r.nan);
+                    throw std::runtime_error("unsound range");
+                }
+            }
+        }
+    }
+    if (std::getenv("FR_TEST_VERBOSE")) std::fprintf(stderr, "%llu values checked, %llu nodes with a finite bound\n", (unsigned long long)checked, (unsigned long long)bounded_nodes);
+    CHECK(bounded_nodes > 500);
+}
+
 int main(int argc, char **argv) {
     std::vector<std::pair<const char *, std::function<void()>>> tests = {
         {"lowering_folds_constants", lowering_folds_constants}, {"lowering_errors", lowering_errors},
@@ -810,7 +911,9 @@ int main(int argc, char **argv) {
         {"effects_chain_is_staged", effects_chain_is_staged}, {"dynamic_delay_goes_to_pull", dynamic_delay_goes_to_pull},
         {"composite_instances_are_interned", composite_instances_are_interned},
         {"stage_programs_compile_to_source", stage_programs_compile_to_source},
-        {"incremental_lowering_equals_from_scratch", incremental_lowering_equals_from_scratch}};
+        {"incremental_lowering_equals_from_scratch", incremental_lowering_equals_from_scratch},
+        {"bounded_signal_delays_are_staged", bounded_signal_delays_are_staged},
+        {"value_ranges_are_sound", value_ranges_are_sound}};
     int failed = 0, ran = 0;
     for (auto &t : tests) {
         if (argc > 1 && std::string(argv[1]) != t.first) continue;

@@ -462,6 +462,29 @@ def test_edit_of_a_large_tree_relowers_only_what_changed(hip_lib, oracle_lib):
         assert same_bits(got[:, :4], exp4), first_diff(got[:, :4], exp4)
 
 
+@pytest.mark.parametrize("V,P,T,taps", [(4, 64, 128, 0), (3, 32, 100, 2), (6, 32, 64, 0)])
+def test_chorus_signal_delay_is_staged(hip_lib, oracle_lib, V, P, T, taps):
+    """Delay with a SIGNAL amount (reference.rs:197-216: evaluated at the undelayed t, floored): when interval analysis
+    bounds the amount (here base + depth * (x mod 1)) the source is kept in a ring like a constant delay's and the
+    program computes the offset per sample -- no pull interpreter, voices stay on the bank kernel."""
+    tree = synth.chorus_tree(V, P, depth=30.0, base=11.0, rate_hz=900.0, taps=taps, base_delay=70.0)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        _effects_sequence(hip, ref, V, T, calls=5, seek_to=20 * T + 5)
+        plan = hip.plan()
+        assert plan["pull_rows"] == 0 and plan["banks"] and plan["banks"][0]["to_ring"] is True, plan
+        assert 41 + 70 * taps * (taps + 1) // 2 <= plan["max_lookback"] <= 43 + 70 * taps * (taps + 1) // 2, plan
+    with Renderer(hip_lib, mode="pull") as pull, Renderer(hip_lib) as hip:   # and against the generic evaluator at a larger size
+        big = synth.chorus_tree(8, 256, taps=1)
+        synth.install(pull, big)
+        synth.install(hip, big)
+        for k in range(2):
+            t = synth.time_ramp(k * 1500, (k + 1) * 1500)
+            a, b = hip.fill_buffer(8, k * 1500, (k + 1) * 1500, [t]), pull.fill_buffer(8, k * 1500, (k + 1) * 1500, [t])
+            assert same_bits(a, b), first_diff(a, b)
+
+
 def test_graph_edit_rebuilds_delay_state(hip_lib, oracle_lib):
     """Edits between calls apply to ALL times evaluated afterwards, look-back included: the rings
     are rebuilt from the input history with the new graph."""
