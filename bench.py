@@ -99,9 +99,10 @@ def run():
     ap.add_argument("--shard", default="time", choices=["time", "voices", "partials"],
                     help="how N > 1 ranks split the job (libfriendship_amd/shard.py): time stripes (weak scaling, no exchange; "
                          "default), voices (strong, no exchange), partial blocks (strong, RCCL all-gather + tree-order sum)")
-    ap.add_argument("--tree", default="additive", choices=["additive", "effects"],
+    ap.add_argument("--tree", default="additive", choices=["additive", "effects", "chorus"],
                     help="additive = BASELINE configs[2] shape (the headline); effects = configs[3] shape (detune + ADSR + "
-                         "4-tap delay chain), a diagnostic run: use with --voices 128 --partials 1024 --no-cpu-baseline")
+                         "4-tap delay chain), a diagnostic run: use with --voices 128 --partials 1024 --no-cpu-baseline; "
+                         "chorus = every voice through a Delay with a SIGNAL amount (LFO) + the 4-tap chain, also a diagnostic")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl is RCCL on ROCm (default)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even with one rank and take the partial-shard exchange path (RCCL plumbing check)")
@@ -139,9 +140,10 @@ def run():
     shard_mode = args.shard if use_dist else "time"
     # seeded synthetic tree, ~12 primitive nodes per partial; under voices/partials sharding each rank
     # holds only its sub-graph
-    if args.tree == "effects":
-        assert world == 1, "the effects tree is a single-GPU diagnostic"
-        tree, shard_info = synth.effects_tree(V, P), {"partials": (0, P), "voices": (0, V), "mode": "time"}
+    if args.tree in ("effects", "chorus"):
+        assert world == 1, "the effects and chorus trees are single-GPU diagnostics"
+        tree = synth.effects_tree(V, P) if args.tree == "effects" else synth.chorus_tree(V, P, taps=4)
+        shard_info = {"partials": (0, P), "voices": (0, V), "mode": "time"}
     else:
         tree, shard_info = shard.additive_tree_shard(V, P, rank, world, shard_mode)
     full_tree = tree if shard_mode == "time" else None
@@ -234,7 +236,7 @@ def run():
 
     # short blocks ("also report T in {64, 512}"): latency of one call through the device entry point
     short_blocks = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and elapsed / K < 5e-3:   # (not when a call takes milliseconds: pull-mode diagnostics)
         short_blocks = {}
         for tb in (64, 512):
             base = stripe0 + (n_calls + 8) * T
@@ -294,7 +296,9 @@ def run():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"additive tree, {P} partials x {V} voices, 48 kHz, {T}-frame fill_buffer calls "
                                 f"(BASELINE.json configs[2])" if args.tree == "additive" else
-                                f"harmonics + detune + ADSR + 4-tap delay chain, {P} partials x {V} voices (BASELINE.json configs[3] shape)"),
+                                f"harmonics + detune + ADSR + 4-tap delay chain, {P} partials x {V} voices (BASELINE.json configs[3] shape)"
+                                if args.tree == "effects" else
+                                f"chorus (Delay with an LFO amount) + 4-tap delay chain, {P} partials x {V} voices (diagnostic)"),
                    "voices": V, "partials": P, "frames_per_call": T,
                    "sharding": {"time": "time stripes, one per GPU, no collective",
                                 "voices": "voices split over GPUs, no collective",
