@@ -581,14 +581,11 @@ __device__ __forceinline__ float gbank_group(const ParamGroup &pg, uint32_t j, f
 }
 
 template <bool FAST>
-__device__ __forceinline__ float gbank_wave(const float *params, const uint32_t *gmeta, uint32_t ngroups, float t, float *stack /* [GB_MAX_DEPTH][64] + lane */) {
+__device__ __forceinline__ float gbank_wave(const float *params, const uint32_t *gmeta, uint32_t nitems, float t, float *stack /* [GB_MAX_DEPTH][64] + lane */) {
     uint32_t sp = 0;
     const_f32_ptr p = (const_f32_ptr)params;
     typedef uint32_t __attribute__((address_space(4))) const *const_u32_ptr;
     const_u32_ptr gm = (const_u32_ptr)gmeta;
-    ParamGroup pa, pb;
-    load_group(pa, p, 0);
-    uint32_t meta_a = gm[0], meta_b = 0;
     auto finish = [&](float v, uint32_t meta) {
         for (uint32_t m = meta >> 4; m != 0u; --m) {   // v = pop() + v
             --sp;
@@ -597,16 +594,36 @@ __device__ __forceinline__ float gbank_wave(const float *params, const uint32_t 
         stack[sp * 64u] = v;
         ++sp;
     };
-    for (uint32_t g = 0; g < ngroups; g += 2) {
-        const bool has_b = g + 1 < ngroups;
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        if (has_b) { load_group(pb, p, g + 1); meta_b = gm[g + 1]; }
-        finish(gbank_group<FAST>(pa, meta_a & 15u, t), meta_a);
-        if (has_b) {
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            if (g + 2 < ngroups) { load_group(pa, p, g + 2); meta_a = gm[g + 2]; }
-            finish(gbank_group<FAST>(pb, meta_b & 15u, t), meta_b);
+    // Items of 16..2048 leaves (complete sub-trees) run the balanced kernel's inner loop: parameters through the
+    // scalar cache with its own prefetch, group sums merged by the register carry chain.  Smaller items are single
+    // groups; the next one's parameters are requested before this one's math when it is small too.
+    ParamGroup cur, nxt;
+    bool have = false;
+    uint32_t goff = 0;          // parameter group (8 pairs) the current item starts at
+    uint32_t meta = gm[0];
+    for (uint32_t i = 0; i < nitems; ++i) {
+        const uint32_t meta_next = i + 1 < nitems ? gm[i + 1] : 0u;
+        const uint32_t k = meta & 15u;
+        float v;
+        if (k > 3u) {
+            const float tt[1] = {t};
+            float res[1];
+            bank_wave_sum<1, FAST, false>(params + (size_t)goff * 16u, 1u << (k - 3u), k - 3u, tt, res);
+            v = res[0];
+            goff += 1u << (k - 3u);
+            have = false;
+        } else {
+            if (!have) load_group(cur, p, goff);
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): cur and meta_next have landed
+            const bool next_small = i + 1 < nitems && (meta_next & 15u) <= 3u;
+            if (next_small) load_group(nxt, p, goff + 1u);
+            v = gbank_group<FAST>(cur, k, t);
+            goff += 1u;
+            have = next_small;
+            if (next_small) cur = nxt;
         }
+        finish(v, meta);
+        meta = meta_next;
     }
     return stack[0];   // a well-formed schedule leaves exactly the root
 }
@@ -623,11 +640,11 @@ __global__ void __launch_bounds__(256) gbank_kernel(BankArgs a, uint32_t tile_gr
     const uint64_t ti = (uint64_t)tile * 64u + lane;
     const float t = bank_time(a, ti);
     const bool fast = a.fast_ok && __all(t >= 0.0f && t <= 4294967296.0f);
-    const uint32_t g0 = a.group_off[voice], ng = a.group_off[voice + 1] - g0;
-    const float2 *vparams = a.params + (size_t)g0 * 8u;
+    const uint32_t i0 = a.group_off[2u * voice], ni = a.group_off[2u * voice + 2u] - i0;
+    const float2 *vparams = a.params + (size_t)a.group_off[2u * voice + 1u] * 8u;
     float *stack = &stack_mem[wave][0][lane];
-    float r = fast ? gbank_wave<true>((const float *)vparams, a.groups + g0, ng, t, stack)
-                   : gbank_wave<false>((const float *)vparams, a.groups + g0, ng, t, stack);
+    float r = fast ? gbank_wave<true>((const float *)vparams, a.groups + i0, ni, t, stack)
+                   : gbank_wave<false>((const float *)vparams, a.groups + i0, ni, t, stack);
     float *orow = a.out + (size_t)a.rows[voice] * a.out_stride;
     const bool live = ti < a.n_times;
     if (live) orow[bank_out_index(a, ti)] = r;
@@ -639,15 +656,17 @@ __global__ void __launch_bounds__(256) gbank_kernel(BankArgs a, uint32_t tile_gr
         uint64_t tz_i = (uint64_t)tile * 64u + l;
         float tz = bank_time(a, tz_i);
         bool ok = true;
-        for (uint32_t k = lane; k < ng * 8u && ok; k += 64u) {
-            uint32_t sz = 1u << (a.groups[g0 + (k >> 3)] & 15u);
-            if ((k & 7u) < sz) {
-                float2 p = vparams[k];
+        uint32_t pair0 = 0;   // first parameter pair of the item
+        for (uint32_t i = 0; i < ni && ok; ++i) {
+            const uint32_t kk = a.groups[i0 + i] & 15u, sz = 1u << kk;
+            for (uint32_t q = lane; q < sz && ok; q += 64u) {
+                float2 p = vparams[pair0 + q];
                 ok = __float_as_uint(bank_leaf<false, true>(tz, p.x, p.y)) == 0x80000000u;
             }
+            ok = __all(ok);
+            pair0 += sz < 8u ? 8u : sz;
         }
-        bool all = __all(ok);
-        if (lane == 0) orow[bank_out_index(a, tz_i)] = all ? -0.0f : 0.0f;
+        if (lane == 0) orow[bank_out_index(a, tz_i)] = ok ? -0.0f : 0.0f;
     }
 }
 

@@ -63,8 +63,9 @@ struct BankArgs {
     uint32_t leaf_variant;     // 0 = product-form leaves; 1 = FMA-form leaves + zero-sign repair (same bits, faster)
     float *hist_dst;           // if non-null: the kernel also copies time[0..time_valid) here (input-history append)
     float *ws;                 // [P >> chunk_log2][n_voices][n_times] partial sums; unused when one chunk
-    // general voices (launch_gbank): params = [group][8]{w, -4*amp}; groups[g] = log2(size) | merges_after << 4;
-    // voice v owns groups [group_off[v], group_off[v+1])
+    // general voices (launch_gbank): groups[i] = log2(item leaves, <= 11) | merges_after << 4; params = the items'
+    // {w, -4*amp} pairs in order, items of < 8 leaves padded to 8 pairs; voice v owns items
+    // [group_off[2v], group_off[2v+2]) and its parameters start at pair 8 * group_off[2v+1]
     const uint32_t *groups;
     const uint32_t *group_off;
 };

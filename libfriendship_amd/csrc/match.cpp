@@ -122,8 +122,8 @@ struct Matcher {
 struct BankMatcher::Impl : Matcher {
     using Matcher::Matcher;
 
-    // height of the complete sub-tree of matched leaves rooted at n (0 = a leaf, up to 3 = 8 leaves), -1 if n is a
-    // Sum2 node that is not such a sub-tree, -2 if n is neither a leaf nor a Sum2 (not a voice at all)
+    // height of the complete sub-tree of matched leaves rooted at n (0 = a leaf, up to GENERAL_MAX_ITEM_LOG2 = 2048
+    // leaves), -1 if n is a Sum2 node that is not such a sub-tree, -2 if n is neither a leaf nor a Sum2 (not a voice)
     std::unordered_map<uint32_t, int> cj_memo;
     int complete_height(uint32_t id, uint64_t &budget) {
         auto it = cj_memo.find(id);
@@ -138,7 +138,7 @@ struct BankMatcher::Impl : Matcher {
         } else {
             int a = complete_height(n(id).a, budget), b = complete_height(n(id).b, budget);
             if (a == -2 || b == -2) r = -2;
-            else if (a >= 0 && a == b && a < 3) r = a + 1;
+            else if (a >= 0 && a == b && a < (int)GENERAL_MAX_ITEM_LOG2) r = a + 1;
             else r = -1;
         }
         cj_memo.emplace(id, r);
@@ -160,7 +160,7 @@ struct BankMatcher::Impl : Matcher {
         append_leaves(n(id).b, vm, first, ok);
     }
 
-    // post-order emission: complete sub-trees become groups, every other Sum2 node a merge after its right operand
+    // post-order emission: maximal complete sub-trees become items, every other Sum2 node a merge after its right operand
     bool emit_general(uint32_t root, VoiceMatch &vm) {
         uint64_t budget = 1u << 22;
         if (complete_height(root, budget) == -2) return false;
@@ -181,7 +181,7 @@ struct BankMatcher::Impl : Matcher {
             if (cj >= 0) {
                 size_t before = vm.params.size();
                 append_leaves(it.id, vm, first, ok);
-                vm.params.resize(before + 16, 0.0f);   // pad the group to 8 {w, A4} pairs
+                if (cj < 3) vm.params.resize(before + 16, 0.0f);   // a small item is padded to one group of 8 {w, A4} pairs
                 vm.groups.push_back((uint32_t)cj);
                 max_depth = std::max(max_depth, ++depth);
                 if (vm.groups.size() > (1u << 20)) return false;

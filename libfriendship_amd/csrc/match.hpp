@@ -14,8 +14,11 @@ namespace fr {
 // One recognised voice: a Sum2 tree over partial leaves.
 //   balanced (general == false): complete tree over 2^log2_p leaves; params = [P]{w, -4*amp}.
 //   general  (general == true):  any Sum2 tree (odd carries, unbalanced, non-power-of-two leaf counts), cut into
-//     groups = maximal complete sub-trees of 1, 2, 4 or 8 consecutive leaves, evaluated in post-order with a stack:
-//     groups[i] = log2(size) | merges_after << 4; params = [n_groups][8]{w, -4*amp}, unused entries zero.
+//     items = maximal complete sub-trees of 2^j <= 2048 consecutive leaves, evaluated in post-order with a stack:
+//     groups[i] = j | merges_after << 4; params = the items' {w, -4*amp} pairs in order, an item of fewer than 8
+//     leaves padded with zeros to 8 pairs (so every item starts on a group-of-8 boundary).
+constexpr uint32_t GENERAL_MAX_ITEM_LOG2 = 11;   // kernels.hip bank_wave_sum: at most 2^8 groups of 8 leaves
+
 struct VoiceMatch {
     uint32_t log2_p = 0;
     uint32_t input_slot = 0;        // external input slot read as `t`

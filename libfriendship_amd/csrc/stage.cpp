@@ -199,7 +199,7 @@ void add_voice(std::vector<BankLaunch> &banks, std::unordered_map<std::string, s
         gi = grp.emplace(key, banks.size()).first;
         BankLaunch bl;
         bl.log2_p = vm.log2_p; bl.input_slot = vm.input_slot; bl.to_ring = ring; bl.general = vm.general;
-        if (vm.general) bl.group_off.push_back(0);
+        if (vm.general) { bl.group_off.push_back(0); bl.group_off.push_back(0); }
         if (vm.jit) { bl.jit = true; bl.shape = vm.shape; bl.varying = vm.varying; bl.literal_bits = vm.literal_bits; bl.alias = vm.alias; bl.k = vm.k; }
         banks.push_back(std::move(bl));
     }
@@ -210,6 +210,7 @@ void add_voice(std::vector<BankLaunch> &banks, std::unordered_map<std::string, s
     if (vm.general) {
         bl.groups.insert(bl.groups.end(), vm.groups.begin(), vm.groups.end());
         bl.group_off.push_back((uint32_t)bl.groups.size());
+        bl.group_off.push_back((uint32_t)(bl.params.size() / 16));
         bl.max_leaves = std::max(bl.max_leaves, vm.n_leaves);
     }
 }

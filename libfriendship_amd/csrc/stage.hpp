@@ -21,7 +21,7 @@ struct BankLaunch {
     std::vector<float> params;       // balanced: [voices][P]{w, -4*amp}; general: [groups][8]{w, -4*amp}
     bool general = false;            // voices are arbitrary Sum2 trees evaluated by schedule (match.hpp VoiceMatch)
     std::vector<uint32_t> groups;    // general: group words of all voices, concatenated
-    std::vector<uint32_t> group_off; // general: [voices + 1] first group of each voice
+    std::vector<uint32_t> group_off; // general: [voices + 1][2] {first item, first parameter group of 8 pairs} of each voice
     uint32_t max_leaves = 0;
     // jit == true: leaves of an arbitrary common shape, kernel specialised with hipRTC (jit.hpp); params = [voices][P][k]
     bool jit = false;

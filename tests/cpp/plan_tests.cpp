@@ -160,17 +160,24 @@ static float bank_voice_host(const BankLaunch &bl, size_t v, float t) {
         return cur[0];
     }
     std::vector<float> st;
-    for (uint32_t g = bl.group_off[v]; g < bl.group_off[v + 1]; ++g) {
+    size_t pair0 = (size_t)bl.group_off[2 * v + 1] * 8;
+    for (uint32_t g = bl.group_off[2 * v]; g < bl.group_off[2 * v + 2]; ++g) {
         uint32_t j = bl.groups[g] & 15u, m = bl.groups[g] >> 4;
-        float l[8];
-        for (int k = 0; k < 8; ++k) l[k] = leaf_host(t, bl.params[((size_t)g * 8 + k) * 2], bl.params[((size_t)g * 8 + k) * 2 + 1]);
-        float val = l[0];
-        if (j >= 1) val = l[0] + l[1];
-        if (j >= 2) val = val + (l[2] + l[3]);
-        if (j >= 3) val = val + ((l[4] + l[5]) + (l[6] + l[7]));
+        CHECK(j <= GENERAL_MAX_ITEM_LOG2);
+        std::vector<float> cur((size_t)1 << j);                     // the item: a complete tree over 2^j leaves
+        for (size_t k = 0; k < cur.size(); ++k) cur[k] = leaf_host(t, bl.params[(pair0 + k) * 2], bl.params[(pair0 + k) * 2 + 1]);
+        for (size_t k = cur.size(); k < 8; ++k) CHECK(bl.params[(pair0 + k) * 2] == 0.0f && bl.params[(pair0 + k) * 2 + 1] == 0.0f);   // padding
+        pair0 += std::max<size_t>(cur.size(), 8);
+        while (cur.size() > 1) {
+            std::vector<float> nx(cur.size() / 2);
+            for (size_t i = 0; i < nx.size(); ++i) nx[i] = cur[2 * i] + cur[2 * i + 1];
+            cur = nx;
+        }
+        float val = cur[0];
         for (; m; --m) { val = st.back() + val; st.pop_back(); }
         st.push_back(val);
     }
+    if (v + 1 < bl.rows.size()) CHECK(pair0 == (size_t)bl.group_off[2 * v + 3] * 8);
     CHECK(st.size() == 1);
     return st[0];
 }
