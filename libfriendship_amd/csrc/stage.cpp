@@ -163,6 +163,38 @@ struct Planner {
         return true;
     }
 
+    // Splits the program region of cut node m (everything under m down to leaves, banks, Delays and other cut nodes)
+    // so that no piece has more than `limit` nodes counted as a tree (shared nodes with multiplicity: an over-estimate
+    // of the program's instruction count): whenever a node's count exceeds the limit its bigger operand becomes a cut.
+    void split_region(uint32_t m, uint64_t limit) {
+        std::unordered_map<uint32_t, uint64_t> size;
+        auto atomic = [&](uint32_t n) { return n != m && (is_leaf(n) || bank_of.count(n) || cut.count(n)); };
+        std::vector<std::pair<uint32_t, int>> st{{m, 0}};
+        while (!st.empty()) {
+            auto [n, state] = st.back();
+            st.pop_back();
+            if (size.count(n)) continue;
+            if (atomic(n)) { size[n] = 1; continue; }
+            const FlatNode &x = g.nodes[n];
+            const bool delay = x.op == OP_DELAY;
+            if (delay && !dyn_max.count(n)) { size[n] = 1; continue; }   // a ring / input read
+            if (state == 0) {
+                st.push_back({n, 1});
+                st.push_back({x.b, 0});
+                if (!delay) st.push_back({x.a, 0});                      // (a signal-amount Delay computes only its amount here)
+                continue;
+            }
+            for (;;) {
+                uint64_t sa = delay ? 0 : size[x.a], sb = size[x.b];
+                if (1 + sa + sb <= limit) { size[n] = 1 + sa + sb; break; }
+                uint32_t big = (!delay && sa >= sb) ? x.a : x.b;
+                if (size[big] <= 1) { size[n] = 1 + sa + sb; break; }    // both operands already atomic
+                cut.insert(big);
+                size[big] = 1;
+            }
+        }
+    }
+
     // marks banks and cut nodes under a root
     void explore(uint32_t root) {
         std::vector<uint32_t> st{root};
@@ -385,16 +417,30 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
     for (auto &kv : rows_of)
         if (!P.bank_of.count(kv.first)) P.cut.insert(kv.first);   // a root that is a leaf gets a trivial program too
 
-    // programs (cut node ids ascending == topological)
-    std::vector<uint32_t> cuts(P.cut.begin(), P.cut.end());
-    std::sort(cuts.begin(), cuts.end());
+    // programs (cut node ids ascending == topological).  An expression too big for one program (instructions or
+    // registers) is split: nodes inside it become extra cut nodes -- materialised in a ring, read back at the same
+    // frame -- until every piece fits; the levels below order them.
+    std::vector<uint32_t> cuts;
     std::unordered_map<uint32_t, uint32_t> dense_input;
     std::unordered_map<uint32_t, ProgBuild> built;
-    bool ok = true;
-    for (uint32_t m : cuts) {
-        ProgBuild pb;
-        if (!allow_programs || !build_program(g, P, m, dense_input, sp.input_slots, pb)) { ok = false; break; }
-        built.emplace(m, std::move(pb));
+    bool ok = allow_programs || P.cut.empty();
+    for (uint64_t limit = 1024; ok;) {
+        cuts.assign(P.cut.begin(), P.cut.end());
+        std::sort(cuts.begin(), cuts.end());
+        uint32_t failed = 0;
+        bool all = true;
+        for (uint32_t m : cuts) {
+            if (built.count(m)) continue;
+            ProgBuild pb;
+            if (!build_program(g, P, m, dense_input, sp.input_slots, pb)) { all = false; failed = m; break; }
+            built.emplace(m, std::move(pb));
+        }
+        if (all) break;
+        size_t before = P.cut.size();
+        P.split_region(failed, limit);
+        if (P.cut.size() == before) limit /= 2;    // nothing left to cut at this size: try smaller pieces
+        else built.clear();                        // programs that inlined a node that is now a cut read its ring instead
+        if (limit < 8) ok = false;
     }
     if (!ok) {
         // budget exceeded somewhere: keep only rows whose root is itself a bank (direct launches), pull the rest

@@ -911,6 +911,33 @@ static void value_ranges_are_sound() {
     CHECK(bounded_nodes > 500);
 }
 
+static void oversized_expressions_are_split() {
+    // one output whose expression is far beyond a single program (4096 instructions / 48 registers): a 3000-long
+    // accumulation chain over a wide tree of non-template terms, with shared sub-expressions and a Delay in the middle
+    std::mt19937 rng(31);
+    Build b;
+    std::vector<uint32_t> terms;
+    for (int i = 0; i < 700; ++i) {
+        uint32_t x = b.op(FR_PRIM_MULTIPLY, In(i % 2), Cf(0.001f * (float)(i + 1)));
+        uint32_t y = b.op(FR_PRIM_MODULO, N(x), Cf(1.0f + (float)(i % 5)));
+        uint32_t z = b.op(FR_PRIM_MINIMUM, N(y), N(b.op(FR_PRIM_DIVIDE, N(x), Cf(3.0f + (float)(i % 7)))));
+        terms.push_back(b.op(FR_PRIM_SUM2, N(z), N(y)));
+    }
+    uint32_t tree = sum_tree(b, terms);                       // ~700 * 5 + 699 nodes in one expression
+    uint32_t acc = tree;
+    for (int i = 0; i < 3000; ++i) {                          // left-deep chain re-using the terms
+        acc = b.op(i % 3 ? FR_PRIM_SUM2 : FR_PRIM_MINIMUM, N(acc), N(terms[(size_t)(rng() % terms.size())]));
+        if (i == 1500) acc = b.op(FR_PRIM_SUM2, N(acc), N(b.op(FR_PRIM_DELAY, N(acc), Cf(9.0f))));
+    }
+    b.out(N(acc), 0);
+    b.out(N(tree), 1);
+    check_graph(b, 2, 20, 3, true, "oversized expression", [](const FlatGraph &, const StagedPlan &sp) {
+        CHECK(sp.pull_rows.empty());                          // (before splitting existed both rows fell back to the pull interpreter)
+        CHECK(sp.progs.size() > 6);
+        for (const StageProg &pg : sp.progs) CHECK(pg.n_instr <= 4096);
+    });
+}
+
 int main(int argc, char **argv) {
     std::vector<std::pair<const char *, std::function<void()>>> tests = {
         {"lowering_folds_constants", lowering_folds_constants}, {"lowering_errors", lowering_errors},
@@ -920,7 +947,8 @@ int main(int argc, char **argv) {
         {"stage_programs_compile_to_source", stage_programs_compile_to_source},
         {"incremental_lowering_equals_from_scratch", incremental_lowering_equals_from_scratch},
         {"bounded_signal_delays_are_staged", bounded_signal_delays_are_staged},
-        {"value_ranges_are_sound", value_ranges_are_sound}};
+        {"value_ranges_are_sound", value_ranges_are_sound},
+        {"oversized_expressions_are_split", oversized_expressions_are_split}};
     int failed = 0, ran = 0;
     for (auto &t : tests) {
         if (argc > 1 && std::string(argv[1]) != t.first) continue;

@@ -51,4 +51,4 @@ def test_engine_host_logic_against_oracle(oracle_lib):
                         "-Wno-subobject-linkage", "-o", PLAN_BIN, PLAN_SRC, "-ldl"], check=True)
     env = dict(os.environ, FRIENDSHIP_ORACLE_LIB=oracle_lib.path)
     p = subprocess.run([PLAN_BIN], env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and "11 passed; 0 failed" in p.stdout, p.stdout + p.stderr
+    assert p.returncode == 0 and "12 passed; 0 failed" in p.stdout, p.stdout + p.stderr

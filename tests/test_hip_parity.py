@@ -485,6 +485,38 @@ def test_chorus_signal_delay_is_staged(hip_lib, oracle_lib, V, P, T, taps):
             assert same_bits(a, b), first_diff(a, b)
 
 
+def test_oversized_expression_is_split_not_pulled(hip_lib, oracle_lib):
+    """An output whose expression exceeds one stage program (4096 instructions / 48 registers) is cut into pieces that
+    hand values over through rings at the same frame; it used to send every non-bank row to the pull interpreter."""
+    g = synth.GraphArrays()
+    f = np.float32
+    n = 600
+    x = g.binop(synth.K_MUL, synth.IN(0), synth.C((0.001 * np.arange(1, n + 1)).astype(f)), n)
+    y = g.binop(synth.K_MOD, x, synth.C((1.0 + np.arange(n) % 5).astype(f)), n)
+    z = g.binop(synth.K_MIN, y, g.binop(synth.K_DIV, x, synth.C((3.0 + np.arange(n) % 7).astype(f)), n), n)
+    terms = g.binop(synth.K_SUM2, z, y, n)
+    tree = synth.sum_tree(g, terms.reshape(1, n))[0]
+    acc = np.array([tree], dtype=np.uint32)
+    rng = np.random.default_rng(5)
+    for i in range(2500):
+        acc = g.binop(synth.K_SUM2 if i % 3 else synth.K_MIN, acc, terms[rng.integers(n):][:1], 1)
+        if i == 1200:
+            acc = g.binop(synth.K_SUM2, acc, g.binop(synth.K_DELAY, acc, synth.C(f(9.0)), 1), 1)
+    g.edge(acc, 0, 0, 0)
+    g.edge(tree, 0, 0, 1)
+    tree_d = g.finish(2)
+    T = 40
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree_d)
+        synth.install(ref, tree_d)
+        for k in range(3):
+            rows = [synth.time_ramp(k * T, (k + 1) * T)]
+            got, exp = hip.fill_buffer(2, k * T, (k + 1) * T, rows), ref.fill_buffer(2, k * T, (k + 1) * T, rows)
+            assert same_bits(got, exp), f"call {k}: " + first_diff(got, exp)
+        plan = hip.plan()
+        assert plan["pull_rows"] == 0 and plan["stage_programs"] > 6, plan
+
+
 def test_graph_edit_rebuilds_delay_state(hip_lib, oracle_lib):
     """Edits between calls apply to ALL times evaluated afterwards, look-back included: the rings
     are rebuilt from the input history with the new graph."""
