@@ -29,9 +29,13 @@ def main():
                                               signal_delays=bool(seed % 3))
         T = int(rng.integers(1, 200))
         calls = [(0, T), (T, 2 * T), (2 * T, 3 * T), (int(rng.integers(4 * T, 10**6)), None)]
+        edit_after = {0, 2} if seed % 2 else set()          # odd seeds: graph edits between calls (incremental re-lowering)
         with Renderer(oracle) as ref:
             randgraph.install_steps(ref, steps)
             modes = {m: Renderer(hip, mode=m) for m in ("auto", "staged", "pull")}
+            os.environ["FR_STAGE_JIT"] = "force"          # read at renderer creation: every stage program through hipRTC
+            modes["staged+jit"] = Renderer(hip, mode="staged")
+            del os.environ["FR_STAGE_JIT"]
             for r in modes.values():
                 randgraph.install_steps(r, steps)
             for k, (s, e) in enumerate(calls):
@@ -57,11 +61,15 @@ def main():
                     if not same_bits(got, exp):
                         print(f"seed {seed} mode {m} call {k}: MISMATCH")
                         bad += 1
+                if k in edit_after:
+                    edits = randgraph.random_edits(rng, steps, int(rng.integers(1, 5)), signal_delays=bool(seed % 3))
+                    for r in list(modes.values()) + [ref]:
+                        randgraph.install_steps(r, edits)
             for r in modes.values():
                 r.close()
         if seed % 50 == 49:
             print(f"{seed + 1} graphs, {bad} problems", flush=True)
-    print(f"done: {n} graphs x 3 modes, {bad} problems")
+    print(f"done: {n} graphs x 4 modes, {bad} problems")
     return 1 if bad else 0
 
 
