@@ -60,6 +60,26 @@ struct DevBuf {
     template <class T> T *as() const { return (T *)p; }
 };
 
+// Page-locked host staging memory (DMA without the runtime's own bounce copies; async copies stay async).
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    void ensure(size_t n) {
+        if (n <= bytes) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = std::max(n, (size_t)4096);
+        HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        bytes = want;
+    }
+    template <class T> T *as() const { return (T *)p; }
+};
+
 // One external input slot's history on the device (reference.rs:25 `inputs[slot]`).
 struct InSlot {
     bool fed = false;        // ever received a row (otherwise implicit zeros)
@@ -117,7 +137,8 @@ struct fr_renderer {
     uint64_t head = 0;
     Plan plan;
     DevBuf d_out, d_in_table, d_stack_node, d_stack_time, d_stack_val, d_bank_ws;
-    std::vector<float> h_stage;
+    // host-buffer entry point: input rows go up through pinned staging (one region per row, no sync between rows)
+    PinnedBuf h_in_stage;
     bool timing = false;
     // A/B switches (environment, read at create; defaults are the measured best):
     uint32_t bank_leaf_variant = 1;      // FR_BANK_LEAF=0: product-form leaves (kernels.hpp BankArgs::leaf_variant)
@@ -237,6 +258,8 @@ struct fr_renderer {
                 throw Error(FR_ERR_INPUT_TOO_LONG, "input row " + std::to_string(r) + " longer than the range rendered");
         }
         if (rows > slots.size()) slots.resize(rows);
+        // (every host-buffer call ends with a stream synchronisation, so the staging buffer is idle here)
+        if (!device_rows && rows) h_in_stage.ensure((size_t)rows * n_times * sizeof(float));
         for (uint32_t r = 0; r < rows; ++r) {
             InSlot &s = slots[r];
             if (!s.fed) { s.fed = true; s.base = implicit_len(r); s.len = s.base; }
@@ -254,18 +277,18 @@ struct fr_renderer {
                     HIP_CHECK(launch_pad(dst + rl, n_times - rl, last, st));
                 }
             } else {
-                // host rows: build row + padding in a staging buffer, one H2D copy
+                // host rows: row + padding assembled in this row's region of the pinned staging buffer, one H2D copy,
+                // no sync (the region is not touched again before the call's final synchronisation)
                 float pad = 0.0f;
                 if (rl) pad = in_data[offs[r] + rl - 1];
                 else if (stored) {
                     HIP_CHECK(hipMemcpyAsync(&pad, dst - 1, sizeof(float), hipMemcpyDeviceToHost, st));
                     HIP_CHECK(hipStreamSynchronize(st));
                 }
-                h_stage.resize(n_times);
-                if (rl) std::memcpy(h_stage.data(), in_data + offs[r], rl * sizeof(float));
-                std::fill(h_stage.begin() + rl, h_stage.end(), pad);
-                HIP_CHECK(hipMemcpyAsync(dst, h_stage.data(), n_times * sizeof(float), hipMemcpyHostToDevice, st));
-                HIP_CHECK(hipStreamSynchronize(st));   // h_stage is reused by the next row
+                float *stage = h_in_stage.as<float>() + (size_t)r * n_times;
+                if (rl) std::memcpy(stage, in_data + offs[r], rl * sizeof(float));
+                std::fill(stage + rl, stage + n_times, pad);
+                HIP_CHECK(hipMemcpyAsync(dst, stage, n_times * sizeof(float), hipMemcpyHostToDevice, st));
             }
             s.len += n_times;
         }
@@ -730,6 +753,9 @@ fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t 
         hipStream_t st = r->stream;
         r->store_inputs(n_slots, n_times, idx, in_data, in_row_offsets, n_in_rows, false, st);
         size_t bytes = (size_t)n_slots * n_times * sizeof(float);
+        // (Rendering a long call as 2-4 sub-calls so that chunk c's D2H overlaps chunk c+1's kernels was tried: every
+        //  extra sub-call costs ~35 us of launch/sync overhead and smaller, less efficient launches -- 197 us became
+        //  231 / 242 / 277 us at 2 / 3 / 4 chunks for config C; profiles/r01_host_path.txt.)
         r->d_out.ensure(bytes);
         r->execute(r->d_out.as<float>(), n_slots, n_times, idx, st);
         if (bytes) HIP_CHECK(hipMemcpyAsync(out, r->d_out.p, bytes, hipMemcpyDeviceToHost, st));
