@@ -107,7 +107,8 @@ def run():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even with one rank and take the partial-shard exchange path (RCCL plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=48)
+    ap.add_argument("--cpu-frames", type=int, default=144,
+                    help="frames the CPU path renders single-threaded for cpu_baseline and the parity check (about 12 s)")
     args = ap.parse_args()
 
     import torch
