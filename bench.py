@@ -107,6 +107,9 @@ def run():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even with one rank and take the partial-shard exchange path (RCCL plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--short-blocks", action="store_true",
+                    help="after the timed region also time 64- and 512-frame calls (SURVEY.md 8d) -> `short_blocks`; off by "
+                         "default so that the default command launches only the timed workload's kernels (rocprof summaries)")
     ap.add_argument("--cpu-frames", type=int, default=144,
                     help="frames the CPU path renders single-threaded for cpu_baseline and the parity check (about 12 s)")
     args = ap.parse_args()
@@ -237,7 +240,7 @@ def run():
 
     # short blocks ("also report T in {64, 512}"): latency of one call through the device entry point
     short_blocks = None
-    if rank == 0 and world == 1 and elapsed / K < 5e-3:   # (not when a call takes milliseconds: pull-mode diagnostics)
+    if args.short_blocks and rank == 0 and world == 1 and elapsed / K < 5e-3:   # (not when a call takes milliseconds: pull-mode diagnostics)
         short_blocks = {}
         for tb in (64, 512):
             base = stripe0 + (n_calls + 8) * T

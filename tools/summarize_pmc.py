@@ -8,6 +8,7 @@ import json
 import sys
 
 src, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r01")
+outdir = sys.argv[3] if len(sys.argv) > 3 else "profiles"
 V, P, T = 64, 4096, 4800
 out = {}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
@@ -41,5 +42,5 @@ summ = {
         "clock_ghz_from_GRBM_GUI_ACTIVE": out["GRBM_GUI_ACTIVE"]["mean"] / 8 / avg_s / 1e9 if avg_s else None,
     },
 }
-json.dump(summ, open(f"profiles/{tag}_bank_pmc_summary.json", "w"), indent=1)
+json.dump(summ, open(f"{outdir}/{tag}_bank_pmc_summary.json", "w"), indent=1)
 print(json.dumps(summ["derived"], indent=1))
