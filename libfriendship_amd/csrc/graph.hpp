@@ -12,6 +12,7 @@
 // structurally identical sub-expressions have identical values at every t.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <deque>
 #include <memory>
@@ -160,14 +161,14 @@ public:
     // position of the top-level node it touched (| JOURNAL_NODE when the node itself was added, replaced or deleted).
     // `journal_overflow` means the journal does not describe every edit since it was cleared: lower from scratch.
     static constexpr uint32_t JOURNAL_NODE = 0x80000000u;
-    static constexpr size_t JOURNAL_LIMIT = 1u << 16;
+    static constexpr size_t JOURNAL_LIMIT = 1u << 16;   // (at least; see note())
     bool journal_on = false;
     bool journal_overflow = true;
     std::vector<uint32_t> journal;
 
 private:
-    void note(uint32_t entry) {
-        if (!journal_on || journal.size() >= JOURNAL_LIMIT) journal_overflow = true;
+    void note(uint32_t entry) {   // up to half the graph's size in edits is still cheaper to replay than to start over
+        if (!journal_on || journal.size() >= std::max<size_t>(JOURNAL_LIMIT, nodes.size() / 2)) journal_overflow = true;
         else journal.push_back(entry);
     }
     std::shared_ptr<const SubGraph> intern(const fr_effect *e, int depth);

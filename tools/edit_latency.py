@@ -54,6 +54,24 @@ def main():
             t_edit = (time.perf_counter() - t0) * 1e3
             e[row, 2] = new
             after.append((t_edit, call(), r.plan()))
+        # note-on: a whole new voice (P partials, ~12 P nodes and ~22 P edges) arrives between two calls
+        note_on = []
+        for i in range(3):
+            g = synth.GraphArrays()
+            g.next = int(tree["handles"].max()) + 1 + i * 16 * P
+            vp = synth.voice_params(1, P, 0x5EED0100 + i)
+            root = synth.sum_tree(g, synth.partial_leaves(g, vp["w"], vp["amp"]).reshape(1, P))
+            g.edge(root, 0, 0, V + i)
+            extra = g.finish(V + i + 1)
+            extra["handles"], extra["kinds"] = extra["handles"][1:], extra["kinds"][1:]   # the constant node exists already
+            t0 = time.perf_counter()
+            synth.install(r, extra)
+            t_msgs = (time.perf_counter() - t0) * 1e3
+            tt = synth.time_ramp(idx, idx + T)
+            t0 = time.perf_counter()
+            r.fill_buffer(V + i + 1, idx, idx + T, [tt])
+            idx += T
+            note_on.append((t_msgs, (time.perf_counter() - t0) * 1e3, r.plan()))
         print(f"{a.tree} tree {V} x {P}, {T} frames per call (host-buffer API)")
         print(f"  install (mirror build)        {t_install * 1e3:9.1f} ms")
         print(f"  first call (lower+plan+run)   {first:9.1f} ms   lower {plan['lower_ms']:.1f} ms, build {plan['build_ms']:.1f} ms")
@@ -61,6 +79,9 @@ def main():
         for t_edit, ms, p in after:
             print(f"  call after an edit            {ms:9.3f} ms   edit msgs {t_edit:.3f} ms, {p['lowering']}, "
                   f"{p['relowered_nodes']} nodes re-lowered, build {p['build_ms']:.2f} ms")
+        for t_msgs, ms, p in note_on:
+            print(f"  call after a note-on          {ms:9.3f} ms   a {P}-partial voice added: batch messages {t_msgs:.1f} ms, {p['lowering']}, "
+                  f"{p['relowered_nodes']} nodes lowered, build {p['build_ms']:.2f} ms")
 
 
 if __name__ == "__main__":

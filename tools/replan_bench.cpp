@@ -102,6 +102,45 @@ int main(int argc, char **argv) {
                     rep ? "edit" : "build", rep, low.last_was_full() ? "full" : "incremental", t_lower, (unsigned long long)low.last_relowered(),
                     fg.nodes.size(), t_plan, sp.banks.size(), pbytes);
     }
+    for (int rep = 0; rep < 4 && effects; ++rep) {   // note-on: a plain voice added as a new output slot
+        std::vector<uint32_t> cur;
+        for (uint32_t k = 0; k < P; ++k) {
+            float w = 61.0f * (k + 1) / 48000.0f * (1.0f + 0.01f * rep), amp = 1.0f / (k + 1);
+            uint32_t x = node(FR_PRIM_MULTIPLY); m.add_edge({0, x, 0, 0}); cst(x, w, 1);
+            uint32_t ph = node(FR_PRIM_MODULO); m.add_edge({x, ph, 0, 0}); cst(ph, 1.0f, 1);
+            uint32_t u = node(FR_PRIM_SUM2); m.add_edge({ph, u, 0, 0}); cst(u, -0.5f, 1);
+            uint32_t nu = node(FR_PRIM_MULTIPLY); cst(nu, -1.0f, 0); m.add_edge({u, nu, 0, 1});
+            uint32_t mn = node(FR_PRIM_MINIMUM); m.add_edge({u, mn, 0, 0}); m.add_edge({nu, mn, 0, 1});
+            uint32_t ab = node(FR_PRIM_MULTIPLY); cst(ab, -1.0f, 0); m.add_edge({mn, ab, 0, 1});
+            uint32_t n1 = node(FR_PRIM_MULTIPLY); cst(n1, -1.0f, 0); m.add_edge({ab, n1, 0, 1});
+            uint32_t q = node(FR_PRIM_SUM2); cst(q, 0.5f, 0); m.add_edge({n1, q, 0, 1});
+            uint32_t p16 = node(FR_PRIM_MULTIPLY); cst(p16, -16.0f, 0); m.add_edge({u, p16, 0, 1});
+            uint32_t y = node(FR_PRIM_MULTIPLY); m.add_edge({p16, y, 0, 0}); m.add_edge({q, y, 0, 1});
+            uint32_t leaf = node(FR_PRIM_MULTIPLY); cst(leaf, amp, 0); m.add_edge({y, leaf, 0, 1});
+            cur.push_back(leaf);
+        }
+        while (cur.size() > 1) {
+            std::vector<uint32_t> nxt;
+            for (size_t i = 0; i + 1 < cur.size(); i += 2) {
+                uint32_t s = node(FR_PRIM_SUM2);
+                m.add_edge({cur[i], s, 0, 0}); m.add_edge({cur[i + 1], s, 0, 1});
+                nxt.push_back(s);
+            }
+            cur = nxt;
+        }
+        m.add_edge({cur[0], 0, 0, V + rep});
+        auto t1 = Clock::now();
+        const FlatGraph &fg = low.update(m, V + rep + 1);
+        double t_lower = ms(t1);
+        auto t2 = Clock::now();
+        StagedPlan sp = plan_stages(fg, true, true, 20, false, true, matcher.get());
+        double t_plan = ms(t2);
+        StageJitPlan sj;
+        bool jit = plan_stage_jit(sp.progs, sp.instrs, 32, false, sj);
+        std::printf("note-on %d: lowering %s %.2f ms (%llu nodes), plan_stages %.2f ms, %zu banks, %zu programs, jit %d shapes %u source hash %zx\n", rep,
+                    low.last_was_full() ? "full" : "incremental", t_lower, (unsigned long long)low.last_relowered(), t_plan, sp.banks.size(),
+                    sp.progs.size(), (int)jit, sj.n_shapes, std::hash<std::string>{}(sj.source));
+    }
     {   // reference point: the same edit with from-scratch lowering and matching
         auto t1 = Clock::now();
         FlatGraph fg = lower(m, V);
