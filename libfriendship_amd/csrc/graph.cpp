@@ -473,8 +473,9 @@ struct Lowering::Impl {
 
     // journal == nullptr: from scratch
     const FlatGraph &update(const Mirror &mm, uint32_t n_slots, const std::vector<uint32_t> *journal) {
-        const bool garbage = fg.nodes.size() > 2 * base_nodes + (1u << 16) || ctxs.size() > 2 * base_ctxs + (1u << 16) ||
-                             cells.size() > 2 * base_cells + (1u << 20);
+        // superseded nodes cost memory only (32 B each with their hash-table entry), a rebuild costs a stall: be generous
+        const bool garbage = fg.nodes.size() > 8 * base_nodes + (1u << 20) || ctxs.size() > 8 * base_ctxs + (1u << 16) ||
+                             cells.size() > 8 * base_cells + (1u << 22);
         const bool full = !valid || m != &mm || !journal || garbage;
         relowered = 0;
         was_full = full;

@@ -216,7 +216,7 @@ private:
 // it (and which composite instances' inbound edges were followed to reach it), an edit invalidates the touched node
 // and, transitively, its readers, and evaluation of the outputs recomputes exactly those.  The FlatGraph is
 // append-only and hash-consed, so an unchanged sub-expression keeps its id across updates (plans cache per id);
-// superseded nodes stay behind as garbage until it outweighs the live graph, then everything is rebuilt.
+// superseded nodes stay behind as garbage until they outnumber the live graph 8:1, then everything is rebuilt.
 class Mirror;
 struct FlatGraph;
 FlatGraph lower(const Mirror &m, uint32_t n_slots);
