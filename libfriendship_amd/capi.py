@@ -79,6 +79,7 @@ class Effect:
 
     def __init__(self, kind, nodes=(), edges=()):
         self.kind = kind
+        self._nodes = [(int(h), e) for h, e in nodes]
         self._children = [e for _, e in nodes]
         self.c = fr_effect()
         self.c.kind = kind
@@ -103,6 +104,13 @@ class Effect:
     def graph(cls, nodes, edges):
         """nodes: [(handle, Effect)], edges: [(from, to, from_slot, to_slot)] -- an AdjList (adjlist.rs:11-15)."""
         return cls(FR_EFFECT_GRAPH, list(nodes), list(edges))
+
+    def to_json(self):
+        """Inverse of from_json (fixture form)."""
+        if self.kind != FR_EFFECT_GRAPH:
+            return PRIMITIVES[self.kind]
+        return {"graph": {"nodes": [[h, e.to_json()] for h, e in self._nodes],
+                          "edges": [[int(x) for x in row] for row in self._edges]}}
 
     @classmethod
     def from_json(cls, spec):

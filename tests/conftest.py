@@ -41,3 +41,10 @@ def hip_lib():
 def kat():
     with open(os.path.join(ROOT, "tests", "golden", "reference_kat.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def selfcheck():
+    """Self-consistency vectors (rendered by the oracle when they were made; NOT reference outputs)."""
+    with open(os.path.join(ROOT, "tests", "golden", "selfcheck_vectors.json")) as f:
+        return json.load(f)

@@ -32,8 +32,15 @@ def replay(rlib, test, mode="auto"):
                 r.on_add_edge(st["from"], st["to"], st["from_slot"], st["to_slot"])
             elif op == "del_edge":
                 r.on_del_edge(st["from"], st["to"], st["from_slot"], st["to_slot"])
+            elif op == "synth_tree":   # one of the repository's seeded synthetic configurations
+                from libfriendship_amd import synth
+                assert st["kind"] == "additive"
+                synth.install(r, synth.additive_tree(st["voices"], st["partials"]))
             elif op == "render":
-                got = r.fill_buffer(st["n_slots"], st["range"][0], st["range"][1], bits_to_f32(st["inputs_bits"]))
+                rows = bits_to_f32(st["inputs_bits"])
+                if st.get("time_ramp_row0"):   # row 0 = the f32 frame ramp of the range (not stored)
+                    rows = [np.arange(st["range"][0], st["range"][1], dtype=np.float64).astype(np.float32)] + rows
+                got = r.fill_buffer(st["n_slots"], st["range"][0], st["range"][1], rows)
                 out.append((st, got))
             else:
                 raise ValueError(op)
@@ -42,5 +49,7 @@ def replay(rlib, test, mode="auto"):
 
 def check(rlib, test, mode="auto"):
     for st, got in replay(rlib, test, mode):
+        if "expect_cols" in st:   # long renders keep only some column ranges of the expected output
+            got = np.concatenate([got[:, a:b] for a, b in st["expect_cols"]], axis=1)
         exp = np.array(st["expect_bits"], dtype=np.uint32).view(np.float32).reshape(got.shape)
         assert same_bits(got, exp), f"{test['name']} ({st.get('ref')}): got {got.tolist()} expected {exp.tolist()}"

@@ -33,6 +33,13 @@ def test_reference_kat_on_hip(hip_lib, kat, i, mode):
 
 
 # ---- random graphs of all seven primitives ---------------------------------------------------------
+@pytest.mark.parametrize("mode", ["auto", "pull", "staged"])
+@pytest.mark.parametrize("i", range(14))
+def test_selfcheck_vectors_on_hip(hip_lib, selfcheck, i, mode):
+    """The committed self-consistency vectors (tests/golden/selfcheck_vectors.json) through the HIP engine."""
+    kat_replay.check(hip_lib, selfcheck["tests"][i], mode=mode)
+
+
 @pytest.mark.parametrize("mode", ["pull", "auto"])
 @pytest.mark.parametrize("seed", range(24))
 def test_random_graphs(hip_lib, oracle_lib, seed, mode):
