@@ -505,6 +505,7 @@ struct fr_renderer {
                 j.log2_p = a.log2_p;
                 j.tiles = (uint32_t)((blen + 63) / 64);
                 j.nblocks = j.tiles * j.n_voices;
+                j.fract_ok = bs.grp.fast_ok ? 1u : 0u;
                 Scope sc(this, &t_bank, st);
                 HIP_CHECK(launch_jit_bank(*bs.jit, j, st));
                 sc.done();

@@ -35,20 +35,9 @@ __device__ __forceinline__ float jit_min(float a, float b) {   // Rust >= 1.20 f
 
 LEAF_FUNCTION
 
-extern "C" __global__ void __launch_bounds__(256) jit_bank(JitBankArgs a) {
-    unsigned b = blockIdx.x;
-    unsigned lid = (a.nblocks % 8u == 0u) ? (b % 8u) * (a.nblocks / 8u) + b / 8u : b;   // XCD-contiguous work ranges
-    const unsigned voice = lid / a.tiles, tile = lid - voice * a.tiles;
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned long long ti = (unsigned long long)tile * 64u + lane;
-    float x[NIN > 0 ? NIN : 1];
-#pragma unroll
-    for (int i = 0; i < NIN; ++i)
-        x[i] = (ti >= a.in_skip[i] && ti - a.in_skip[i] < a.in_valid[i]) ? a.in[i][ti - a.in_skip[i]] : 0.0f;
-
-    const unsigned P = 1u << a.log2_p, Pw = P >> 2, ngroups = Pw >> 3, levels = a.log2_p - 5u;
-    cptr p = (cptr)(a.params + ((size_t)voice * P + (size_t)wave * Pw) * K);
+// one wave's share of a voice: Pw leaves in groups of 8, group sums merged by the binary-counter carry chain
+template <bool FAST>
+__device__ __forceinline__ float wave_sum(cptr p, const float *x, unsigned ngroups, unsigned levels) {
     float s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0, s8 = 0;
     for (unsigned g = 0; g < ngroups; ++g) {
         float c[8 * K];
@@ -73,6 +62,35 @@ extern "C" __global__ void __launch_bounds__(256) jit_bank(JitBankArgs a) {
     float r = s8;
     r = levels == 7u ? s7 : r; r = levels == 6u ? s6 : r; r = levels == 5u ? s5 : r; r = levels == 4u ? s4 : r;
     r = levels == 3u ? s3 : r; r = levels == 2u ? s2 : r; r = levels == 1u ? s1 : r; r = levels == 0u ? s0 : r;
+    return r;
+}
+
+extern "C" __global__ void __launch_bounds__(256) jit_bank(JitBankArgs a) {
+    unsigned b = blockIdx.x;
+    unsigned lid = (a.nblocks % 8u == 0u) ? (b % 8u) * (a.nblocks / 8u) + b / 8u : b;   // XCD-contiguous work ranges
+    const unsigned voice = lid / a.tiles, tile = lid - voice * a.tiles;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long ti = (unsigned long long)tile * 64u + lane;
+    float x[NIN > 0 ? NIN : 1];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i)
+        x[i] = (ti >= a.in_skip[i] && ti - a.in_skip[i] < a.in_valid[i]) ? a.in[i][ti - a.in_skip[i]] : 0.0f;
+
+    const unsigned P = 1u << a.log2_p, Pw = P >> 2, ngroups = Pw >> 3, levels = a.log2_p - 5u;
+    cptr p = (cptr)(a.params + ((size_t)voice * P + (size_t)wave * Pw) * K);
+    float r;
+#if HAS_MOD1
+    // the body with Modulo(x, 1.0) as v_fract_f32 is exact when the host proved it for inputs in [+0, 2^32]
+    // (a.fract_ok) and this wave's inputs are in that range
+    bool in_range = a.fract_ok != 0u;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i)
+        if ((FRACT_INPUTS >> i) & 1u) in_range = in_range && __builtin_bit_cast(unsigned, x[i]) <= 0x4F800000u;
+    if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) r = wave_sum<true>(p, x, ngroups, levels);
+    else
+#endif
+        r = wave_sum<false>(p, x, ngroups, levels);
 
     __shared__ float sm[4][64];
     sm[wave][lane] = r;
@@ -92,7 +110,10 @@ std::string JitCache::generate_source(const LeafShape &shape, const std::vector<
     std::vector<int> pidx(shape.n_consts, -1);
     for (uint32_t c = 0; c < shape.n_consts; ++c)
         if (varying[c]) pidx[c] = alias[c] == c ? (int)k++ : pidx[alias[c]];
-    leaf << "__device__ __forceinline__ float leaf(const float *x";
+    bool has_mod1 = false;
+    uint32_t fract_inputs = 0;                       // inputs the argument of some Modulo(x, 1.0) depends on
+    std::vector<uint32_t> dep(shape.ops.size(), 0);  // per op: mask of the inputs it depends on
+    leaf << "template <bool FAST>\n__device__ __forceinline__ float leaf(const float *x";
     for (uint32_t i = 0; i < (k ? k : 1); ++i) leaf << ", float p" << i;
     leaf << ") {\n    (void)x; (void)p0;\n";
     for (size_t i = 0; i < shape.ops.size(); ++i) {
@@ -104,30 +125,36 @@ std::string JitCache::generate_source(const LeafShape &shape, const std::vector<
             if (varying[o.a]) leaf << "p" << pidx[o.a];
             else { std::snprintf(buf, sizeof buf, "__builtin_bit_cast(float, 0x%08xu)", literal_bits[o.a]); leaf << buf; }
             break;
-        case OP_INPUT: leaf << "x[" << o.a << "]"; break;
+        case OP_INPUT: leaf << "x[" << o.a << "]"; dep[i] = 1u << o.a; break;
         case OP_SUM2: leaf << "v" << o.a << " + v" << o.b; break;
         case OP_MUL: leaf << "v" << o.a << " * v" << o.b; break;
         case OP_DIV: leaf << "v" << o.a << " / v" << o.b; break;
         case OP_MOD: {   // a literal divisor of exactly 1.0 (every oscillator's phase wrap) avoids the generic fmodf routine
             const LeafShape::Op &d = shape.ops[o.b];
-            if (d.op == OP_CONST && !varying[d.a] && literal_bits[d.a] == 0x3F800000u) leaf << "jit_mod1(v" << o.a << ")";
+            if (d.op == OP_CONST && !varying[d.a] && literal_bits[d.a] == 0x3F800000u) {
+                leaf << "(FAST ? __builtin_amdgcn_fractf(v" << o.a << ") : jit_mod1(v" << o.a << "))";
+                has_mod1 = true;
+                fract_inputs |= dep[o.a];
+            }
             else leaf << "jit_mod(v" << o.a << ", v" << o.b << ")";
             break;
         }
         default: leaf << "jit_min(v" << o.a << ", v" << o.b << ")"; break;
         }
         leaf << ";\n";
+        if (o.op != OP_CONST && o.op != OP_INPUT) dep[i] = dep[o.a] | dep[o.b];
     }
     leaf << "    return v" << shape.ops.size() - 1 << ";\n}\n";
     const uint32_t K = k ? k : 1;
     std::ostringstream call;
-    call << "leaf(x";
+    call << "leaf<FAST>(x";
     for (uint32_t i = 0; i < K; ++i) call << ", c[(j) * K + " << i << "]";
     call << ")";
     std::ostringstream src;
     src << "#pragma clang fp contract(off)\n";
     src << FR_STR(FR_JIT_ARGS_TEXT) << "\n";
-    src << "#define K " << K << "\n#define NIN " << shape.input_slots.size() << "\n";
+    src << "#define K " << K << "\n#define NIN " << shape.input_slots.size() << "\n#define HAS_MOD1 " << (has_mod1 ? 1 : 0)
+        << "\n#define FRACT_INPUTS " << fract_inputs << "u\n";
     src << "#define LEAF_CALL(j) " << call.str() << "\n";
     std::string body = kSkeleton;
     const std::string tag = "LEAF_FUNCTION";

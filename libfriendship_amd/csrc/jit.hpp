@@ -45,6 +45,7 @@ namespace fr {
         unsigned int log2_p;                                                                                   \
         unsigned int tiles;                                                                                    \
         unsigned int nblocks;                                                                                  \
+        unsigned int fract_ok;          /* host-proved: Modulo(x, 1) == fract(x) for inputs in [+0, 2^32] */   \
     };
 FR_JIT_ARGS_TEXT
 

@@ -15,6 +15,8 @@
 // mismatch costs speed, never correctness.
 #include "match.hpp"
 
+#include "range.hpp"
+
 #include <algorithm>
 #include <cmath>
 #include <functional>
@@ -331,7 +333,58 @@ struct BankMatcher::Impl : Matcher {
         vm.jit = true;
         vm.log2_p = h;
         vm.n_leaves = (uint32_t)leaves.size();
+        vm.fast_ok = fract_form_is_exact(vm, all, first);
         return true;
+    }
+
+    // The generated kernel has a second body in which Modulo(x, 1.0) is one v_fract_f32 (x - floor(x)); that equals the
+    // graph's fmod-based value exactly when x is finite and >= +0.  Decide here whether that holds for EVERY such
+    // Modulo of the leaf whenever the inputs are in [+0, 2^32] (the kernel tests the inputs per wave): interval
+    // arithmetic for finiteness, a sign rule for "never negative, never -0".
+    bool fract_form_is_exact(const VoiceMatch &vm, const std::vector<uint32_t> &all, const std::vector<uint32_t> &first) const {
+        const uint32_t nc = vm.shape.n_consts;
+        const size_t n_leaves = nc ? all.size() / nc : 0;
+        struct Val { Range r; bool nonneg; };
+        std::vector<Val> col(nc);
+        for (uint32_t c = 0; c < nc; ++c) {
+            if (!vm.varying[c]) {
+                float f = f32_from_bits(first[c]);
+                col[c] = Val{Range::exactly(f), !(first[c] >> 31) && f == f};
+                continue;
+            }
+            double lo = HUGE_VAL, hi = -HUGE_VAL;
+            bool nan = false, nonneg = true;
+            for (size_t i = 0; i < n_leaves; ++i) {
+                uint32_t bits = all[i * nc + c];
+                float f = f32_from_bits(bits);
+                if (f != f) { nan = true; continue; }
+                lo = std::min(lo, (double)f);
+                hi = std::max(hi, (double)f);
+                nonneg = nonneg && !(bits >> 31);
+            }
+            col[c] = Val{Range{lo, hi, nan}, nonneg && !nan};
+        }
+        std::vector<Val> val(vm.shape.ops.size());
+        bool any = false;
+        for (size_t i = 0; i < vm.shape.ops.size(); ++i) {
+            const LeafShape::Op &o = vm.shape.ops[i];
+            if (o.op == OP_CONST) { val[i] = col[o.a]; continue; }
+            if (o.op == OP_INPUT) { val[i] = Val{Range{0.0, 4294967296.0, false}, true}; continue; }
+            const Val &a = val[o.a], &b = val[o.b];
+            bool nonneg;
+            switch (o.op) {
+            case OP_SUM2: case OP_MUL: case OP_MIN: nonneg = a.nonneg && b.nonneg; break;
+            case OP_DIV: nonneg = a.nonneg && b.nonneg && b.r.lo > 0.0; break;
+            default: nonneg = a.nonneg && b.r.lo > 0.0 && !b.r.nan; break;   // OP_MOD: fmod keeps the dividend's sign
+            }
+            val[i] = Val{Range::combine(o.op, a.r, b.r), nonneg};
+            const LeafShape::Op &d = vm.shape.ops[o.b];
+            if (o.op == OP_MOD && d.op == OP_CONST && !vm.varying[d.a] && first[d.a] == 0x3F800000u) {
+                any = true;
+                if (!(a.nonneg && !a.r.nan && a.r.hi <= 3.0e38)) return false;
+            }
+        }
+        return any;
     }
 };
 

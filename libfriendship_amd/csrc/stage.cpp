@@ -12,6 +12,8 @@
 // delays of 2^31 frames or more, programs that outgrow the register/instruction budget.
 #include "stage.hpp"
 
+#include "range.hpp"
+
 #include <algorithm>
 #include <cmath>
 #include <memory>
@@ -49,49 +51,10 @@ struct Planner {
     // frame offset per sample.  Bounds come from interval arithmetic over the amount's expression (doubles, widened
     // outward after every step so that f32 rounding cannot escape them).  `nan` = the value may also be NaN (which
     // as a delay amount means 0 frames, reference.rs:206-211).  Infinite bounds make everything downstream unbounded.
-    struct Range { double lo, hi; bool nan; };
+    using Range = fr::Range;
     std::unordered_map<uint32_t, Range> range_memo;
     std::unordered_map<uint32_t, uint64_t> dyn_max;   // Delay node with a signal amount -> bound on the delay in frames
 
-    static Range unbounded() { return Range{-HUGE_VAL, HUGE_VAL, true}; }
-    static bool finite(const Range &r) { return std::isfinite(r.lo) && std::isfinite(r.hi); }
-    static Range widened(double lo, double hi, bool nan) {
-        if (std::isnan(lo) || std::isnan(hi)) return unbounded();
-        const double FMAX = 3.4028234663852886e38;
-        lo -= std::fabs(lo) * 1e-6 + 1e-30;
-        hi += std::fabs(hi) * 1e-6 + 1e-30;
-        if (lo < -FMAX) lo = -HUGE_VAL;
-        if (hi > FMAX) hi = HUGE_VAL;
-        return Range{lo, hi, nan};
-    }
-    static Range combine(uint32_t op, const Range &a, const Range &b) {
-        const bool nan = a.nan || b.nan;
-        switch (op) {
-        case OP_SUM2:
-            if (!finite(a) || !finite(b)) return unbounded();
-            return widened(a.lo + b.lo, a.hi + b.hi, nan);
-        case OP_MUL: {
-            if (!finite(a) || !finite(b)) return unbounded();
-            double p[4] = {a.lo * b.lo, a.lo * b.hi, a.hi * b.lo, a.hi * b.hi};
-            return widened(*std::min_element(p, p + 4), *std::max_element(p, p + 4), nan);
-        }
-        case OP_DIV: {
-            if (!finite(a) || !finite(b) || (b.lo <= 0.0 && b.hi >= 0.0)) return unbounded();
-            double q[4] = {a.lo / b.lo, a.lo / b.hi, a.hi / b.lo, a.hi / b.hi};
-            return widened(*std::min_element(q, q + 4), *std::max_element(q, q + 4), nan);
-        }
-        case OP_MOD: {   // rem = fmod(a, b); rem < 0 ? rem + b : rem.  Any dividend (inf, NaN give NaN); |rem| < |b|
-            if (!finite(b)) return unbounded();
-            if (b.lo > 0.0) return widened(0.0, b.hi, true);              // [0, b] (the sum can round up to b itself)
-            const double B = std::max(std::fabs(b.lo), std::fabs(b.hi));
-            return widened(-2.0 * B, B, true);                            // a non-positive divisor: (-2|b|, |b|)
-        }
-        default: {        // Minimum = (a < b || isnan(b)) ? a : b: NaN only if both are; a NaN on one side selects the other side
-            double hi = (!a.nan && !b.nan) ? std::min(a.hi, b.hi) : !a.nan ? a.hi : !b.nan ? b.hi : std::max(a.hi, b.hi);
-            return Range{std::min(a.lo, b.lo), hi, a.nan && b.nan};
-        }
-        }
-    }
     Range range(uint32_t root) {
         std::vector<uint32_t> st{root};
         while (!st.empty()) {
@@ -100,11 +63,11 @@ struct Planner {
             const FlatNode &x = g.nodes[n];
             if (x.op == OP_CONST) {
                 float c = g.const_val(n);
-                range_memo[n] = c != c ? Range{0.0, 0.0, true} : Range{(double)c, (double)c, false};
+                range_memo[n] = Range::exactly(c);
                 st.pop_back();
                 continue;
             }
-            if (x.op == OP_INPUT) { range_memo[n] = unbounded(); st.pop_back(); continue; }
+            if (x.op == OP_INPUT) { range_memo[n] = Range::unbounded(); st.pop_back(); continue; }
             bool need_a = !range_memo.count(x.a);
             bool need_b = x.op != OP_DELAY && !range_memo.count(x.b);
             if (need_a) st.push_back(x.a);
@@ -114,7 +77,7 @@ struct Planner {
                 Range s = range_memo[x.a];
                 range_memo[n] = Range{std::min(s.lo, 0.0), std::max(s.hi, 0.0), s.nan};
             } else {
-                range_memo[n] = combine(x.op, range_memo[x.a], range_memo[x.b]);
+                range_memo[n] = Range::combine(x.op, range_memo[x.a], range_memo[x.b]);
             }
             st.pop_back();
         }

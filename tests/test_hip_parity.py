@@ -735,6 +735,43 @@ def test_jit_specialised_voices(hip_lib, oracle_lib, V, P, T, am, delayed):
         assert sum(b["voices"] for b in jb) == V and all(b["partials"] == P and b["leaf_params"] == 2 for b in jb), plan
 
 
+def test_jit_voices_unusual_time_inputs(hip_lib, oracle_lib):
+    """Generated leaves have two kernel bodies: Modulo(x, 1.0) as one v_fract_f32 when the host proved the argument
+    finite and >= +0 for inputs in [+0, 2^32] AND the wave's inputs are in that range, the fmod form otherwise.
+    Negative, fractional, huge, NaN/inf and -0.0 times must take the second body; same bits either way."""
+    rng = np.random.default_rng(7)
+    rows = [
+        synth.time_ramp(0, 200),                                      # in range: fract body
+        (-synth.time_ramp(0, 200)),                                   # negative times
+        (rng.normal(size=200) * 1000).astype(np.float32),             # mixed sign inside one wave
+        np.array([0, 1, 2, np.nan, np.inf, -np.inf, 1e30, 3e38, 1e-30, -0.0] * 20, dtype=np.float32),
+        np.array([4294967296.0, 4294967808.0, 16777216.0, 0.5] * 50, dtype=np.float32),   # at and just above 2^32
+    ]
+    for am in (False, True):
+        tree = _triangle_tree(2, 64, am, False)
+        with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+            synth.install(hip, tree)
+            synth.install(ref, tree)
+            for i, row in enumerate(rows):
+                ins = [row, (rng.normal(size=200) * 2).astype(np.float32)]
+                got = hip.fill_buffer(2, i * 200, (i + 1) * 200, ins)
+                exp = ref.fill_buffer(2, i * 200, (i + 1) * 200, ins)
+                assert same_bits(got, exp), f"am={am} row {i}: " + first_diff(got, exp)
+            assert any(b["jit"] for b in hip.plan()["banks"])
+    # negative frequencies: the host cannot prove the argument non-negative, the fmod body runs for every wave
+    g = synth.GraphArrays()
+    w = (np.linspace(-0.01, 0.02, 128)).astype(np.float32).reshape(2, 64)
+    leaves = synth.triangle_leaves(g, w, np.ones_like(w)).reshape(2, 64)
+    g.edge(synth.sum_tree(g, leaves), 0, 0, np.arange(2, dtype=np.uint32))
+    tree = g.finish(2)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        t = synth.time_ramp(0, 300)
+        assert same_bits(hip.fill_buffer(2, 0, 300, [t]), ref.fill_buffer(2, 0, 300, [t]))
+        assert any(b["jit"] for b in hip.plan()["banks"])
+
+
 def test_jit_disabled_gives_the_same_bits(hip_lib, monkeypatch):
     """FR_JIT=0: the same voices run as stage programs / pull instead of a specialised kernel; identical output."""
     tree = _triangle_tree(2, 32, am=True)
