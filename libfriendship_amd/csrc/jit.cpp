@@ -5,6 +5,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <sstream>
 
@@ -113,6 +114,23 @@ std::string JitCache::generate_source(const LeafShape &shape, const std::vector<
     bool has_mod1 = false;
     uint32_t fract_inputs = 0;                       // inputs the argument of some Modulo(x, 1.0) depends on
     std::vector<uint32_t> dep(shape.ops.size(), 0);  // per op: mask of the inputs it depends on
+    // maybe_negzero[i]: can op i evaluate to -0.0?  (conservative; a sum is -0 only if both terms are)
+    std::vector<bool> maybe_negzero(shape.ops.size(), true);
+    // structural equality of two sub-expressions of the tree form (constants: same literal, or the same parameter)
+    std::function<bool(uint32_t, uint32_t)> same_expr = [&](uint32_t i, uint32_t j) -> bool {
+        const LeafShape::Op &a = shape.ops[i], &b = shape.ops[j];
+        if (a.op != b.op) return false;
+        if (a.op == OP_INPUT) return a.a == b.a;
+        if (a.op == OP_CONST) {
+            if (varying[a.a] != varying[b.a]) return false;
+            return varying[a.a] ? pidx[a.a] == pidx[b.a] : literal_bits[a.a] == literal_bits[b.a];
+        }
+        return same_expr(a.a, b.a) && same_expr(a.b, b.b);
+    };
+    auto is_literal = [&](uint32_t i, uint32_t bits) {
+        const LeafShape::Op &c = shape.ops[i];
+        return c.op == OP_CONST && !varying[c.a] && literal_bits[c.a] == bits;
+    };
     leaf << "template <bool FAST>\n__device__ __forceinline__ float leaf(const float *x";
     for (uint32_t i = 0; i < (k ? k : 1); ++i) leaf << ", float p" << i;
     leaf << ") {\n    (void)x; (void)p0;\n";
@@ -139,10 +157,25 @@ std::string JitCache::generate_source(const LeafShape &shape, const std::vector<
             else leaf << "jit_mod(v" << o.a << ", v" << o.b << ")";
             break;
         }
-        default: leaf << "jit_min(v" << o.a << ", v" << o.b << ")"; break;
+        default: {
+            // Minimum(x, -1 * x) == -|x| bit for bit unless x is -0.0 (the graph gives +0 there): the abs idiom the
+            // reference's doc comment suggests (effect.rs:106-111), one sign-modifier instead of two compares + select
+            const LeafShape::Op &nb = shape.ops[o.b];
+            bool neg_of_a = nb.op == OP_MUL && ((is_literal(nb.a, 0xBF800000u) && same_expr(nb.b, o.a)) ||
+                                                (is_literal(nb.b, 0xBF800000u) && same_expr(nb.a, o.a)));
+            if (neg_of_a && !maybe_negzero[o.a]) leaf << "-__builtin_fabsf(v" << o.a << ")";
+            else leaf << "jit_min(v" << o.a << ", v" << o.b << ")";
+            break;
+        }
         }
         leaf << ";\n";
         if (o.op != OP_CONST && o.op != OP_INPUT) dep[i] = dep[o.a] | dep[o.b];
+        switch (o.op) {
+        case OP_CONST: maybe_negzero[i] = varying[o.a] || literal_bits[o.a] == 0x80000000u; break;
+        case OP_SUM2: maybe_negzero[i] = maybe_negzero[o.a] && maybe_negzero[o.b]; break;
+        case OP_MIN: maybe_negzero[i] = maybe_negzero[o.a] || maybe_negzero[o.b]; break;
+        default: maybe_negzero[i] = true; break;   // inputs, products, quotients, remainders: not analysed
+        }
     }
     leaf << "    return v" << shape.ops.size() - 1 << ";\n}\n";
     const uint32_t K = k ? k : 1;

@@ -772,6 +772,30 @@ def test_jit_voices_unusual_time_inputs(hip_lib, oracle_lib):
         assert any(b["jit"] for b in hip.plan()["banks"])
 
 
+def test_template_voices_through_generated_kernel(hip_lib, oracle_lib, monkeypatch):
+    """FR_BANK_TEMPLATE=0: the N1 partial itself goes through shape matching + hipRTC instead of the hand-written
+    kernel -- the generated leaf with its exact peepholes (x mod 1 as fract in the in-range body, Minimum(u, -u) as
+    -|u| where u cannot be -0) must reproduce the oracle on ordinary and on hostile time inputs."""
+    monkeypatch.setenv("FR_BANK_TEMPLATE", "0")
+    tree = synth.additive_tree(3, 256, detune=True)
+    rng = np.random.default_rng(3)
+    rows = [
+        synth.time_ramp(0, 300),
+        (-synth.time_ramp(0, 300)),
+        (rng.normal(size=300) * 500).astype(np.float32),
+        np.array([0, 0.5, 1, np.nan, np.inf, -np.inf, 1e30, 3e38, 1e-30, -0.0, 4294967296.0, 8e9] * 25, dtype=np.float32),
+        synth.time_ramp(100000, 100300),
+    ]
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        for i, row in enumerate(rows):
+            got, exp = hip.fill_buffer(3, i * 300, (i + 1) * 300, [row]), ref.fill_buffer(3, i * 300, (i + 1) * 300, [row])
+            assert same_bits(got, exp), f"row {i}: " + first_diff(got, exp)
+        plan = hip.plan()
+        assert plan["banks"] and all(b["jit"] for b in plan["banks"]), plan
+
+
 def test_jit_disabled_gives_the_same_bits(hip_lib, monkeypatch):
     """FR_JIT=0: the same voices run as stage programs / pull instead of a specialised kernel; identical output."""
     tree = _triangle_tree(2, 32, am=True)
