@@ -38,8 +38,10 @@ static void set_slot(std::vector<EdgeRef> &v, uint32_t slot, const EdgeRef &r) {
     v[slot] = r;
 }
 
+static void set_slot(EdgeSlots &v, uint32_t slot, const EdgeRef &r) { v.set(slot, r); }
+
 bool SubGraph::equals(const SubGraph &o) const {
-    auto same_refs = [](const std::vector<EdgeRef> &a, const std::vector<EdgeRef> &b) {
+    auto same_refs = [](const auto &a, const auto &b) {
         if (a.size() != b.size()) return false;
         for (size_t i = 0; i < a.size(); ++i)
             if (a[i].present != b[i].present ||
@@ -149,16 +151,14 @@ void Mirror::add_edge(const fr_edge &e) {  // reference.rs:124-126,141-153
 }
 
 void Mirror::del_edge(const fr_edge &e) {  // reference.rs:127-136
-    std::vector<EdgeRef> *inbound;
     if (e.to == 0) {
-        inbound = &outputs;
+        if (e.to_slot < outputs.size()) outputs[e.to_slot] = EdgeRef{};
     } else {
         MNode *n = nodes.find(e.to);
         if (!n) throw Error(FR_ERR_NO_SUCH_NODE, "Attempt to delete edge, but it was never created!");
-        inbound = &n->inbound;
+        n->inbound.clear(e.to_slot);
         note(n->pos);
     }
-    if (e.to_slot < inbound->size()) (*inbound)[e.to_slot] = EdgeRef{};
     ++version;
 }
 

@@ -92,13 +92,51 @@ struct EdgeRef {
     bool present = false;
 };
 
+// Inbound edges of a node by to_slot.  Primitives have at most two inputs: those live inline, so a node is one
+// allocation-free 64-byte record (a patch is millions of them); composite instances with more inputs spill to a vector.
+class EdgeSlots {
+    EdgeRef inl_[2];
+    uint32_t n_ = 0;
+    std::unique_ptr<std::vector<EdgeRef>> more_;   // slots 2.. when present
+
+public:
+    EdgeSlots() = default;
+    EdgeSlots(const EdgeSlots &o) : n_(o.n_) {
+        inl_[0] = o.inl_[0]; inl_[1] = o.inl_[1];
+        if (o.more_) more_.reset(new std::vector<EdgeRef>(*o.more_));
+    }
+    EdgeSlots &operator=(const EdgeSlots &o) {
+        if (this != &o) { EdgeSlots t(o); *this = std::move(t); }
+        return *this;
+    }
+    EdgeSlots(EdgeSlots &&) noexcept = default;
+    EdgeSlots &operator=(EdgeSlots &&) noexcept = default;
+    size_t size() const { return n_; }
+    const EdgeRef &operator[](size_t i) const { return i < 2 ? inl_[i] : (*more_)[i - 2]; }
+    void set(uint32_t slot, const EdgeRef &r) {          // grows with empty slots like Vec::resize
+        if (slot >= 2) {
+            if (!more_) more_.reset(new std::vector<EdgeRef>());
+            if (more_->size() <= slot - 2) more_->resize((size_t)slot - 1);
+            (*more_)[slot - 2] = r;
+        } else {
+            inl_[slot] = r;
+        }
+        if (n_ <= slot) n_ = slot + 1;
+    }
+    void clear(uint32_t slot) {                          // Option::take on an existing slot; size unchanged
+        if (slot >= n_) return;
+        if (slot < 2) inl_[slot] = EdgeRef{};
+        else (*more_)[slot - 2] = EdgeRef{};
+    }
+};
+
 struct SubGraph;
 
 struct MNode {
     int32_t kind = 0;                          // FR_PRIM_* or FR_EFFECT_GRAPH
     uint32_t pos = 0;                          // dense position inside the owning table (top level only)
     std::shared_ptr<const SubGraph> sub;       // composite definition (interned)
-    std::vector<EdgeRef> inbound;              // by to_slot
+    EdgeSlots inbound;                         // by to_slot
 };
 
 // Immutable composite definition: nodes in a dense array, looked up by handle through `index`.
