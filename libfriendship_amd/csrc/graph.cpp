@@ -223,8 +223,8 @@ uint32_t FlatGraph::make(FlatOp op, uint32_t a, uint32_t b) {
         // a+b and a*b are bitwise commutative up to NaN payload, which is outside the contract.
         if ((op == OP_SUM2 || op == OP_MUL) && a > b) std::swap(a, b);
     }
-    uint64_t key = ((uint64_t)a << 32) | b;
-    uint64_t &e = cse_[op].get(key);
+    uint64_t key = ((uint64_t)op << 60) | ((uint64_t)a << 30) | b;
+    uint64_t &e = cse_bin_.get(key);
     if (e) return (uint32_t)(e - 1);
     uint32_t d = 1 + std::max(nodes[a].depth, nodes[b].depth);
     uint32_t id = push(op, a, b, d);
@@ -307,6 +307,7 @@ struct Lowering::Impl {
         readers_head.top.reserve(mm.nodes.capacity_positions());
         cells.clear();
         free_cells.clear();
+        fg.reserve_nodes(mm.nodes.size());
         fg.konst(0);   // node 0 is always +0.0
         ++generation;
     }

@@ -243,9 +243,11 @@ struct FlatGraph {
     bool is_const(uint32_t id) const { return nodes[id].op == OP_CONST; }
     bool is_const(uint32_t id, float v) const;
     float const_val(uint32_t id) const;
+    void reserve_nodes(size_t n) { nodes.reserve(n); cse_bin_.reserve(n); }   // one allocation instead of repeated regrowth
 
 private:
-    FlatMap64 cse_[8];   // (a << 32 | b) -> node id + 1
+    FlatMap64 cse_[2];   // OP_CONST: bits -> node id + 1; OP_INPUT: slot -> node id + 1
+    FlatMap64 cse_bin_;  // (op << 60 | a << 30 | b) -> node id + 1   (ids < 2^30)
     uint32_t push(FlatOp op, uint32_t a, uint32_t b, uint32_t depth);
 };
 
