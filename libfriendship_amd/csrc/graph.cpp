@@ -138,6 +138,10 @@ void Mirror::del_node(uint32_t handle) {  // reference.rs:121-123
 }
 
 void Mirror::add_edge(const fr_edge &e) {  // reference.rs:124-126,141-153
+    // The reference resizes its slot vector to to_slot + 1 whatever the value (reference.rs:148-150); a conforming
+    // host never sends a slot beyond an effect's arity (routegraph.rs:165-208 checks first).  Refuse absurd ones
+    // instead of allocating gigabytes on garbage.
+    if (e.to_slot >= MAX_TO_SLOT) throw Error(FR_ERR_UNSUPPORTED, "add_edge: to_slot " + std::to_string(e.to_slot) + " beyond the supported " + std::to_string(MAX_TO_SLOT));
     EdgeRef r{e.from, e.from_slot, true};
     if (e.to == 0) {
         set_slot(outputs, e.to_slot, r);

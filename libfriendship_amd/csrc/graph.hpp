@@ -198,6 +198,7 @@ public:
     // Edit journal for incremental lowering (class Lowering).  While `journal_on`, every edit appends the dense
     // position of the top-level node it touched (| JOURNAL_NODE when the node itself was added, replaced or deleted).
     // `journal_overflow` means the journal does not describe every edit since it was cleared: lower from scratch.
+    static constexpr uint32_t MAX_TO_SLOT = 1u << 20;   // input / output slots per node the engine accepts
     static constexpr uint32_t JOURNAL_NODE = 0x80000000u;
     static constexpr size_t JOURNAL_LIMIT = 1u << 16;   // (at least; see note())
     bool journal_on = false;

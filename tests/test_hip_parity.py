@@ -234,6 +234,15 @@ def test_hip_error_codes(hip_lib):
         with pytest.raises(RenderError) as ei:
             r.fill_buffer(1, 0, 4)
         assert ei.value.status == FR_ERR_CYCLE
+    with Renderer(hip_lib) as r:   # garbage slot indices are refused, not allocated (no crash, state intact)
+        r.on_add_node(1, "Sum2")
+        for to in (1, 0):
+            with pytest.raises(RenderError) as ei:
+                r.on_add_edge(0, to, 0, 0xFFFFFFF0)
+            assert ei.value.status == 10   # FR_ERR_UNSUPPORTED
+        r.on_add_edge(0, 1, 0, 0)
+        r.on_add_edge(1, 0, 0, 0)
+        assert r.fill_buffer(1, 0, 3, [[1, 2, 3]]).tolist() == [[1, 2, 3]]
 
 
 def test_hip_rows_beyond_storage_are_dropped(hip_lib):
