@@ -139,6 +139,20 @@ struct fr_renderer {
     DevBuf d_out, d_in_table, d_stack_node, d_stack_time, d_stack_val, d_bank_ws;
     // host-buffer entry point: input rows go up through pinned staging (one region per row, no sync between rows)
     PinnedBuf h_in_stage;
+    // Device-entry calls return before their work is done; a following call on ANOTHER stream (or the host entry
+    // point, which uses the renderer's own stream) must still see this one's history, rings and plan uploads.
+    hipEvent_t ev_last = nullptr;        // recorded after the last asynchronous call, on last_stream
+    hipStream_t last_stream = nullptr;
+    bool last_pending = false;
+    void order_after_previous(hipStream_t st) {
+        if (last_pending && last_stream != st) HIP_CHECK(hipStreamWaitEvent(st, ev_last, 0));
+    }
+    void remember_async(hipStream_t st) {
+        if (!ev_last) HIP_CHECK(hipEventCreateWithFlags(&ev_last, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ev_last, st));
+        last_stream = st;
+        last_pending = true;
+    }
     bool timing = false;
     // A/B switches (environment, read at create; defaults are the measured best):
     uint32_t bank_leaf_variant = 1;      // FR_BANK_LEAF=0: product-form leaves (kernels.hpp BankArgs::leaf_variant)
@@ -164,6 +178,7 @@ struct fr_renderer {
         for (TimerClass *tc : {&t_bank, &t_pull, &t_stage})
             for (auto &pr : tc->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
+        if (ev_last) (void)hipEventDestroy(ev_last);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -752,6 +767,7 @@ fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t 
         check_fill_args(out, n_slots, n_times, in_data, in_row_offsets, n_in_rows);
         HIP_CHECK(hipSetDevice(r->device));
         hipStream_t st = r->stream;
+        r->order_after_previous(st);
         r->store_inputs(n_slots, n_times, idx, in_data, in_row_offsets, n_in_rows, false, st);
         size_t bytes = (size_t)n_slots * n_times * sizeof(float);
         // (Rendering a long call as 2-4 sub-calls so that chunk c's D2H overlaps chunk c+1's kernels was tried: every
@@ -761,6 +777,7 @@ fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t 
         r->execute(r->d_out.as<float>(), n_slots, n_times, idx, st);
         if (bytes) HIP_CHECK(hipMemcpyAsync(out, r->d_out.p, bytes, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));   // synchronous contract: dispatch.rs:150-151
+        r->last_pending = false;               // everything issued so far, on any stream, is complete
         r->head = idx + n_times;               // reference.rs:84
     });
 }
@@ -772,8 +789,10 @@ fr_status fr_fill_buffer_device(fr_renderer *r, float *d_out, uint32_t n_slots, 
         check_fill_args(d_out, n_slots, n_times, d_in_data, in_row_offsets, n_in_rows);
         HIP_CHECK(hipSetDevice(r->device));
         hipStream_t st = (hipStream_t)stream;
+        r->order_after_previous(st);
         r->store_inputs(n_slots, n_times, idx, d_in_data, in_row_offsets, n_in_rows, true, st);
         r->execute(d_out, n_slots, n_times, idx, st);
+        r->remember_async(st);
         r->head = idx + n_times;
     });
 }

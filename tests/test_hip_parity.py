@@ -274,6 +274,36 @@ def test_device_resident_entry_point(hip_lib, oracle_lib):
             assert same_bits(d_out.cpu().numpy(), exp), first_diff(d_out.cpu().numpy(), exp)
 
 
+def test_calls_on_different_streams_are_ordered(hip_lib, oracle_lib):
+    """Device-entry calls are asynchronous; consecutive calls issued on DIFFERENT streams (and a host-buffer call in
+    between, which uses the renderer's own stream) still see each other's input history and delay rings: the engine
+    chains them with an event.  No synchronisation by the caller until the end."""
+    import torch
+    V, T, calls = 4, 1024, 6
+    tree = synth.effects_tree(V, 64, taps=3, base_delay=300.0)
+    t = synth.time_ramp(0, calls * T)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        d_t = torch.from_numpy(t).cuda()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [torch.empty((V, T), dtype=torch.float32, device="cuda") for _ in range(calls)]
+        host_out = {}
+        torch.cuda.synchronize()
+        for k in range(calls):
+            if k == 3:   # a host-buffer call in the middle of the asynchronous ones
+                host_out[k] = hip.fill_buffer(V, k * T, (k + 1) * T, [t[k * T:(k + 1) * T]])
+                continue
+            s = streams[k % 3]
+            row = d_t[k * T:(k + 1) * T]
+            hip.fill_buffer_device(outs[k].data_ptr(), V, T, k * T, row.data_ptr(), [0, T], s.cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(calls):
+            exp = ref.fill_buffer(V, k * T, (k + 1) * T, [t[k * T:(k + 1) * T]])
+            got = host_out[k] if k in host_out else outs[k].cpu().numpy()
+            assert same_bits(got, exp), f"call {k}: " + first_diff(got, exp)
+
+
 def test_device_calls_keep_input_history(hip_lib, oracle_lib):
     """With device-resident full rows the bank kernel itself appends the time row to the slot's history;
     a Delay on the same input must still see earlier calls' samples (tests/ext_input.rs:108-121 semantics)."""
