@@ -149,7 +149,11 @@ fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t 
 
 /* Same contract with every buffer already resident in device memory (out, in_data device pointers;
  * in_row_offsets stays a host pointer -- it is control data).  Work is enqueued on `stream`
- * (a hipStream_t; NULL = the default stream) and NOT synchronised: the caller owns ordering.
+ * (a hipStream_t; NULL = the default stream) and NOT synchronised: the caller synchronises before
+ * reading d_out and keeps d_in_data alive until then.  Calls on one handle are still issued one
+ * after another by the host; when consecutive calls use different streams (or a host-buffer call
+ * follows) the library itself orders their device work with an event, so the renderer's state --
+ * input history, delay lines -- is always that of the previous call.
  * The CPU oracle library returns FR_ERR_UNSUPPORTED. */
 fr_status fr_fill_buffer_device(fr_renderer *r, float *d_out, uint32_t n_slots, uint64_t n_times,
                                 uint64_t idx, const float *d_in_data,
