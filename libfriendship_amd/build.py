@@ -12,7 +12,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 OUT = os.path.join(PKG_DIR, "libfriendship_hip.so")
-SOURCES = ["engine.cpp", "graph.cpp", "match.cpp", "stage.cpp", "jit.cpp", "stagejit.cpp", "kernels.hip"]
+SOURCES = ["engine.cpp", "graph.cpp", "match.cpp", "stage.cpp", "jit.cpp", "leafjit.cpp", "stagejit.cpp", "kernels.hip"]
 HEADERS = ["graph.hpp", "kernels.hpp", "match.hpp", "stage.hpp", "jit.hpp", "leafshape.hpp", os.path.join("..", "..", "include", "friendship_render.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-slp-vectorize", "-mllvm", "-simplifycfg-sink-common=false", "-Wall", "-Wextra"]

@@ -82,6 +82,18 @@ struct StageJitPlan {
 bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<StageInstr> &instrs, uint32_t max_shapes, bool force,
                     StageJitPlan &out);
 
+// Text of `template <bool FAST> float leaf(const float *x, float p0, ...)` for one leaf shape, preceded by the helper
+// functions it calls.  FAST = the body in which Modulo(x, 1.0) is one v_fract_f32 (valid under the conditions of
+// match.cpp's fract_form_is_exact + the kernel's per-wave input test).
+struct LeafSource {
+    std::string text;
+    uint32_t k = 1;              // parameters per leaf (>= 1)
+    bool has_mod1 = false;       // the leaf contains a Modulo(x, 1.0)
+    uint32_t fract_inputs = 0;   // mask of the inputs its arguments depend on
+};
+LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
+                                const std::vector<uint32_t> &alias);
+
 // One compiled specialisation.
 struct JitKernel {
     hipModule_t module = nullptr;

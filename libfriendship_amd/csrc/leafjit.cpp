@@ -1,0 +1,109 @@
+// leafjit.cpp -- source text of one shape-matched voice's leaf function (see jit.hpp).  No HIP runtime calls in this
+// file: tests/cpp/plan_tests.cpp builds the generated leaf with g++ and compares it with the graph's own evaluation.
+#include <cstdio>
+#include <functional>
+#include <sstream>
+
+#include "graph.hpp"
+#include "jit.hpp"
+
+namespace fr {
+
+// helpers every generated leaf may call (device functions; plain C++ otherwise)
+static const char *kLeafHelpers = R"JIT(
+__device__ __forceinline__ float jit_mod(float a, float b) {   // reference.rs:254-261
+    float rem = fmodf(a, b);
+    return rem < 0.0f ? rem + b : rem;
+}
+__device__ __forceinline__ float jit_mod1(float a) {           // Modulo(a, 1.0): fmodf(a, 1) == a - trunc(a) exactly for finite a
+    float rem = a - truncf(a);                                  // (inf - inf = NaN, like fmodf); then the same fix-up
+    return rem < 0.0f ? rem + 1.0f : rem;
+}
+__device__ __forceinline__ float jit_min(float a, float b) {   // Rust >= 1.20 f32::min
+    return (a < b || b != b) ? a : b;
+}
+)JIT";
+
+LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
+                                const std::vector<uint32_t> &alias) {
+    std::ostringstream leaf;
+    uint32_t k = 0;
+    std::vector<int> pidx(shape.n_consts, -1);
+    for (uint32_t c = 0; c < shape.n_consts; ++c)
+        if (varying[c]) pidx[c] = alias[c] == c ? (int)k++ : pidx[alias[c]];
+    bool has_mod1 = false;
+    uint32_t fract_inputs = 0;                       // inputs the argument of some Modulo(x, 1.0) depends on
+    std::vector<uint32_t> dep(shape.ops.size(), 0);  // per op: mask of the inputs it depends on
+    // maybe_negzero[i]: can op i evaluate to -0.0?  (conservative; a sum is -0 only if both terms are)
+    std::vector<bool> maybe_negzero(shape.ops.size(), true);
+    // structural equality of two sub-expressions of the tree form (constants: same literal, or the same parameter)
+    std::function<bool(uint32_t, uint32_t)> same_expr = [&](uint32_t i, uint32_t j) -> bool {
+        const LeafShape::Op &a = shape.ops[i], &b = shape.ops[j];
+        if (a.op != b.op) return false;
+        if (a.op == OP_INPUT) return a.a == b.a;
+        if (a.op == OP_CONST) {
+            if (varying[a.a] != varying[b.a]) return false;
+            return varying[a.a] ? pidx[a.a] == pidx[b.a] : literal_bits[a.a] == literal_bits[b.a];
+        }
+        return same_expr(a.a, b.a) && same_expr(a.b, b.b);
+    };
+    auto is_literal = [&](uint32_t i, uint32_t bits) {
+        const LeafShape::Op &c = shape.ops[i];
+        return c.op == OP_CONST && !varying[c.a] && literal_bits[c.a] == bits;
+    };
+    leaf << "template <bool FAST>\n__device__ __forceinline__ float leaf(const float *x";
+    for (uint32_t i = 0; i < (k ? k : 1); ++i) leaf << ", float p" << i;
+    leaf << ") {\n    (void)x; (void)p0;\n";
+    for (size_t i = 0; i < shape.ops.size(); ++i) {
+        const LeafShape::Op &o = shape.ops[i];
+        leaf << "    float v" << i << " = ";
+        char buf[64];
+        switch (o.op) {
+        case OP_CONST:
+            if (varying[o.a]) leaf << "p" << pidx[o.a];
+            else { std::snprintf(buf, sizeof buf, "__builtin_bit_cast(float, 0x%08xu)", literal_bits[o.a]); leaf << buf; }
+            break;
+        case OP_INPUT: leaf << "x[" << o.a << "]"; dep[i] = 1u << o.a; break;
+        case OP_SUM2: leaf << "v" << o.a << " + v" << o.b; break;
+        case OP_MUL: leaf << "v" << o.a << " * v" << o.b; break;
+        case OP_DIV: leaf << "v" << o.a << " / v" << o.b; break;
+        case OP_MOD: {   // a literal divisor of exactly 1.0 (every oscillator's phase wrap) avoids the generic fmodf routine
+            const LeafShape::Op &d = shape.ops[o.b];
+            if (d.op == OP_CONST && !varying[d.a] && literal_bits[d.a] == 0x3F800000u) {
+                leaf << "(FAST ? __builtin_amdgcn_fractf(v" << o.a << ") : jit_mod1(v" << o.a << "))";
+                has_mod1 = true;
+                fract_inputs |= dep[o.a];
+            }
+            else leaf << "jit_mod(v" << o.a << ", v" << o.b << ")";
+            break;
+        }
+        default: {
+            // Minimum(x, -1 * x) == -|x| bit for bit unless x is -0.0 (the graph gives +0 there): the abs idiom the
+            // reference's doc comment suggests (effect.rs:106-111), one sign-modifier instead of two compares + select
+            const LeafShape::Op &nb = shape.ops[o.b];
+            bool neg_of_a = nb.op == OP_MUL && ((is_literal(nb.a, 0xBF800000u) && same_expr(nb.b, o.a)) ||
+                                                (is_literal(nb.b, 0xBF800000u) && same_expr(nb.a, o.a)));
+            if (neg_of_a && !maybe_negzero[o.a]) leaf << "-__builtin_fabsf(v" << o.a << ")";
+            else leaf << "jit_min(v" << o.a << ", v" << o.b << ")";
+            break;
+        }
+        }
+        leaf << ";\n";
+        if (o.op != OP_CONST && o.op != OP_INPUT) dep[i] = dep[o.a] | dep[o.b];
+        switch (o.op) {
+        case OP_CONST: maybe_negzero[i] = varying[o.a] || literal_bits[o.a] == 0x80000000u; break;
+        case OP_SUM2: maybe_negzero[i] = maybe_negzero[o.a] && maybe_negzero[o.b]; break;
+        case OP_MIN: maybe_negzero[i] = maybe_negzero[o.a] || maybe_negzero[o.b]; break;
+        default: maybe_negzero[i] = true; break;   // inputs, products, quotients, remainders: not analysed
+        }
+    }
+    leaf << "    return v" << shape.ops.size() - 1 << ";\n}\n";
+    LeafSource out;
+    out.k = k ? k : 1;
+    out.has_mod1 = has_mod1;
+    out.fract_inputs = fract_inputs;
+    out.text = std::string(kLeafHelpers) + leaf.str();
+    return out;
+}
+
+}  // namespace fr

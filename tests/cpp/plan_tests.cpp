@@ -21,6 +21,7 @@
 #include "../../libfriendship_amd/csrc/match.cpp"
 #include "../../libfriendship_amd/csrc/stage.cpp"
 #include "../../libfriendship_amd/csrc/stagejit.cpp"
+#include "../../libfriendship_amd/csrc/leafjit.cpp"
 
 using namespace fr;
 
@@ -938,6 +939,116 @@ static void oversized_expressions_are_split() {
     });
 }
 
+// ---- generated leaves (leafjit.cpp) on the CPU -----------------------------------------------------------------------
+// The leaf function the hipRTC bank kernel is built around, compiled with g++ and compared with the lowered graph's
+// own value for every leaf of a voice, on ordinary and hostile inputs: the general body always, the v_fract body
+// (FAST) wherever the kernel would select it.  Pins the peepholes (x mod 1 as fract, Minimum(u, -u) as -|u|).
+static void generated_leaves_equal_the_graph() {
+    const float hostile[] = {0.0f, -0.0f, 1.0f, 0.5f, 0.25f, 3.0f, 1e-30f, 1e-42f, 48000.0f, 16777216.0f, 4294967296.0f, 4294967808.0f,
+                             1e30f, 3e38f, -1.0f, -0.5f, -2.75f, -1e30f, INFINITY, -INFINITY, NAN};
+    struct Case { const char *name; std::function<uint32_t(Build &, float, float)> leaf; bool expect_fast, expect_abs; };
+    std::vector<Case> cases;
+    cases.push_back({"N1 partial", [](Build &b, float w, float amp) { return partial(b, w, amp); }, true, true});
+    cases.push_back({"triangle x input 1", [](Build &b, float w, float amp) {
+        uint32_t ph = b.op(FR_PRIM_MODULO, N(b.op(FR_PRIM_MULTIPLY, In(0), Cf(w))), Cf(1.0f));
+        uint32_t u = b.op(FR_PRIM_SUM2, N(ph), Cf(-0.5f));
+        uint32_t au = b.op(FR_PRIM_MULTIPLY, Cf(-1.0f), N(b.op(FR_PRIM_MINIMUM, N(u), N(b.op(FR_PRIM_MULTIPLY, Cf(-1.0f), N(u))))));
+        uint32_t tri = b.op(FR_PRIM_SUM2, Cf(1.0f), N(b.op(FR_PRIM_MULTIPLY, Cf(-4.0f), N(au))));
+        return b.op(FR_PRIM_MULTIPLY, N(b.op(FR_PRIM_MULTIPLY, Cf(amp), N(tri))), In(1)); }, true, true});
+    cases.push_back({"phase offset that can go negative", [](Build &b, float w, float amp) {
+        uint32_t x = b.op(FR_PRIM_SUM2, N(b.op(FR_PRIM_MULTIPLY, In(0), Cf(w))), Cf(amp - 0.3f));   // offset in (-0.3, 0.7]
+        uint32_t ph = b.op(FR_PRIM_MODULO, N(x), Cf(1.0f));
+        return b.op(FR_PRIM_MULTIPLY, N(ph), Cf(amp)); }, false, false});
+    cases.push_back({"abs of a product (can be -0), other divisors", [](Build &b, float w, float amp) {
+        uint32_t x = b.op(FR_PRIM_MULTIPLY, In(0), Cf(w));
+        uint32_t m = b.op(FR_PRIM_MINIMUM, N(x), N(b.op(FR_PRIM_MULTIPLY, N(x), Cf(-1.0f))));       // -|x| only if x is never -0: it can be
+        uint32_t r = b.op(FR_PRIM_MODULO, N(m), Cf(0.75f));
+        return b.op(FR_PRIM_DIVIDE, N(r), Cf(amp + 0.5f)); }, false, false});
+    for (const Case &cs : cases) {
+        std::mt19937 rng(77);
+        Build b;
+        std::vector<uint32_t> leaves;
+        for (int k = 0; k < 32; ++k) leaves.push_back(cs.leaf(b, 0.0013f * (float)(k + 1), 1.0f / (float)(k + 1)));
+        b.out(N(sum_tree(b, leaves)), 0);
+        Mirror m;
+        b.apply(m);
+        FlatGraph fg = lower(m, 1);
+        BankMatcher bm(fg, 20, true, false);
+        VoiceMatch vm;
+        CHECK(bm.try_voice(fg.outputs[0], vm) && vm.jit && vm.log2_p == 5);
+        LeafSource ls = generate_leaf_source(vm.shape, vm.varying, vm.literal_bits, vm.alias);
+        CHECK(vm.fast_ok == cs.expect_fast);
+        CHECK((ls.text.find("__builtin_fabsf") != std::string::npos) == cs.expect_abs);
+        // lowered ids of the leaves, in parameter order (left to right)
+        std::vector<uint32_t> leaf_ids;
+        std::function<void(uint32_t, int)> walk = [&](uint32_t id, int h) {
+            if (h == 0) { leaf_ids.push_back(id); return; }
+            walk(fg.nodes[id].a, h - 1);
+            walk(fg.nodes[id].b, h - 1);
+        };
+        walk(fg.outputs[0], 5);
+        // build the leaf for the CPU
+        static int serial = 0;
+        std::string base = "/tmp/fr_leafjit_" + std::to_string((long)getpid()) + "_" + std::to_string(serial++);
+        FILE *f = std::fopen((base + ".cpp").c_str(), "w");
+        CHECK(f != nullptr);
+        std::fputs("#include <cmath>\n#define __device__\n#define __forceinline__ inline\n"
+                   "static inline float __builtin_amdgcn_fractf(float a) { return a - floorf(a); }\n", f);
+        std::fputs(ls.text.c_str(), f);
+        for (int fast = 0; fast < 2; ++fast) {
+            std::fprintf(f, "extern \"C\" float leaf_%s(const float *x, const float *p) { return leaf<%s>(x", fast ? "fast" : "general", fast ? "true" : "false");
+            for (uint32_t i = 0; i < ls.k; ++i) std::fprintf(f, ", p[%u]", i);
+            std::fputs("); }\n", f);
+        }
+        std::fclose(f);
+        CHECK(std::system(("g++ -std=c++17 -O1 -ffp-contract=off -w -shared -fPIC -o " + base + ".so " + base + ".cpp").c_str()) == 0);
+        void *so = dlopen((base + ".so").c_str(), RTLD_NOW | RTLD_LOCAL);
+        CHECK(so != nullptr);
+        auto general = (float (*)(const float *, const float *))dlsym(so, "leaf_general");
+        auto fastf = (float (*)(const float *, const float *))dlsym(so, "leaf_fast");
+        CHECK(general && fastf);
+        std::remove((base + ".cpp").c_str());
+        std::remove((base + ".so").c_str());
+        const size_t nin = vm.shape.input_slots.size();
+        uint64_t n_fast = 0, n_general = 0;
+        std::uniform_real_distribution<float> uni(0.0f, 100000.0f);
+        for (int trial = 0; trial < 600; ++trial) {
+            float xin[4] = {0, 0, 0, 0};
+            Inputs in(4);
+            for (size_t i = 0; i < nin; ++i) {
+                float val = trial < 200 ? hostile[(trial * (i + 3) + i) % (sizeof hostile / sizeof hostile[0])]
+                                        : (trial % 3 ? std::floor(uni(rng)) : uni(rng) - 20000.0f);
+                xin[i] = val;
+                uint32_t slot = vm.shape.input_slots[i];
+                in[slot].assign(1, val);
+            }
+            bool in_range = vm.fast_ok && ls.has_mod1;
+            for (size_t i = 0; i < nin; ++i)
+                if ((ls.fract_inputs >> i) & 1u) in_range = in_range && f32_to_bits(xin[i]) <= 0x4F800000u;
+            for (size_t li = 0; li < leaf_ids.size(); ++li) {
+                float expect = flat_eval(fg, leaf_ids[li], 0, in);
+                const float *prm = vm.params.data() + li * ls.k;
+                float got = general(xin, prm);
+                ++n_general;
+                if (!same_bits(got, expect)) {
+                    std::fprintf(stderr, "%s: general body, leaf %zu, x0=%a: %a vs graph %a\n", cs.name, li, xin[0], got, expect);
+                    throw std::runtime_error("mismatch");
+                }
+                if (in_range) {
+                    float gf = fastf(xin, prm);
+                    ++n_fast;
+                    if (!same_bits(gf, expect)) {
+                        std::fprintf(stderr, "%s: fract body, leaf %zu, x0=%a: %a vs graph %a\n", cs.name, li, xin[0], gf, expect);
+                        throw std::runtime_error("mismatch");
+                    }
+                }
+            }
+        }
+        dlclose(so);
+        CHECK(n_general == 600 * 32 && (cs.expect_fast ? n_fast > 5000 : n_fast == 0));
+    }
+}
+
 int main(int argc, char **argv) {
     std::vector<std::pair<const char *, std::function<void()>>> tests = {
         {"lowering_folds_constants", lowering_folds_constants}, {"lowering_errors", lowering_errors},
@@ -948,7 +1059,8 @@ int main(int argc, char **argv) {
         {"incremental_lowering_equals_from_scratch", incremental_lowering_equals_from_scratch},
         {"bounded_signal_delays_are_staged", bounded_signal_delays_are_staged},
         {"value_ranges_are_sound", value_ranges_are_sound},
-        {"oversized_expressions_are_split", oversized_expressions_are_split}};
+        {"oversized_expressions_are_split", oversized_expressions_are_split},
+        {"generated_leaves_equal_the_graph", generated_leaves_equal_the_graph}};
     int failed = 0, ran = 0;
     for (auto &t : tests) {
         if (argc > 1 && std::string(argv[1]) != t.first) continue;

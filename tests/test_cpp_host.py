@@ -44,11 +44,11 @@ def test_engine_host_logic_against_oracle(oracle_lib):
     """tests/cpp/plan_tests.cpp: the lowered graph and the staged plan (banks, rings, level and fused programs,
     general-tree schedules), executed by small CPU interpreters in the test, equal the oracle bit for bit; the source
     generated for compiled stage programs, built with g++, does too."""
-    deps = [PLAN_SRC] + [os.path.join(CSRC, f) for f in ("graph.cpp", "graph.hpp", "match.cpp", "match.hpp", "stage.cpp", "stage.hpp", "stagejit.cpp", "jit.hpp", "kernels.hpp")]
+    deps = [PLAN_SRC] + [os.path.join(CSRC, f) for f in ("graph.cpp", "graph.hpp", "match.cpp", "match.hpp", "stage.cpp", "stage.hpp", "stagejit.cpp", "leafjit.cpp", "range.hpp", "jit.hpp", "kernels.hpp")]
     if not os.path.exists(PLAN_BIN) or os.path.getmtime(PLAN_BIN) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(PLAN_BIN), exist_ok=True)
         subprocess.run(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
                         "-Wno-subobject-linkage", "-o", PLAN_BIN, PLAN_SRC, "-ldl"], check=True)
     env = dict(os.environ, FRIENDSHIP_ORACLE_LIB=oracle_lib.path)
     p = subprocess.run([PLAN_BIN], env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and "12 passed; 0 failed" in p.stdout, p.stdout + p.stderr
+    assert p.returncode == 0 and "13 passed; 0 failed" in p.stdout, p.stdout + p.stderr
