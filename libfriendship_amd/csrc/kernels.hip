@@ -546,11 +546,9 @@ hipError_t launch_bank(const BankArgs &a, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------------
 // General voices: the same leaf, any Sum2 tree (odd carries, unbalanced, non-power-of-two partial counts).
-// The host cuts the tree into groups = maximal complete sub-trees of 1/2/4/8 consecutive leaves and a post-order
-// schedule "group, then m merges"; one wave per (voice, 64-frame tile) runs it with a small register stack whose
-// pointer is wave-uniform (scalar branch ladders, no dynamic register indexing).  Same bits as the graph: every
-// add is the tree's own add.  One wave per voice tile keeps the schedule sequential; voices x tiles give the
-// parallelism (this path exists for generality, the balanced kernel above is the fast one).
+// The host cuts the tree into items = maximal complete sub-trees of up to 2048 consecutive leaves and a post-order
+// schedule "item, then m merges"; one workgroup per (voice, 64-frame tile) runs it (gbank_tile below).  Same bits as
+// the graph: every add is the tree's own add.
 // ---------------------------------------------------------------------------------------------------
 // The evaluation stack lives in LDS as [level][lane] columns (a lane only touches its own column: no barriers, no
 // bank conflicts); its pointer is wave-uniform.  (A first version kept the stack in 16 named registers selected by
@@ -580,13 +578,18 @@ __device__ __forceinline__ float gbank_group(const ParamGroup &pg, uint32_t j, f
     return v;
 }
 
+// One workgroup (4 waves) per (voice, 64-frame tile).  Items of >= 32 leaves are complete sub-trees: each wave sums a
+// quarter of the item with the balanced kernel's inner loop (parameters through the scalar cache, register carry
+// chain), the four quarter sums meet in LDS in the tree's own association; smaller items are evaluated by wave 0
+// alone.  Wave 0 then runs the merge schedule on its LDS stack.  Two barriers per big item keep the hand-over safe.
 template <bool FAST>
-__device__ __forceinline__ float gbank_wave(const float *params, const uint32_t *gmeta, uint32_t nitems, float t, float *stack /* [GB_MAX_DEPTH][64] + lane */) {
+__device__ __forceinline__ float gbank_tile(const float *params, const uint32_t *gmeta, uint32_t nitems, float t, uint32_t wave, uint32_t lane,
+                                            float *stack /* wave 0: [GB_MAX_DEPTH][64] + lane */, float (*sm)[64]) {
     uint32_t sp = 0;
     const_f32_ptr p = (const_f32_ptr)params;
     typedef uint32_t __attribute__((address_space(4))) const *const_u32_ptr;
     const_u32_ptr gm = (const_u32_ptr)gmeta;
-    auto finish = [&](float v, uint32_t meta) {
+    auto finish = [&](float v, uint32_t meta) {        // wave 0 only
         for (uint32_t m = meta >> 4; m != 0u; --m) {   // v = pop() + v
             --sp;
             v = stack[sp * 64u] + v;
@@ -594,57 +597,56 @@ __device__ __forceinline__ float gbank_wave(const float *params, const uint32_t 
         stack[sp * 64u] = v;
         ++sp;
     };
-    // Items of 16..2048 leaves (complete sub-trees) run the balanced kernel's inner loop: parameters through the
-    // scalar cache with its own prefetch, group sums merged by the register carry chain.  Smaller items are single
-    // groups; the next one's parameters are requested before this one's math when it is small too.
-    ParamGroup cur, nxt;
-    bool have = false;
     uint32_t goff = 0;          // parameter group (8 pairs) the current item starts at
-    uint32_t meta = gm[0];
     for (uint32_t i = 0; i < nitems; ++i) {
-        const uint32_t meta_next = i + 1 < nitems ? gm[i + 1] : 0u;
+        const uint32_t meta = gm[i];
         const uint32_t k = meta & 15u;
-        float v;
-        if (k > 3u) {
-            const float tt[1] = {t};
-            float res[1];
-            bank_wave_sum<1, FAST, false>(params + (size_t)goff * 16u, 1u << (k - 3u), k - 3u, tt, res);
-            v = res[0];
+        const float tt[1] = {t};
+        float res[1];
+        if (k >= 5u) {          // 32..2048 leaves: a quarter (2^(k-5) groups of 8) per wave
+            const uint32_t gq = 1u << (k - 5u);
+            bank_wave_sum<1, FAST, false>(params + ((size_t)goff + (size_t)wave * gq) * 16u, gq, k - 5u, tt, res);
+            sm[wave][lane] = res[0];
+            __syncthreads();
+            if (wave == 0u) finish((sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]), meta);
+            __syncthreads();
             goff += 1u << (k - 3u);
-            have = false;
+        } else if (wave == 0u) {
+            if (k == 4u) {      // 16 leaves: two groups
+                bank_wave_sum<1, FAST, false>(params + (size_t)goff * 16u, 2u, 1u, tt, res);
+                finish(res[0], meta);
+            } else {
+                ParamGroup cur;
+                load_group(cur, p, goff);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                finish(gbank_group<FAST>(cur, k, t), meta);
+            }
+            goff += k == 4u ? 2u : 1u;
         } else {
-            if (!have) load_group(cur, p, goff);
-            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): cur and meta_next have landed
-            const bool next_small = i + 1 < nitems && (meta_next & 15u) <= 3u;
-            if (next_small) load_group(nxt, p, goff + 1u);
-            v = gbank_group<FAST>(cur, k, t);
-            goff += 1u;
-            have = next_small;
-            if (next_small) cur = nxt;
+            goff += k == 4u ? 2u : 1u;
         }
-        finish(v, meta);
-        meta = meta_next;
     }
-    return stack[0];   // a well-formed schedule leaves exactly the root
+    return wave == 0u ? stack[0] : 0.0f;   // a well-formed schedule leaves exactly the root
 }
 
-// 4 independent waves per workgroup, each its own 64-frame tile of the same voice.
-__global__ void __launch_bounds__(256) gbank_kernel(BankArgs a, uint32_t tile_groups, uint32_t nblocks) {
-    __shared__ float stack_mem[4][GB_MAX_DEPTH][64];
+__global__ void __launch_bounds__(256) gbank_kernel(BankArgs a, uint32_t tiles, uint32_t nblocks) {
+    __shared__ float stack_mem[GB_MAX_DEPTH][64];
+    __shared__ float sm[4][64];
     uint32_t b = blockIdx.x;
     uint32_t lid = (nblocks % 8u == 0u) ? (b % 8u) * (nblocks / 8u) + b / 8u : b;
-    const uint32_t voice = lid / tile_groups;
+    const uint32_t voice = lid / tiles;
+    const uint32_t tile = lid - voice * tiles;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = (lid - voice * tile_groups) * 4u + wave;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t ti = (uint64_t)tile * 64u + lane;
     const float t = bank_time(a, ti);
-    const bool fast = a.fast_ok && __all(t >= 0.0f && t <= 4294967296.0f);
+    const bool fast = a.fast_ok && __all(t >= 0.0f && t <= 4294967296.0f);   // same for the 4 waves: same 64 frames
     const uint32_t i0 = a.group_off[2u * voice], ni = a.group_off[2u * voice + 2u] - i0;
     const float2 *vparams = a.params + (size_t)a.group_off[2u * voice + 1u] * 8u;
-    float *stack = &stack_mem[wave][0][lane];
-    float r = fast ? gbank_wave<true>((const float *)vparams, a.groups + i0, ni, t, stack)
-                   : gbank_wave<false>((const float *)vparams, a.groups + i0, ni, t, stack);
+    float *stack = &stack_mem[0][lane];
+    float r = fast ? gbank_tile<true>((const float *)vparams, a.groups + i0, ni, t, wave, lane, stack, sm)
+                   : gbank_tile<false>((const float *)vparams, a.groups + i0, ni, t, wave, lane, stack, sm);
+    if (wave != 0u) return;
     float *orow = a.out + (size_t)a.rows[voice] * a.out_stride;
     const bool live = ti < a.n_times;
     if (live) orow[bank_out_index(a, ti)] = r;
@@ -672,10 +674,10 @@ __global__ void __launch_bounds__(256) gbank_kernel(BankArgs a, uint32_t tile_gr
 
 hipError_t launch_gbank(const BankArgs &a, hipStream_t s) {
     if (!a.groups || !a.group_off) return hipErrorInvalidValue;
-    uint64_t tg64 = ((a.n_times + 63) / 64 + 3) / 4, nblocks64 = tg64 * a.n_voices;   // 4 tiles (waves) per workgroup
+    uint64_t tiles = (a.n_times + 63) / 64, nblocks64 = tiles * a.n_voices;   // one workgroup (4 waves) per (voice, tile)
     if (nblocks64 == 0) return hipSuccess;
     if (nblocks64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gbank_kernel, dim3((uint32_t)nblocks64), dim3(256), 0, s, a, (uint32_t)tg64, (uint32_t)nblocks64);
+    hipLaunchKernelGGL(gbank_kernel, dim3((uint32_t)nblocks64), dim3(256), 0, s, a, (uint32_t)tiles, (uint32_t)nblocks64);
     return hipGetLastError();
 }
 
