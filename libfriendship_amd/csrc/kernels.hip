@@ -581,7 +581,8 @@ __device__ __forceinline__ float gbank_group(const ParamGroup &pg, uint32_t j, f
 // One workgroup (4 waves) per (voice, 64-frame tile).  Items of >= 32 leaves are complete sub-trees: each wave sums a
 // quarter of the item with the balanced kernel's inner loop (parameters through the scalar cache, register carry
 // chain), the four quarter sums meet in LDS in the tree's own association; smaller items are evaluated by wave 0
-// alone.  Wave 0 then runs the merge schedule on its LDS stack.  Two barriers per big item keep the hand-over safe.
+// alone.  Wave 0 then runs the merge schedule on its LDS stack.  One barrier per big item (double-buffered hand-over:
+// item i+2 reuses item i's buffer only after the barrier of item i+1, which wave 0 reaches after reading item i's).
 template <bool FAST>
 __device__ __forceinline__ float gbank_tile(const float *params, const uint32_t *gmeta, uint32_t nitems, float t, uint32_t wave, uint32_t lane,
                                             float *stack /* wave 0: [GB_MAX_DEPTH][64] + lane */, float (*sm)[64]) {
@@ -598,6 +599,7 @@ __device__ __forceinline__ float gbank_tile(const float *params, const uint32_t 
         ++sp;
     };
     uint32_t goff = 0;          // parameter group (8 pairs) the current item starts at
+    uint32_t nbig = 0;
     for (uint32_t i = 0; i < nitems; ++i) {
         const uint32_t meta = gm[i];
         const uint32_t k = meta & 15u;
@@ -606,10 +608,11 @@ __device__ __forceinline__ float gbank_tile(const float *params, const uint32_t 
         if (k >= 5u) {          // 32..2048 leaves: a quarter (2^(k-5) groups of 8) per wave
             const uint32_t gq = 1u << (k - 5u);
             bank_wave_sum<1, FAST, false>(params + ((size_t)goff + (size_t)wave * gq) * 16u, gq, k - 5u, tt, res);
-            sm[wave][lane] = res[0];
+            float(*buf)[64] = sm + 4u * (nbig & 1u);   // double-buffered: the next item's sums do not wait for wave 0 to read these
+            ++nbig;
+            buf[wave][lane] = res[0];
             __syncthreads();
-            if (wave == 0u) finish((sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]), meta);
-            __syncthreads();
+            if (wave == 0u) finish((buf[0][lane] + buf[1][lane]) + (buf[2][lane] + buf[3][lane]), meta);
             goff += 1u << (k - 3u);
         } else if (wave == 0u) {
             if (k == 4u) {      // 16 leaves: two groups
@@ -631,7 +634,7 @@ __device__ __forceinline__ float gbank_tile(const float *params, const uint32_t 
 
 __global__ void __launch_bounds__(256) gbank_kernel(BankArgs a, uint32_t tiles, uint32_t nblocks) {
     __shared__ float stack_mem[GB_MAX_DEPTH][64];
-    __shared__ float sm[4][64];
+    __shared__ float sm[8][64];
     uint32_t b = blockIdx.x;
     uint32_t lid = (nblocks % 8u == 0u) ? (b % 8u) * (nblocks / 8u) + b / 8u : b;
     const uint32_t voice = lid / tiles;
