@@ -297,6 +297,39 @@ __device__ __forceinline__ bool leaves_all_negzero(const float2 *params, uint32_
     return ok;
 }
 
+// The same question for all 64 frames of a tile at once, for tiles whose results are mostly zeros (a silent voice:
+// every amplitude 0; partials beyond 2^23 cycles): lanes over frames and parameters through the scalar cache like
+// the hot loop, each wave over its own share of the partials.  Returns per lane whether every leaf of the share is
+// exactly -0.0 (AND and OR of the bit patterns both equal to the sign bit).  Not inlined: its registers must not
+// disturb the hot loop's allocation (an inlined second loop made the kernel 1.6x slower, profiles/r01_bank_variants.txt).
+template <bool FAST>
+__device__ __attribute__((noinline)) bool wave_leaves_all_negzero(const float *params, uint32_t ngroups, float t) {
+    const_f32_ptr p = (const_f32_ptr)params;
+    uint32_t all_and = 0xFFFFFFFFu, all_or = 0u;
+    ParamGroup pa, pb;
+    load_group(pa, p, 0);
+    auto fold = [&](const ParamGroup &pg) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t b = __float_as_uint(bank_leaf<FAST, true>(t, pg.w[j], pg.A[j]));
+            all_and &= b;
+            all_or |= b;
+        }
+    };
+    for (uint32_t g = 0; g < ngroups; g += 2) {
+        const bool has_b = g + 1 < ngroups;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (has_b) load_group(pb, p, g + 1);
+        fold(pa);
+        if (has_b) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (g + 2 < ngroups) load_group(pa, p, g + 2);
+            fold(pb);
+        }
+    }
+    return all_and == 0x80000000u && all_or == 0x80000000u;
+}
+
 __device__ __forceinline__ float bank_time(const BankArgs &a, uint64_t ti) {
     return (ti >= a.time_skip && ti - a.time_skip < a.time_valid) ? a.time[ti - a.time_skip] : 0.0f;
 }
@@ -381,6 +414,20 @@ __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tile
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             unsigned long long m = zmask[f];          // workgroup-uniform
+            if (__builtin_popcountll(m) > 4) {        // many zeros in this tile: settle all 64 frames in one pass
+                bool mine = fast ? wave_leaves_all_negzero<true>(params, ngroups, t[f])
+                                 : wave_leaves_all_negzero<false>(params, ngroups, t[f]);
+                sm[wave][f][lane] = mine ? 1.0f : 0.0f;   // (the sums in sm were consumed before the barrier above)
+                __syncthreads();
+                if (wave == 0 && ((m >> lane) & 1ull)) {
+                    bool all = sm[0][f][lane] != 0.0f && sm[1][f][lane] != 0.0f && sm[2][f][lane] != 0.0f && sm[3][f][lane] != 0.0f;
+                    if (NW == 8) all = all && sm[4][f][lane] != 0.0f && sm[5][f][lane] != 0.0f && sm[6][f][lane] != 0.0f && sm[7][f][lane] != 0.0f;
+                    uint64_t ti = t0 + (uint32_t)f * 64u + lane;
+                    orow[direct ? bank_out_index(a, ti) : ti] = all ? -0.0f : 0.0f;
+                }
+                __syncthreads();
+                continue;
+            }
             while (m) {
                 uint32_t l = (uint32_t)__builtin_ctzll(m);
                 m &= m - 1;
@@ -513,6 +560,10 @@ void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &
         return;
     }
     const uint64_t blocks = ((n_times + 63) / 64) * n_voices;
+    // small voices: a wave's share of the partials is a handful of groups, so the fixed cost per workgroup dominates;
+    // 2 or 4 frames per lane amortise it (measured with tools/bank_bench: 32 partials 2.1 -> 3.2 T partial-frames/s,
+    // 128 partials 5.3 -> 6.2, 512 partials 8.5 -> 8.8; at 4096 one frame per lane is best)
+    if (n_times >= 1024 && blocks >= 4096) frames_per_lane = log2_p <= 7 ? 4 : (log2_p <= 9 ? 2 : 1);
     waves_per_group = (log2_p >= 14 || (blocks < 512 && log2_p >= 6)) ? 8 : 4;
     const uint32_t cmax = waves_per_group == 8 ? 14 : 13;
     chunk_log2 = log2_p < cmax ? log2_p : cmax;

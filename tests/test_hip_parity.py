@@ -150,6 +150,35 @@ def test_bank_unusual_time_inputs(hip_lib, oracle_lib):
         assert hip.plan()["banks"]
 
 
+def test_silent_and_degenerate_voices(hip_lib, oracle_lib):
+    """Voices whose mix is identically zero -- every amplitude +0 or -0 (a silent voice), or every t*w beyond 2^23
+    cycles -- have leaves that are all +-0; the sign of the exact-zero sum follows the graph (-0 iff every leaf is
+    -0).  Tiles full of zeros take the all-frames pass of the bank kernel; mixed voices take the per-frame one."""
+    V, P, T = 6, 256, 300
+    p = synth.voice_params(V, P, seed=1)
+    w, amp = p["w"].copy(), p["amp"].copy()
+    amp[0, :] = 0.0                      # silent: +0 amplitudes
+    amp[1, :] = -0.0                     # silent: -0 amplitudes
+    amp[2, ::2] = 0.0                    # half the partials silent: a normal non-zero mix
+    w[3, :] = (2.0 ** 24) * np.arange(1, P + 1, dtype=np.float32)   # every phase an integer: all leaves zero
+    amp[4, :] = 0.0
+    amp[4, 7] = -0.0                     # silent with one -0 amplitude among +0
+    g = synth.GraphArrays()
+    leaves = synth.partial_leaves(g, w, amp).reshape(V, P)
+    g.edge(synth.sum_tree(g, leaves), 0, 0, np.arange(V, dtype=np.uint32))
+    tree = g.finish(V)
+    rng = np.random.default_rng(2)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        rows = [synth.time_ramp(0, T), -synth.time_ramp(0, T), (rng.normal(size=T) * 100).astype(np.float32), synth.time_ramp(5000, 5000 + T)]
+        for i, row in enumerate(rows):
+            got, exp = hip.fill_buffer(V, i * T, (i + 1) * T, [row]), ref.fill_buffer(V, i * T, (i + 1) * T, [row])
+            assert same_bits(got, exp), f"row {i}: " + first_diff(got, exp)
+            assert not got[0].any() and not got[1].any() and got[2].any()
+        assert hip.plan()["banks"] and not hip.plan()["pull_rows"]
+
+
 def test_bank_negative_frequency_and_mixed_outputs(hip_lib, oracle_lib):
     """A voice with negative w (general fract path), next to outputs that are not banks: the bank delayed by 5
     frames (staged: the bank fills a ring, two small programs read it) and the time input itself."""
