@@ -700,12 +700,52 @@ __global__ void __launch_bounds__(256) gbank_kernel(BankArgs a, uint32_t tiles, 
     float *stack = &stack_mem[0][lane];
     float r = fast ? gbank_tile<true>((const float *)vparams, a.groups + i0, ni, t, wave, lane, stack, sm)
                    : gbank_tile<false>((const float *)vparams, a.groups + i0, ni, t, wave, lane, stack, sm);
-    if (wave != 0u) return;
     float *orow = a.out + (size_t)a.rows[voice] * a.out_stride;
     const bool live = ti < a.n_times;
-    if (live) orow[bank_out_index(a, ti)] = r;
+    if (wave == 0u && live) orow[bank_out_index(a, ti)] = r;
     // sign of a zero result: -0 iff every (valid) leaf is -0, see leaves_all_negzero
-    unsigned long long zm = __ballot(live && r == 0.0f);
+    __shared__ unsigned long long zshared;
+    if (wave == 0u) {
+        unsigned long long z = __ballot(live && r == 0.0f);
+        if (lane == 0u) zshared = z;
+    }
+    __syncthreads();
+    unsigned long long zm = zshared;   // workgroup-uniform
+    if (zm == 0ull) return;
+    if (__builtin_popcountll(zm) > 4) {
+        // many zero frames (a silent voice): all 64 frames at once, items of >= 32 leaves split over the 4 waves like
+        // the sums were, the few leaves of smaller items on wave 0 (padding pairs are not leaves and are skipped)
+        bool ok = true;
+        uint32_t goff = 0;
+        const float *fp = (const float *)vparams;
+        for (uint32_t i = 0; i < ni; ++i) {
+            const uint32_t kk = a.groups[i0 + i] & 15u;
+            if (kk >= 5u) {
+                const uint32_t gq = 1u << (kk - 5u);
+                const float *q = fp + ((size_t)goff + (size_t)wave * gq) * 16u;
+                ok = (fast ? wave_leaves_all_negzero<true>(q, gq, t) : wave_leaves_all_negzero<false>(q, gq, t)) && ok;
+                goff += 1u << (kk - 3u);
+            } else {
+                if (wave == 0u) {
+                    const uint32_t sz = 1u << kk;
+                    for (uint32_t j = 0; j < sz; ++j) {
+                        const float2 pr = vparams[(size_t)goff * 8u + j];   // wave-uniform address
+                        const float lf = fast ? bank_leaf<true, true>(t, pr.x, pr.y) : bank_leaf<false, true>(t, pr.x, pr.y);
+                        ok = ok && __float_as_uint(lf) == 0x80000000u;
+                    }
+                }
+                goff += kk == 4u ? 2u : 1u;
+            }
+        }
+        sm[wave][lane] = ok ? 1.0f : 0.0f;     // (every wave is past the last hand-over of gbank_tile: zshared's barrier)
+        __syncthreads();
+        if (wave == 0u && ((zm >> lane) & 1ull)) {
+            const bool all = sm[0][lane] != 0.0f && sm[1][lane] != 0.0f && sm[2][lane] != 0.0f && sm[3][lane] != 0.0f;
+            orow[bank_out_index(a, ti)] = all ? -0.0f : 0.0f;
+        }
+        return;
+    }
+    if (wave != 0u) return;
     while (zm) {
         uint32_t l = (uint32_t)__builtin_ctzll(zm);
         zm &= zm - 1;

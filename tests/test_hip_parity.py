@@ -177,6 +177,25 @@ def test_silent_and_degenerate_voices(hip_lib, oracle_lib):
             assert same_bits(got, exp), f"row {i}: " + first_diff(got, exp)
             assert not got[0].any() and not got[1].any() and got[2].any()
         assert hip.plan()["banks"] and not hip.plan()["pull_rows"]
+    # the same for voices that are not balanced trees (schedule kernel): 250 and 1000 partials
+    for P2 in (250, 1000):
+        p = synth.voice_params(4, P2, seed=3)
+        w, amp = p["w"].copy(), p["amp"].copy()
+        amp[0, :] = 0.0
+        amp[1, :] = -0.0
+        amp[2, 1::3] = 0.0
+        g = synth.GraphArrays()
+        leaves = synth.partial_leaves(g, w, amp).reshape(4, P2)
+        g.edge(synth.sum_tree(g, leaves), 0, 0, np.arange(4, dtype=np.uint32))
+        tree = g.finish(4)
+        with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+            synth.install(hip, tree)
+            synth.install(ref, tree)
+            for i, row in enumerate([synth.time_ramp(0, 130), -synth.time_ramp(0, 130), synth.time_ramp(7000, 7130)]):
+                got, exp = hip.fill_buffer(4, i * 130, (i + 1) * 130, [row]), ref.fill_buffer(4, i * 130, (i + 1) * 130, [row])
+                assert same_bits(got, exp), f"P={P2} row {i}: " + first_diff(got, exp)
+                assert not got[0].any() and not got[1].any() and got[3].any()
+            assert any(b["general_tree"] for b in hip.plan()["banks"])
 
 
 def test_bank_negative_frequency_and_mixed_outputs(hip_lib, oracle_lib):
