@@ -158,6 +158,7 @@ struct fr_renderer {
     uint32_t bank_leaf_variant = 1;      // FR_BANK_LEAF=0: product-form leaves (kernels.hpp BankArgs::leaf_variant)
     bool allow_jit = true;               // FR_JIT=0: no hipRTC specialisation (those voices run as programs / pull)
     bool allow_template = true;          // FR_BANK_TEMPLATE=0: template voices go through the JIT path literally
+    bool allow_multi = true;             // FR_BANK_MULTI=0: never the whole-voices-per-wave kernel for small voices
     int stage_jit_mode = 1;              // FR_STAGE_JIT=0: programs always interpreted; 1: compiled when >= 4 programs share
                                          // a skeleton on average; 2 ("force"): compiled whenever they fit one kernel
     JitCache jit_cache;
@@ -535,7 +536,11 @@ struct fr_renderer {
                 sc.done();
                 continue;
             }
-            bank_shape(a.log2_p, a.n_voices, blen, a.chunk_log2, a.frames_per_lane, a.waves_per_group, a.small_call);
+            bank_shape(a.log2_p, a.n_voices, blen, a.chunk_log2, a.frames_per_lane, a.waves_per_group, a.small_call, a.voices_per_wave);
+            if (a.voices_per_wave && !allow_multi) {   // A/B: the quarter-voice-per-wave kernel, one frame per lane
+                a.voices_per_wave = 0;
+                a.frames_per_lane = 1;
+            }
             if (a.small_call && a.hist_dst) throw Error(FR_ERR_DEVICE, "internal: deferred history append on a short call");
             a.leaf_variant = bank_leaf_variant;
             if (a.chunk_log2 != a.log2_p) {
@@ -718,6 +723,7 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     if (const char *lv = std::getenv("FR_BANK_LEAF")) r->bank_leaf_variant = (lv[0] == '1') ? 1u : 0u;
     if (const char *jv = std::getenv("FR_JIT")) r->allow_jit = jv[0] != '0';
     if (const char *tv = std::getenv("FR_BANK_TEMPLATE")) r->allow_template = tv[0] != '0';
+    if (const char *mv = std::getenv("FR_BANK_MULTI")) r->allow_multi = mv[0] != '0';
     if (const char *sv = std::getenv("FR_STAGE_JIT")) r->stage_jit_mode = sv[0] == '0' ? 0 : (sv[0] == '1' ? 1 : 2);
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {
         delete r;

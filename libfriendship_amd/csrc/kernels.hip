@@ -440,6 +440,67 @@ __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tile
     }
 }
 
+// Many small voices (<= 256 partials each): one workgroup per (batch of voices, tile of frames); every wave sums WHOLE
+// voices, `voices_per_wave` of them one after the other, with the same inner loop.  Nothing is shared between waves:
+// no LDS, no barriers; the tile's time values are loaded once and stay in registers for all the wave's voices.  (With
+// a quarter of a 32-partial voice per wave the fixed cost of a workgroup -- time loads, one exposed parameter load,
+// LDS hand-over, barrier -- outweighs its 8 leaves: 2.1 T partial-frames/s.)
+template <int F, int MODE>
+__global__ void __launch_bounds__(256) bank_multi_kernel(BankArgs a, uint32_t tiles, uint32_t nblocks) {
+    uint32_t b = blockIdx.x;
+    uint32_t lid = (nblocks % 8u == 0u) ? (b % 8u) * (nblocks / 8u) + b / 8u : b;
+    const uint32_t vb = lid / tiles, tile = lid - vb * tiles;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t t0 = (uint64_t)tile * (64u * F);
+    float t[F];
+    bool nonneg = true;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        uint64_t ti = t0 + (uint32_t)f * 64u + lane;
+        t[f] = bank_time(a, ti);
+        nonneg = nonneg && (t[f] >= 0.0f) && (t[f] <= 4294967296.0f);
+        if (a.hist_dst && vb == 0u && wave == 0u && ti < a.time_valid) a.hist_dst[ti] = t[f];
+    }
+    const bool fast = a.fast_ok && __all(nonneg);
+    const uint32_t ngroups = 1u << (a.log2_p - 3u), levels = a.log2_p - 3u;
+    const uint32_t v0 = (vb * 4u + wave) * a.voices_per_wave;
+    constexpr bool EXACT = (MODE == 0);
+    for (uint32_t j = 0; j < a.voices_per_wave; ++j) {
+        const uint32_t voice = v0 + j;
+        if (voice >= a.n_voices) break;                      // wave-uniform
+        const float2 *vparams = a.params + ((size_t)voice << a.log2_p);
+        float res[F];
+        if (fast) bank_wave_sum<F, true, EXACT>((const float *)vparams, ngroups, levels, t, res);
+        else bank_wave_sum<F, false, EXACT>((const float *)vparams, ngroups, levels, t, res);
+        float *orow = a.out + (size_t)a.rows[voice] * a.out_stride;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const uint64_t ti = t0 + (uint32_t)f * 64u + lane;
+            const bool live = ti < a.n_times;
+            if (live) orow[bank_out_index(a, ti)] = res[f];
+            if (MODE == 1) {   // sign of exact zeros, as in bank_kernel, within the wave
+                unsigned long long zm = __ballot(live && res[f] == 0.0f);
+                if (zm == 0ull) continue;
+                if (__builtin_popcountll(zm) > 4) {
+                    const bool all = fast ? wave_leaves_all_negzero<true>((const float *)vparams, ngroups, t[f])
+                                          : wave_leaves_all_negzero<false>((const float *)vparams, ngroups, t[f]);
+                    if ((zm >> lane) & 1ull) orow[bank_out_index(a, ti)] = all ? -0.0f : 0.0f;
+                    continue;
+                }
+                while (zm) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(zm);
+                    zm &= zm - 1;
+                    const uint64_t tz_i = t0 + (uint32_t)f * 64u + l;
+                    const float tz = bank_time(a, tz_i);
+                    const bool all = __all(leaves_all_negzero(vparams, 1u << a.log2_p, tz, lane, 64u));
+                    if (lane == 0u) orow[bank_out_index(a, tz_i)] = all ? -0.0f : 0.0f;
+                }
+            }
+        }
+    }
+}
+
 // Short calls (fewer frames than half a wave has lanes): time-major lanes would idle, so here lanes run over
 // PARTIALS -- the layout the north star sketches: coalesced float2 loads of each partial's {w, A4} (held in
 // registers for the call's frames), a wavefront-shuffle butterfly for the per-voice mix, LDS for the 4 waves.
@@ -551,13 +612,31 @@ static hipError_t launch_bank_f(const BankArgs &a, hipStream_t s) {
 //    T = 32: 13.9 vs 37 us); lanes-over-partials only ties at T = 1 (11.4 us), so it is used for T <= 2;
 //  * voices larger than one workgroup's capacity (8192 / 16384 partials) are split into chunks.
 void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane,
-                uint32_t &waves_per_group, uint32_t &small_call) {
+                uint32_t &waves_per_group, uint32_t &small_call, uint32_t &voices_per_wave) {
     frames_per_lane = 1;
+    voices_per_wave = 0;
     small_call = (n_times <= 2 && log2_p >= 8 && n_voices <= 65535u) ? 1u : 0u;
     if (small_call) {
         chunk_log2 = 8;
         waves_per_group = 4;
         return;
+    }
+    if (log2_p <= 8) {
+        // many small voices: whole voices per wave (bank_multi_kernel).  Measured with tools/bank_bench at 4800 frames:
+        // 4096 x 32 partials 2.1 -> 6.7 T partial-frames/s (8 voices in a row, 2 frames per lane), 1024 x 128 5.6 -> 8.2 and
+        // 512 x 256 7.1 -> 8.5 (2 in a row); profiles/r01_small_and_silent_voices.txt.  Needs enough voices to fill the chip.
+        const uint32_t F = (log2_p <= 5 && n_times >= 1024) ? 2u : 1u;
+        const uint64_t tiles = (n_times + 64 * F - 1) / (64 * F);
+        uint32_t vpw = std::max(2u, 256u >> log2_p);
+        auto nblocks = [&](uint32_t per_wave) { return ((n_voices + 4ull * per_wave - 1) / (4ull * per_wave)) * tiles; };
+        while (vpw > 1 && nblocks(vpw) < 2048) vpw >>= 1;
+        if (nblocks(vpw) >= 1024) {
+            voices_per_wave = vpw;
+            frames_per_lane = F;
+            chunk_log2 = log2_p;
+            waves_per_group = 4;
+            return;
+        }
     }
     const uint64_t blocks = ((n_times + 63) / 64) * n_voices;
     // small voices: a wave's share of the partials is a handful of groups, so the fixed cost per workgroup dominates;
@@ -580,6 +659,27 @@ hipError_t launch_bank(const BankArgs &a, hipStream_t s) {
         if (e != hipSuccess || a.log2_p == 8) return e;
         uint64_t total = (uint64_t)a.n_voices * a.n_times;
         hipLaunchKernelGGL(bank_combine_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
+    if (a.voices_per_wave) {   // many small voices: whole voices per wave
+        if (a.log2_p < 3 || a.log2_p > 8 || a.chunk_log2 != a.log2_p || a.voices_per_wave > 64) return hipErrorInvalidValue;
+        if (a.n_times == 0 || a.n_voices == 0) return hipSuccess;
+        const uint32_t F = a.frames_per_lane;
+        if (F != 1 && F != 2) return hipErrorInvalidValue;
+        const uint64_t tiles = (a.n_times + 64 * F - 1) / (64 * F);
+        const uint64_t vgroups = ((uint64_t)a.n_voices + 4ull * a.voices_per_wave - 1) / (4ull * a.voices_per_wave);
+        const uint64_t nb = tiles * vgroups;
+        if (nb > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        const int mode = a.leaf_variant > 2 ? 1 : (int)a.leaf_variant;
+        if (F == 1) {
+            if (mode == 0) hipLaunchKernelGGL((bank_multi_kernel<1, 0>), dim3((uint32_t)nb), dim3(256), 0, s, a, (uint32_t)tiles, (uint32_t)nb);
+            else if (mode == 1) hipLaunchKernelGGL((bank_multi_kernel<1, 1>), dim3((uint32_t)nb), dim3(256), 0, s, a, (uint32_t)tiles, (uint32_t)nb);
+            else hipLaunchKernelGGL((bank_multi_kernel<1, 2>), dim3((uint32_t)nb), dim3(256), 0, s, a, (uint32_t)tiles, (uint32_t)nb);
+        } else {
+            if (mode == 0) hipLaunchKernelGGL((bank_multi_kernel<2, 0>), dim3((uint32_t)nb), dim3(256), 0, s, a, (uint32_t)tiles, (uint32_t)nb);
+            else if (mode == 1) hipLaunchKernelGGL((bank_multi_kernel<2, 1>), dim3((uint32_t)nb), dim3(256), 0, s, a, (uint32_t)tiles, (uint32_t)nb);
+            else hipLaunchKernelGGL((bank_multi_kernel<2, 2>), dim3((uint32_t)nb), dim3(256), 0, s, a, (uint32_t)tiles, (uint32_t)nb);
+        }
         return hipGetLastError();
     }
     if (a.waves_per_group != 4 && a.waves_per_group != 8) return hipErrorInvalidValue;

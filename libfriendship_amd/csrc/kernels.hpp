@@ -60,6 +60,8 @@ struct BankArgs {
     uint32_t frames_per_lane;  // 1, 2 or 4; from bank_shape
     uint32_t waves_per_group;  // 4 or 8; from bank_shape
     uint32_t small_call;       // 1: lanes-over-partials kernel for calls of <= 32 frames; from bank_shape
+    uint32_t voices_per_wave;  // > 0: many small voices (<= 256 partials): a wave sums WHOLE voices, this many in a row, for one
+                               // tile of frames -- no LDS, no barriers, the time values stay in registers (bank_multi_kernel)
     uint32_t leaf_variant;     // 0 = product-form leaves; 1 = FMA-form leaves + zero-sign repair (same bits, faster)
     float *hist_dst;           // if non-null: the kernel also copies time[0..time_valid) here (input-history append)
     float *ws;                 // [P >> chunk_log2][n_voices][n_times] partial sums; unused when one chunk
@@ -70,7 +72,7 @@ struct BankArgs {
     const uint32_t *group_off;
 };
 void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane,
-                uint32_t &waves_per_group, uint32_t &small_call);
+                uint32_t &waves_per_group, uint32_t &small_call, uint32_t &voices_per_wave);
 uint64_t bank_blocks(const BankArgs &a);
 hipError_t launch_bank(const BankArgs &a, hipStream_t s);
 hipError_t launch_gbank(const BankArgs &a, hipStream_t s);   // voices that are arbitrary Sum2 trees (schedule form)

@@ -198,6 +198,45 @@ def test_silent_and_degenerate_voices(hip_lib, oracle_lib):
             assert any(b["general_tree"] for b in hip.plan()["banks"])
 
 
+def test_many_small_voices_kernel(hip_lib, oracle_lib, monkeypatch):
+    """Enough small voices (<= 256 partials) take bank_multi_kernel: whole voices per wave, several in a row, no LDS.
+    Same bits as the quarter-voice kernel (FR_BANK_MULTI=0) on the full output -- silent voices, hostile times and a
+    ring-fed delay included -- and as the oracle on sampled frames."""
+    for V, P, T in ((1024, 32, 1100), (600, 128, 700), (260, 256, 1030)):
+        p = synth.voice_params(V, P, seed=9)
+        w, amp = p["w"].copy(), p["amp"].copy()
+        w = (w * (1.0 + 1e-4 * (np.arange(V) // 64))[:, None]).astype(np.float32)
+        w[:, :] = np.tile(synth.voice_params(64, P, seed=9)["w"], (V // 64 + 1, 1))[:V] * (1.0 + 1e-4 * (np.arange(V) // 64))[:, None].astype(np.float32)
+        amp[5, :] = 0.0                   # silent voices: the all-frames zero-sign pass inside the wave
+        amp[6, :] = -0.0
+        amp[7, 3] = 0.0
+        g = synth.GraphArrays()
+        leaves = synth.partial_leaves(g, w.astype(np.float32), amp).reshape(V, P)
+        roots = synth.sum_tree(g, leaves)
+        g.edge(roots, 0, 0, np.arange(V, dtype=np.uint32))
+        d = g.binop(synth.K_SUM2, roots[0:1], g.binop(synth.K_DELAY, roots[1:2], synth.C(np.float32(11.0)), 1), 1)
+        g.edge(d, 0, 0, V)                # one more row: voice 0 + voice 1 delayed (voice 1 also fills a ring)
+        tree = g.finish(V + 1)
+        rng = np.random.default_rng(V)
+        rows = [synth.time_ramp(0, T), synth.time_ramp(T, 2 * T),
+                np.concatenate([-synth.time_ramp(0, 64), [np.nan, np.inf, -0.0, 1e30], synth.time_ramp(0, T - 68)]).astype(np.float32)]
+        outs = {}
+        for multi in ("1", "0"):
+            monkeypatch.setenv("FR_BANK_MULTI", multi)
+            with Renderer(hip_lib) as hip:
+                synth.install(hip, tree)
+                outs[multi] = [hip.fill_buffer(V + 1, i * T, (i + 1) * T, [row]) for i, row in enumerate(rows)]
+        for i in range(len(rows)):
+            assert same_bits(outs["1"][i], outs["0"][i]), f"V={V} P={P} row {i}: " + first_diff(outs["1"][i], outs["0"][i])
+        with Renderer(oracle_lib) as ref:
+            synth.install(ref, tree)
+            exp = ref.fill_buffer(V + 1, 0, 70, [rows[0][:70]])          # contiguous from 0: the delayed row too
+            assert same_bits(outs["1"][0][:, :70], exp), f"V={V} P={P} first frames: " + first_diff(outs["1"][0][:, :70], exp)
+            for c in (T - 1, int(rng.integers(70, T))):                    # later frames by seeking: rows without a Delay only
+                exp = ref.fill_buffer(V + 1, c, c + 1, [rows[0][c:c + 1]])
+                assert same_bits(outs["1"][0][:V, c:c + 1], exp[:V]), f"V={V} P={P} frame {c}: " + first_diff(outs["1"][0][:V, c:c + 1], exp[:V])
+
+
 def test_bank_negative_frequency_and_mixed_outputs(hip_lib, oracle_lib):
     """A voice with negative w (general fract path), next to outputs that are not banks: the bank delayed by 5
     frames (staged: the bank fills a ring, two small programs read it) and the time input itself."""

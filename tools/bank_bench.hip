@@ -112,13 +112,14 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(d_time, time.data(), T * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_rows, rows.data(), V * 4, hipMemcpyHostToDevice));
 
-    struct Var { int f, leaf, chunk; const char *name; int nw = 4; int small = 0; };
+    struct Var { int f, leaf, chunk; const char *name; int nw = 4; int small = 0; int vpw = 0; };
     std::vector<Var> vars;
     int full = std::min(log2p, 13);
     for (int f : {1, 2, 4})
         for (int leaf : {0, 1}) vars.push_back({f, leaf, full, ""});
     vars.push_back({2, 2, full, ""});
     if (T <= 32 && log2p >= 8) vars.push_back({1, 1, 8, "small", 4, 1});
+    if (log2p <= 8) for (int vpw : {2, 4, 8, 16}) for (int f : {1, 2}) vars.push_back({f, 1, log2p, "multi", 4, 0, vpw});
     vars.push_back({1, 1, full, "", 8});
     vars.push_back({1, 0, full, "", 8});
     vars.push_back({2, 1, full, "", 8});
@@ -131,7 +132,7 @@ int main(int argc, char **argv) {
             fr::BankArgs a{};
             a.params = (const float2 *)d_params; a.time = d_time; a.time_valid = T; a.out = d_out; a.rows = d_rows;
             a.n_voices = V; a.log2_p = log2p; a.n_times = T; a.fast_ok = 1;
-            a.chunk_log2 = vars[i].chunk; a.frames_per_lane = vars[i].f; a.waves_per_group = vars[i].nw; a.out_stride = T; a.small_call = vars[i].small; if (vars[i].small) a.chunk_log2 = 8; a.leaf_variant = vars[i].leaf; a.ws = d_ws;
+            a.chunk_log2 = vars[i].chunk; a.frames_per_lane = vars[i].f; a.waves_per_group = vars[i].nw; a.out_stride = T; a.small_call = vars[i].small; if (vars[i].small) a.chunk_log2 = 8; a.leaf_variant = vars[i].leaf; a.ws = d_ws; a.voices_per_wave = vars[i].vpw;
             CK(hipEventRecord(e0));
             if (fr::launch_bank(a, 0) != hipSuccess) { (void)hipGetLastError(); if (r == 0) outs[i].assign((size_t)V * T, -1.0f); if (r > 0) times[i].push_back(1e9); continue; }   // shape not supported by this variant
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -145,6 +146,7 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < vars.size(); ++i) {
         double med = median(times[i]), mn = *std::min_element(times[i].begin(), times[i].end());
         bool same = std::memcmp(outs[i].data(), outs[0].data(), outs[0].size() * 4) == 0;
+        if (vars[i].vpw) std::printf("  whole voices per wave, %2d in a row ", vars[i].vpw);
         std::printf("  %sNW=%d F=%d leaf=%d chunk=2^%d : %.4f / %.4f ms   %.2f Msamples/s   %.2f Tpf/s   same=%d\n", vars[i].small ? "lanes-over-partials " : "", vars[i].nw, vars[i].f, vars[i].leaf,
                     vars[i].chunk, med, mn, T / (med * 1e-3) / 1e6, pf / (med * 1e-3) / 1e12, (int)same);
     }
