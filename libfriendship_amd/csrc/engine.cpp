@@ -141,15 +141,22 @@ struct fr_renderer {
     PinnedBuf h_in_stage;
     // Device-entry calls return before their work is done; a following call on ANOTHER stream (or the host entry
     // point, which uses the renderer's own stream) must still see this one's history, rings and plan uploads.
-    hipEvent_t ev_last = nullptr;        // recorded after the last asynchronous call, on last_stream
-    hipStream_t last_stream = nullptr;
+    hipEvent_t ev_last = nullptr;
+    hipStream_t last_stream = nullptr;   // stream of the last asynchronous call while its work may still be running
     bool last_pending = false;
     void order_after_previous(hipStream_t st) {
-        if (last_pending && last_stream != st) HIP_CHECK(hipStreamWaitEvent(st, ev_last, 0));
+        if (!last_pending || last_stream == st) return;   // the usual case, one stream: nothing to do, nothing queued
+        // (an event recorded after EVERY call would put a barrier packet between consecutive kernels: ~2 us per call)
+        if (!ev_last) HIP_CHECK(hipEventCreateWithFlags(&ev_last, hipEventDisableTiming));
+        if (hipEventRecord(ev_last, last_stream) == hipSuccess) {
+            HIP_CHECK(hipStreamWaitEvent(st, ev_last, 0));
+        } else {                                          // the caller destroyed that stream: wait for whatever is left
+            (void)hipGetLastError();
+            HIP_CHECK(hipDeviceSynchronize());
+        }
+        last_pending = false;
     }
     void remember_async(hipStream_t st) {
-        if (!ev_last) HIP_CHECK(hipEventCreateWithFlags(&ev_last, hipEventDisableTiming));
-        HIP_CHECK(hipEventRecord(ev_last, st));
         last_stream = st;
         last_pending = true;
     }
