@@ -538,6 +538,15 @@ struct fr_renderer {
                 a.groups = bs.d_groups.as<uint32_t>();
                 a.group_off = bs.d_group_off.as<uint32_t>();
                 a.hist_dst = nullptr;   // (the schedule kernel does not append history)
+                // many small voices: whole voices per wave (gbank_multi_kernel), like bank_multi_kernel for balanced ones
+                a.voices_per_wave = 0;
+                if (allow_multi && bs.grp.max_leaves <= 512) {
+                    const uint64_t tiles = (blen + 63) / 64;
+                    uint32_t vpw = std::max<uint32_t>(1u, std::min<uint32_t>(8u, 256u / std::max<uint32_t>(bs.grp.max_leaves, 1u)));
+                    auto nb = [&](uint32_t per_wave) { return ((a.n_voices + 4ull * per_wave - 1) / (4ull * per_wave)) * tiles; };
+                    while (vpw > 1 && nb(vpw) < 2048) vpw >>= 1;
+                    if (nb(vpw) >= 1024) a.voices_per_wave = vpw;
+                }
                 Scope sc(this, &t_bank, st);
                 HIP_CHECK(launch_gbank(a, st));
                 sc.done();

@@ -879,9 +879,122 @@ __global__ void __launch_bounds__(256) gbank_kernel(BankArgs a, uint32_t tiles, 
     }
 }
 
+// Many small general voices: like bank_multi_kernel, a wave runs WHOLE voices (items + merge schedule), several in a
+// row, for one 64-frame tile; each wave has its own LDS stack; no barriers.
+template <bool FAST>
+__device__ __forceinline__ float gbank_voice(const float *params, const uint32_t *gmeta, uint32_t nitems, float t, float *stack /* [GB_MAX_DEPTH][64] + lane */) {
+    uint32_t sp = 0;
+    const_f32_ptr p = (const_f32_ptr)params;
+    typedef uint32_t __attribute__((address_space(4))) const *const_u32_ptr;
+    const_u32_ptr gm = (const_u32_ptr)gmeta;
+    auto finish = [&](float v, uint32_t meta) {
+        for (uint32_t m = meta >> 4; m != 0u; --m) {   // v = pop() + v
+            --sp;
+            v = stack[sp * 64u] + v;
+        }
+        stack[sp * 64u] = v;
+        ++sp;
+    };
+    uint32_t goff = 0;
+    for (uint32_t i = 0; i < nitems; ++i) {
+        const uint32_t meta = gm[i];
+        const uint32_t k = meta & 15u;
+        if (k > 3u) {
+            const float tt[1] = {t};
+            float res[1];
+            bank_wave_sum<1, FAST, false>(params + (size_t)goff * 16u, 1u << (k - 3u), k - 3u, tt, res);
+            finish(res[0], meta);
+            goff += 1u << (k - 3u);
+        } else {
+            ParamGroup cur;
+            load_group(cur, p, goff);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            finish(gbank_group<FAST>(cur, k, t), meta);
+            goff += 1u;
+        }
+    }
+    return stack[0];
+}
+
+__global__ void __launch_bounds__(256) gbank_multi_kernel(BankArgs a, uint32_t tiles, uint32_t nblocks) {
+    __shared__ float stack_mem[4][GB_MAX_DEPTH][64];
+    uint32_t b = blockIdx.x;
+    uint32_t lid = (nblocks % 8u == 0u) ? (b % 8u) * (nblocks / 8u) + b / 8u : b;
+    const uint32_t vb = lid / tiles, tile = lid - vb * tiles;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t ti = (uint64_t)tile * 64u + lane;
+    const float t = bank_time(a, ti);
+    const bool fast = a.fast_ok && __all(t >= 0.0f && t <= 4294967296.0f);
+    const bool live = ti < a.n_times;
+    float *stack = &stack_mem[wave][0][lane];
+    const uint32_t v0 = (vb * 4u + wave) * a.voices_per_wave;
+    for (uint32_t j = 0; j < a.voices_per_wave; ++j) {
+        const uint32_t voice = v0 + j;
+        if (voice >= a.n_voices) break;                      // wave-uniform
+        const uint32_t i0 = a.group_off[2u * voice], ni = a.group_off[2u * voice + 2u] - i0;
+        const float2 *vparams = a.params + (size_t)a.group_off[2u * voice + 1u] * 8u;
+        const float r = fast ? gbank_voice<true>((const float *)vparams, a.groups + i0, ni, t, stack)
+                             : gbank_voice<false>((const float *)vparams, a.groups + i0, ni, t, stack);
+        float *orow = a.out + (size_t)a.rows[voice] * a.out_stride;
+        if (live) orow[bank_out_index(a, ti)] = r;
+        // sign of exact zeros (see leaves_all_negzero), within the wave
+        unsigned long long zm = __ballot(live && r == 0.0f);
+        if (zm == 0ull) continue;
+        if (__builtin_popcountll(zm) > 4) {                  // a silent voice: all 64 frames in one pass over its items
+            bool ok = true;
+            uint32_t goff = 0;
+            for (uint32_t i = 0; i < ni; ++i) {
+                const uint32_t kk = a.groups[i0 + i] & 15u;
+                if (kk > 3u) {
+                    const float *q = (const float *)vparams + (size_t)goff * 16u;
+                    ok = (fast ? wave_leaves_all_negzero<true>(q, 1u << (kk - 3u), t) : wave_leaves_all_negzero<false>(q, 1u << (kk - 3u), t)) && ok;
+                    goff += 1u << (kk - 3u);
+                } else {
+                    for (uint32_t l = 0; l < (1u << kk); ++l) {
+                        const float2 pr = vparams[(size_t)goff * 8u + l];   // wave-uniform address
+                        const float lf = fast ? bank_leaf<true, true>(t, pr.x, pr.y) : bank_leaf<false, true>(t, pr.x, pr.y);
+                        ok = ok && __float_as_uint(lf) == 0x80000000u;
+                    }
+                    goff += 1u;
+                }
+            }
+            if ((zm >> lane) & 1ull) orow[bank_out_index(a, ti)] = ok ? -0.0f : 0.0f;
+            continue;
+        }
+        while (zm) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(zm);
+            zm &= zm - 1;
+            const uint64_t tz_i = (uint64_t)tile * 64u + l;
+            const float tz = bank_time(a, tz_i);
+            bool ok = true;
+            uint32_t pair0 = 0;
+            for (uint32_t i = 0; i < ni && ok; ++i) {
+                const uint32_t kk = a.groups[i0 + i] & 15u, sz = 1u << kk;
+                for (uint32_t q = lane; q < sz && ok; q += 64u) {
+                    float2 p = vparams[pair0 + q];
+                    ok = __float_as_uint(bank_leaf<false, true>(tz, p.x, p.y)) == 0x80000000u;
+                }
+                ok = __all(ok);
+                pair0 += sz < 8u ? 8u : sz;
+            }
+            if (lane == 0) orow[bank_out_index(a, tz_i)] = ok ? -0.0f : 0.0f;
+        }
+    }
+}
+
 hipError_t launch_gbank(const BankArgs &a, hipStream_t s) {
     if (!a.groups || !a.group_off) return hipErrorInvalidValue;
-    uint64_t tiles = (a.n_times + 63) / 64, nblocks64 = tiles * a.n_voices;   // one workgroup (4 waves) per (voice, tile)
+    const uint64_t tiles = (a.n_times + 63) / 64;
+    if (a.voices_per_wave) {   // many small voices: whole voices per wave
+        if (a.voices_per_wave > 64) return hipErrorInvalidValue;
+        const uint64_t nb = tiles * (((uint64_t)a.n_voices + 4ull * a.voices_per_wave - 1) / (4ull * a.voices_per_wave));
+        if (nb == 0) return hipSuccess;
+        if (nb > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(gbank_multi_kernel, dim3((uint32_t)nb), dim3(256), 0, s, a, (uint32_t)tiles, (uint32_t)nb);
+        return hipGetLastError();
+    }
+    const uint64_t nblocks64 = tiles * a.n_voices;   // one workgroup (4 waves) per (voice, tile)
     if (nblocks64 == 0) return hipSuccess;
     if (nblocks64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gbank_kernel, dim3((uint32_t)nblocks64), dim3(256), 0, s, a, (uint32_t)tiles, (uint32_t)nblocks64);

@@ -237,6 +237,37 @@ def test_many_small_voices_kernel(hip_lib, oracle_lib, monkeypatch):
                 assert same_bits(outs["1"][0][:V, c:c + 1], exp[:V]), f"V={V} P={P} frame {c}: " + first_diff(outs["1"][0][:V, c:c + 1], exp[:V])
 
 
+def test_many_small_general_voices_kernel(hip_lib, oracle_lib, monkeypatch):
+    """The same for voices that are not balanced trees (24, 100, 300 partials): gbank_multi_kernel vs the one-voice-per-
+    workgroup schedule kernel (FR_BANK_MULTI=0) on the full output, and vs the oracle on the first frames."""
+    for V, P, T in ((1400, 24, 900), (700, 100, 700), (300, 300, 1100)):
+        base = synth.voice_params(64, P, seed=4)
+        reps = V // 64 + 1
+        w = (np.tile(base["w"], (reps, 1))[:V] * (1.0 + 1e-4 * (np.arange(V) // 64))[:, None]).astype(np.float32)
+        amp = np.tile(base["amp"], (reps, 1))[:V].copy()
+        amp[3, :] = 0.0
+        amp[4, :] = -0.0
+        amp[5, 1::2] = 0.0
+        g = synth.GraphArrays()
+        leaves = synth.partial_leaves(g, w, amp).reshape(V, P)
+        g.edge(synth.sum_tree(g, leaves), 0, 0, np.arange(V, dtype=np.uint32))
+        tree = g.finish(V)
+        rows = [synth.time_ramp(0, T), np.concatenate([-synth.time_ramp(0, 64), [np.nan, np.inf, -0.0, 1e30], synth.time_ramp(0, T - 68)]).astype(np.float32)]
+        outs = {}
+        for multi in ("1", "0"):
+            monkeypatch.setenv("FR_BANK_MULTI", multi)
+            with Renderer(hip_lib) as hip:
+                synth.install(hip, tree)
+                outs[multi] = [hip.fill_buffer(V, i * T, (i + 1) * T, [row]) for i, row in enumerate(rows)]
+                assert any(b["general_tree"] for b in hip.plan()["banks"])
+        for i in range(len(rows)):
+            assert same_bits(outs["1"][i], outs["0"][i]), f"V={V} P={P} row {i}: " + first_diff(outs["1"][i], outs["0"][i])
+        with Renderer(oracle_lib) as ref:
+            synth.install(ref, tree)
+            exp = ref.fill_buffer(V, 0, 66, [rows[0][:66]])
+            assert same_bits(outs["1"][0][:, :66], exp), f"V={V} P={P}: " + first_diff(outs["1"][0][:, :66], exp)
+
+
 def test_bank_negative_frequency_and_mixed_outputs(hip_lib, oracle_lib):
     """A voice with negative w (general fract path), next to outputs that are not banks: the bank delayed by 5
     frames (staged: the bank fills a ring, two small programs read it) and the time input itself."""

@@ -1,5 +1,5 @@
 """Bank throughput over voice shapes: V voices x P partials with V*P fixed, 4800-frame and 512-frame calls (device entry
-point, audible fundamentals for any V).   python tools/shape_sweep.py [total_partials]"""
+point, audible fundamentals for any V).   python tools/shape_sweep.py [total_partials [P1,P2,...]]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -8,7 +8,8 @@ import libfriendship_amd
 from libfriendship_amd import synth
 
 total = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
-for P in (32, 64, 128, 256, 512, 1000, 1024, 2048, 4096, 8192, 16384):
+SHAPES = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (32, 64, 128, 256, 512, 1000, 1024, 2048, 4096, 8192, 16384)
+for P in SHAPES:
     V = max(1, total // P)
     base = synth.voice_params(min(V, 64), P, 0x5EED0002)
     reps = V // 64 + 1
