@@ -528,6 +528,12 @@ struct fr_renderer {
                 j.log2_p = a.log2_p;
                 j.tiles = (uint32_t)((blen + 63) / 64);
                 j.nblocks = j.tiles * j.n_voices;
+                if (allow_multi && a.log2_p <= 8 && bs.jit->fn_multi) {   // many small voices: whole voices per wave
+                    uint32_t vpw = std::max(2u, 256u >> a.log2_p);
+                    auto nb = [&](uint32_t per_wave) { return ((a.n_voices + 4ull * per_wave - 1) / (4ull * per_wave)) * j.tiles; };
+                    while (vpw > 1 && nb(vpw) < 2048) vpw >>= 1;
+                    if (nb(vpw) >= 1024) { j.voices_per_wave = vpw; j.nblocks = (uint32_t)nb(vpw); }
+                }
                 j.fract_ok = bs.grp.fast_ok ? 1u : 0u;
                 Scope sc(this, &t_bank, st);
                 HIP_CHECK(launch_jit_bank(*bs.jit, j, st));

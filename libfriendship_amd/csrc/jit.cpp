@@ -90,6 +90,38 @@ extern "C" __global__ void __launch_bounds__(256) jit_bank(JitBankArgs a) {
         a.out[(size_t)a.rows[voice] * a.out_stride + o] = t;
     }
 }
+
+// Many small voices: a wave sums WHOLE voices, voices_per_wave in a row, for one tile (see bank_multi_kernel in kernels.hip)
+extern "C" __global__ void __launch_bounds__(256) jit_bank_multi(JitBankArgs a) {
+    unsigned b = blockIdx.x;
+    unsigned lid = (a.nblocks % 8u == 0u) ? (b % 8u) * (a.nblocks / 8u) + b / 8u : b;
+    const unsigned vb = lid / a.tiles, tile = lid - vb * a.tiles;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long ti = (unsigned long long)tile * 64u + lane;
+    float x[NIN > 0 ? NIN : 1];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i)
+        x[i] = (ti >= a.in_skip[i] && ti - a.in_skip[i] < a.in_valid[i]) ? a.in[i][ti - a.in_skip[i]] : 0.0f;
+    bool fast = false;
+#if HAS_MOD1
+    bool in_range = a.fract_ok != 0u;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i)
+        if ((FRACT_INPUTS >> i) & 1u) in_range = in_range && __builtin_bit_cast(unsigned, x[i]) <= 0x4F800000u;
+    fast = __builtin_amdgcn_ballot_w64(!in_range) == 0ull;
+#endif
+    const unsigned P = 1u << a.log2_p, ngroups = P >> 3, levels = a.log2_p - 3u;
+    const unsigned v0 = (vb * 4u + wave) * a.voices_per_wave;
+    const unsigned long long o = a.ring_mask ? ((a.ring_t0 + ti) & a.ring_mask) : ti;
+    for (unsigned j = 0; j < a.voices_per_wave; ++j) {
+        const unsigned voice = v0 + j;
+        if (voice >= a.n_voices) break;
+        cptr p = (cptr)(a.params + (size_t)voice * P * K);
+        const float r = fast ? wave_sum<true>(p, x, ngroups, levels) : wave_sum<false>(p, x, ngroups, levels);
+        if (ti < a.n_times) a.out[(size_t)a.rows[voice] * a.out_stride + o] = r;
+    }
+}
 )JIT";
 
 std::string JitCache::generate_source(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
@@ -151,6 +183,7 @@ std::shared_ptr<JitKernel> JitCache::get_source(const std::string &src, const ch
     auto jk = std::make_shared<JitKernel>();
     if (hipModuleLoadData(&jk->module, code.data()) != hipSuccess) throw Error(FR_ERR_DEVICE, "jit: hipModuleLoadData failed");
     if (hipModuleGetFunction(&jk->fn, jk->module, fn_name) != hipSuccess) throw Error(FR_ERR_DEVICE, "jit: kernel symbol missing");
+    if (std::string(fn_name) == "jit_bank" && hipModuleGetFunction(&jk->fn_multi, jk->module, "jit_bank_multi") != hipSuccess) jk->fn_multi = nullptr;
     compile_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ++compiled_;
     cache_.emplace(src, jk);
@@ -161,7 +194,7 @@ hipError_t launch_jit_bank(const JitKernel &k, const JitBankArgs &a, hipStream_t
     if (a.nblocks == 0) return hipSuccess;
     JitBankArgs copy = a;
     void *args[] = {&copy};
-    return hipModuleLaunchKernel(k.fn, a.nblocks, 1, 1, 256, 1, 1, 0, s, args, nullptr);
+    return hipModuleLaunchKernel(a.voices_per_wave && k.fn_multi ? k.fn_multi : k.fn, a.nblocks, 1, 1, 256, 1, 1, 0, s, args, nullptr);
 }
 
 hipError_t launch_jit_stage(const JitKernel &k, const JitStageArgs &a, uint32_t n_progs, hipStream_t s) {

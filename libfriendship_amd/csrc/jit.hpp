@@ -46,6 +46,7 @@ namespace fr {
         unsigned int tiles;                                                                                    \
         unsigned int nblocks;                                                                                  \
         unsigned int fract_ok;          /* host-proved: Modulo(x, 1) == fract(x) for inputs in [+0, 2^32] */   \
+        unsigned int voices_per_wave;   /* > 0: jit_bank_multi, nblocks = tiles * ceil(n_voices / (4 * this)) */ \
     };
 FR_JIT_ARGS_TEXT
 
@@ -98,6 +99,7 @@ LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> 
 struct JitKernel {
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
+    hipFunction_t fn_multi = nullptr;   // bank modules: the whole-voices-per-wave kernel for many small voices
     uint32_t k = 0;                     // varying constants per leaf
     ~JitKernel();
 };

@@ -953,6 +953,30 @@ def test_template_voices_through_generated_kernel(hip_lib, oracle_lib, monkeypat
         assert plan["banks"] and all(b["jit"] for b in plan["banks"]), plan
 
 
+def test_many_small_generated_voices_kernel(hip_lib, oracle_lib, monkeypatch):
+    """hipRTC-specialised voices (triangle leaves, one amplitude-modulated) in the many-small-voices form
+    (jit_bank_multi) against the one-voice-per-workgroup form (FR_BANK_MULTI=0) and the oracle."""
+    for V, P, T, am in ((1100, 32, 1100, False), (600, 64, 800, True)):
+        tree = _triangle_tree(V, P, am, False)
+        rng = np.random.default_rng(P)
+        rows = [[synth.time_ramp(0, T), (rng.normal(size=T) * 2).astype(np.float32)],
+                [np.concatenate([-synth.time_ramp(0, 64), [np.nan, np.inf, -0.0, 1e30], synth.time_ramp(0, T - 68)]).astype(np.float32),
+                 (rng.normal(size=T) * 2).astype(np.float32)]]
+        outs = {}
+        for multi in ("1", "0"):
+            monkeypatch.setenv("FR_BANK_MULTI", multi)
+            with Renderer(hip_lib) as hip:
+                synth.install(hip, tree)
+                outs[multi] = [hip.fill_buffer(V, i * T, (i + 1) * T, r) for i, r in enumerate(rows)]
+                assert any(b["jit"] for b in hip.plan()["banks"])
+        for i in range(len(rows)):
+            assert same_bits(outs["1"][i], outs["0"][i]), f"V={V} P={P} row {i}: " + first_diff(outs["1"][i], outs["0"][i])
+        with Renderer(oracle_lib) as ref:
+            synth.install(ref, tree)
+            exp = ref.fill_buffer(V, 0, 66, [rows[0][0][:66], rows[0][1][:66]])
+            assert same_bits(outs["1"][0][:, :66], exp), f"V={V} P={P}: " + first_diff(outs["1"][0][:, :66], exp)
+
+
 def test_jit_disabled_gives_the_same_bits(hip_lib, monkeypatch):
     """FR_JIT=0: the same voices run as stage programs / pull instead of a specialised kernel; identical output."""
     tree = _triangle_tree(2, 32, am=True)
