@@ -106,6 +106,9 @@ def run():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl is RCCL on ROCm (default)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even with one rank and take the partial-shard exchange path (RCCL plumbing check)")
+    ap.add_argument("--wrap-voices", type=int, default=0,
+                    help="effects tree only, shape sweeps: fundamentals repeat every N voices (synth.voice_params wrap); the "
+                         "survey's 55*2^(v/12) puts voices beyond v~150 above any representable pitch (identically zero mixes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--short-blocks", action="store_true",
                     help="after the timed region also time 64- and 512-frame calls (SURVEY.md 8d) -> `short_blocks`; off by "
@@ -146,7 +149,7 @@ def run():
     # holds only its sub-graph
     if args.tree in ("effects", "chorus"):
         assert world == 1, "the effects and chorus trees are single-GPU diagnostics"
-        tree = synth.effects_tree(V, P) if args.tree == "effects" else synth.chorus_tree(V, P, taps=4)
+        tree = synth.effects_tree(V, P, wrap=args.wrap_voices or None) if args.tree == "effects" else synth.chorus_tree(V, P, taps=4)
         shard_info = {"partials": (0, P), "voices": (0, V), "mode": "time"}
     else:
         tree, shard_info = shard.additive_tree_shard(V, P, rank, world, shard_mode)

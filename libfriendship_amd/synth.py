@@ -152,12 +152,18 @@ def sum_tree(g, leaves):
     return cur[:, 0]
 
 
-def voice_params(n_voices, n_partials, seed, detune=False, sr=48000.0):
+def voice_params(n_voices, n_partials, seed, detune=False, sr=48000.0, wrap=None):
     """SURVEY.md 8d parameters, every step rounded to f32 like a graph of f32 primitives would:
-    f0_v = 55*2^(v/12); f = f0_v*(k+1) [*(1+delta)]; w = f/sr; amp = 1/(k+1)."""
+    f0_v = 55*2^(v/12); f = f0_v*(k+1) [*(1+delta)]; w = f/sr; amp = 1/(k+1).
+    `wrap` (not part of the survey's definition; shape sweeps only): fundamentals repeat every `wrap` voices, each
+    repetition detuned by 1e-4 so that voices stay distinct -- with hundreds of voices the survey's formula puts most
+    fundamentals far above any audible or even representable pitch (every t*w beyond 2^23: identically zero mixes)."""
     v = np.arange(n_voices, dtype=np.float64)[:, None]
     k1 = np.arange(1, n_partials + 1, dtype=np.float32)[None, :]
-    f0 = (55.0 * 2.0 ** (v / 12.0)).astype(np.float32)
+    if wrap:
+        f0 = (55.0 * 2.0 ** ((v % wrap) / 12.0) * (1.0 + 1e-4 * (v // wrap))).astype(np.float32)
+    else:
+        f0 = (55.0 * 2.0 ** (v / 12.0)).astype(np.float32)
     f = (f0 * k1).astype(np.float32)
     delta = None
     if detune:
@@ -211,9 +217,9 @@ def delay_chain(g, x, taps=4, base_delay=2400.0):
 
 
 def effects_tree(n_voices, n_partials, seed=0x5EED0003, detune=True, envelope=True, taps=4, base_delay=2400.0,
-                 sr=48000.0, time_slot=0):
+                 sr=48000.0, time_slot=0, wrap=None):
     """config D: harmonics + per-partial detune + ADSR envelope + delay chain, one output slot per voice."""
-    p = voice_params(n_voices, n_partials, seed, detune, sr)
+    p = voice_params(n_voices, n_partials, seed, detune, sr, wrap)
     g = GraphArrays()
     leaves = partial_leaves(g, p["w"], p["amp"], time_slot).reshape(n_voices, n_partials)
     x = sum_tree(g, leaves)
