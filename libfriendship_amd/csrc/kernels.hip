@@ -643,7 +643,7 @@ void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &
     // 2 or 4 frames per lane amortise it (measured with tools/bank_bench: 32 partials 2.1 -> 3.2 T partial-frames/s,
     // 128 partials 5.3 -> 6.2, 512 partials 8.5 -> 8.8; at 4096 one frame per lane is best)
     if (n_times >= 1024 && blocks >= 4096) frames_per_lane = log2_p <= 7 ? 4 : (log2_p <= 9 ? 2 : 1);
-    if (n_times >= 512 && blocks < 1024 && log2_p >= 10) {
+    if (n_times >= 512 && blocks < 320 && log2_p >= 10) {
         // a few big voices on a long call: too few workgroups to hide the scalar-load latency of the parameter stream
         // (one 8-wave workgroup per tile leaves a SIMD with 1-2 waves).  Split the voices into chunks of >= 512 partials,
         // about 1024 workgroups in all, plus the combine pass (tools/bank_bench: 1 x 16384 at 4800 frames 25.7 -> 21.4 us,
@@ -656,7 +656,8 @@ void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &
         frames_per_lane = 1;
         return;
     }
-    waves_per_group = (log2_p >= 14 || (blocks < 512 && log2_p >= 6)) ? 8 : 4;
+    // (64 x 4096 at 512 / 1024 frames, 512 / 1024 workgroups: 8 waves 20.7 / 32.3 us, 4 waves 23.4 / 35.5 us, chunks of 2^11 35 / 47 us)
+    waves_per_group = (log2_p >= 14 || (blocks < 2048 && log2_p >= 6)) ? 8 : 4;
     const uint32_t cmax = waves_per_group == 8 ? 14 : 13;
     chunk_log2 = log2_p < cmax ? log2_p : cmax;
 }
