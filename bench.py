@@ -109,10 +109,14 @@ def run():
     ap.add_argument("--wrap-voices", type=int, default=0,
                     help="effects tree only, shape sweeps: fundamentals repeat every N voices (synth.voice_params wrap); the "
                          "survey's 55*2^(v/12) puts voices beyond v~150 above any representable pitch (identically zero mixes)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="issue consecutive steps round-robin on this many HIP streams (each with its own output buffer): calls "
+                         "of a plan without delay state are independent and the engine lets them overlap on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--short-blocks", action="store_true",
-                    help="after the timed region also time 64- and 512-frame calls (SURVEY.md 8d) -> `short_blocks`; off by "
-                         "default so that the default command launches only the timed workload's kernels (rocprof summaries)")
+    ap.add_argument("--extras", "--short-blocks", dest="short_blocks", action="store_true",
+                    help="after the timed region also time (a) the same steps overlapped on two streams -> `overlapped_calls` and "
+                         "(b) 64- and 512-frame calls (SURVEY.md 8d) -> `short_blocks`; off by default so that the default command "
+                         "launches only the timed workload's kernels (rocprof summaries)")
     ap.add_argument("--cpu-frames", type=int, default=144,
                     help="frames the CPU path renders single-threaded for cpu_baseline and the parity check (about 12 s)")
     args = ap.parse_args()
@@ -177,11 +181,18 @@ def run():
         log(f"[rank {rank}] {n_calls} calls share a ring of {ring_steps} resident input rows")
     d_out = torch.empty((max(V_local, 1), T), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    n_streams = max(1, args.streams)
+    side_streams = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else []
+    side_outs = [torch.empty_like(d_out) for _ in range(n_streams)] if n_streams > 1 else []
     d_mixes = [torch.empty_like(d_out) for _ in range(world)] if shard_mode == "partials" else None
 
     def step(k):
         r = k % ring_steps
         row = d_time[r * T:(r + 1) * T]
+        if side_streams and shard_mode != "partials":
+            hip.fill_buffer_device(side_outs[k % n_streams].data_ptr(), V_local, T, stripe0 + k * T, row.data_ptr(), [0, T],
+                                   side_streams[k % n_streams].cuda_stream)
+            return side_outs[k % n_streams]
         hip.fill_buffer_device(d_out.data_ptr(), V_local, T, stripe0 + k * T, row.data_ptr(), [0, T], stream)
         if shard_mode == "partials":
             # the one exchange step of the path: every rank's partial mix to every rank (RCCL over xGMI), then the
@@ -217,7 +228,7 @@ def run():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
-    last = d_out.cpu().numpy()
+    last = (side_outs[(W + K - 1) % n_streams] if side_streams and shard_mode != "partials" else d_out).cpu().numpy()
 
     # kernel-level timing for the roofline: same steps again with HIP events around every launch, recorded
     # on the stream the kernels run on (engine-side, fr_set_timing); a seek back to the stripe start.
@@ -240,6 +251,30 @@ def run():
         for k in range(1, 6):
             hip.fill_buffer(V_local, stripe0 + k * T, stripe0 + (k + 1) * T, [ramp_row(k)])
         host_rate = 5 * T / (time.perf_counter() - th) / 1e6
+
+    # independent calls overlapped on two streams (an extra, never `value`): for a plan without delay state the engine
+    # lets consecutive calls issued on different streams run concurrently, which fills the tail of each launch
+    overlapped = None
+    if args.short_blocks and rank == 0 and world == 1 and n_streams == 1 and not plan.get("rings") and not plan.get("stage_programs") and not plan.get("pull_rows"):
+        s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+        o2 = [torch.empty_like(d_out), torch.empty_like(d_out)]
+        base_k = 2 * (W + K) + 4
+
+        def step2(k):
+            row = d_time[(k % ring_steps) * T:][:T]
+            hip.fill_buffer_device(o2[k % 2].data_ptr(), V_local, T, stripe0 + k * T, row.data_ptr(), [0, T], s2[k % 2].cuda_stream)
+
+        for k in range(base_k, base_k + W):      # the first of these is a seek forward
+            step2(k)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for k in range(base_k + W, base_k + W + K):
+            step2(k)
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t2
+        overlapped = {"streams": 2, "value": K * T / e2 / 1e6, "unit": "Msamples/s", "ms_per_step": e2 / K * 1e3,
+                      "note": "same K steps issued round-robin on 2 HIP streams with separate output buffers; kernels of consecutive "
+                              "calls overlap, so per-launch durations are not comparable with the sequential run above"}
 
     # short blocks ("also report T in {64, 512}"): latency of one call through the device entry point
     short_blocks = None
@@ -316,6 +351,7 @@ def run():
         "roofline": roofline,
         "host_buffer_api_msamples_per_s": host_rate,
         "short_blocks": short_blocks,
+        "overlapped_calls": overlapped,
     }
     # HBM traffic per launch from PMC counters: rocprofv3 cannot wrap a process from inside it, so the figure is
     # read from the committed summary of the separate --pmc passes of this same command (profiles/).

@@ -144,8 +144,28 @@ struct fr_renderer {
     hipEvent_t ev_last = nullptr;
     hipStream_t last_stream = nullptr;   // stream of the last asynchronous call while its work may still be running
     bool last_pending = false;
-    void order_after_previous(hipStream_t st) {
-        if (!last_pending || last_stream == st) return;   // the usual case, one stream: nothing to do, nothing queued
+    bool last_independent = false;       // the last asynchronous call left nothing behind that a later call reads or reuses
+    bool used_scratch = false;           // this call used a buffer shared between calls (the chunk workspace)
+    bool overlapped_streams = false;     // independent calls were let loose on more than one stream since the last ordering point
+    // Calls of a plan without delay lines, programs or pull rows touch only their own input rows and output buffer (and
+    // append their own, disjoint part of the input history): on different streams they may overlap on the device.
+    bool plan_is_stateless(uint32_t n_slots) const {
+        return plan.valid && plan.version == mirror.version && plan.n_slots == n_slots && !plan.sp.uses_rings() && plan.sp.progs.empty() &&
+               plan.pull_rows.empty();
+    }
+    void order_after_previous(hipStream_t st, bool this_independent = false) {
+        if (!last_pending) return;
+        if (overlapped_streams && !this_independent) {    // several streams may hold unfinished calls: wait for all of them
+            HIP_CHECK(hipDeviceSynchronize());
+            overlapped_streams = false;
+            last_pending = false;
+            return;
+        }
+        if (last_stream == st) return;                    // the usual case, one stream: nothing to do, nothing queued
+        if (last_independent && this_independent) {       // independent work on another stream: let it overlap
+            overlapped_streams = true;
+            return;
+        }
         // (an event recorded after EVERY call would put a barrier packet between consecutive kernels: ~2 us per call)
         if (!ev_last) HIP_CHECK(hipEventCreateWithFlags(&ev_last, hipEventDisableTiming));
         if (hipEventRecord(ev_last, last_stream) == hipSuccess) {
@@ -156,7 +176,8 @@ struct fr_renderer {
         }
         last_pending = false;
     }
-    void remember_async(hipStream_t st) {
+    void remember_async(hipStream_t st, bool independent) {
+        last_independent = independent;
         last_stream = st;
         last_pending = true;
     }
@@ -232,6 +253,7 @@ struct fr_renderer {
         DevBuf nb;
         nb.ensure(cap * sizeof(float));
         uint64_t stored = s.len - s.base;
+        if (last_pending) HIP_CHECK(hipDeviceSynchronize());   // a call on another stream may still be appending to the old buffer
         if (stored) HIP_CHECK(hipMemcpyAsync(nb.p, s.buf.p, stored * sizeof(float), hipMemcpyDeviceToDevice, st));
         HIP_CHECK(hipStreamSynchronize(st));   // old buffer is freed below
         s.buf = std::move(nb);
@@ -566,6 +588,7 @@ struct fr_renderer {
             if (a.small_call && a.hist_dst) throw Error(FR_ERR_DEVICE, "internal: deferred history append on a short call");
             a.leaf_variant = bank_leaf_variant;
             if (a.chunk_log2 != a.log2_p) {
+                used_scratch = true;
                 d_bank_ws.ensure(((size_t)a.n_voices << (a.log2_p - a.chunk_log2)) * blen * sizeof(float));
                 a.ws = d_bank_ws.as<float>();
             }
@@ -805,7 +828,7 @@ fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t 
         r->execute(r->d_out.as<float>(), n_slots, n_times, idx, st);
         if (bytes) HIP_CHECK(hipMemcpyAsync(out, r->d_out.p, bytes, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));   // synchronous contract: dispatch.rs:150-151
-        r->last_pending = false;               // everything issued so far, on any stream, is complete
+        r->last_pending = false;               // everything issued so far, on any stream, is complete (order_after_previous)
         r->head = idx + n_times;               // reference.rs:84
     });
 }
@@ -817,10 +840,12 @@ fr_status fr_fill_buffer_device(fr_renderer *r, float *d_out, uint32_t n_slots, 
         check_fill_args(d_out, n_slots, n_times, d_in_data, in_row_offsets, n_in_rows);
         HIP_CHECK(hipSetDevice(r->device));
         hipStream_t st = (hipStream_t)stream;
-        r->order_after_previous(st);
+        const bool independent = r->plan_is_stateless(n_slots) && idx == r->head;   // (a seek or a new plan orders everything)
+        r->order_after_previous(st, independent);
+        r->used_scratch = false;
         r->store_inputs(n_slots, n_times, idx, d_in_data, in_row_offsets, n_in_rows, true, st);
         r->execute(d_out, n_slots, n_times, idx, st);
-        r->remember_async(st);
+        r->remember_async(st, independent && !r->used_scratch);
         r->head = idx + n_times;
     });
 }

@@ -422,6 +422,45 @@ def test_calls_on_different_streams_are_ordered(hip_lib, oracle_lib):
             assert same_bits(got, exp), f"call {k}: " + first_diff(got, exp)
 
 
+def test_independent_calls_overlap_on_two_streams(hip_lib, oracle_lib):
+    """A plan without delay state: consecutive device-entry calls on alternating streams are not ordered against each
+    other (they overlap on the device); each still renders its own frames exactly, the input history they append stays
+    intact (a Delay added afterwards reads it), and a dependent call (a seek; the host entry point) waits for all."""
+    import torch
+    V, P, T, calls = 8, 512, 2048, 8
+    tree = synth.additive_tree(V, P)
+    t = synth.time_ramp(0, (calls + 2) * T)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        d_t = torch.from_numpy(t).cuda()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [torch.empty((V, T), dtype=torch.float32, device="cuda") for _ in range(calls)]
+        torch.cuda.synchronize()
+        for k in range(calls):
+            row = d_t[k * T:(k + 1) * T]
+            hip.fill_buffer_device(outs[k].data_ptr(), V, T, k * T, row.data_ptr(), [0, T], streams[k % 2].cuda_stream)
+        # host entry point right behind them: must wait for both streams, then continue the same timeline
+        host = hip.fill_buffer(V, calls * T, (calls + 1) * T, [t[calls * T:(calls + 1) * T]])
+        torch.cuda.synchronize()
+        for k in range(calls):
+            c = [0, 1, T - 1, 777]
+            got = outs[k].cpu().numpy()
+            for col in c:   # the oracle by random access (no Delay in the graph)
+                exp = ref.fill_buffer(V, k * T + col, k * T + col + 1, [t[k * T + col:k * T + col + 1]])
+                assert same_bits(got[:, col:col + 1], exp), f"call {k} frame {col}: " + first_diff(got[:, col:col + 1], exp)
+        exp = ref.fill_buffer(V, calls * T + 5, calls * T + 6, [t[calls * T + 5:calls * T + 6]])
+        assert same_bits(host[:, 5:6], exp)
+        # the history the overlapped calls appended: a Delay of the time input by 3000 frames, rendered next
+        hip.on_add_node(900001, "Delay")
+        hip.on_add_edge(0, 900001, 0, 0)
+        hip.on_add_edge(synth.CONST_HANDLE, 900001, f32_bits(3000.0), 1)
+        hip.on_add_edge(900001, 0, 0, V)
+        a, b = (calls + 1) * T, (calls + 2) * T
+        got = hip.fill_buffer(V + 1, a, b, [t[a:b]])
+        assert same_bits(got[V], t[a - 3000:b - 3000]), first_diff(got[V], t[a - 3000:b - 3000])
+
+
 def test_device_calls_keep_input_history(hip_lib, oracle_lib):
     """With device-resident full rows the bank kernel itself appends the time row to the slot's history;
     a Delay on the same input must still see earlier calls' samples (tests/ext_input.rs:108-121 semantics)."""
