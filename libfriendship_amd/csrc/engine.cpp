@@ -264,10 +264,22 @@ struct fr_renderer {
     // the caller's row directly and appends it to the history itself (BankArgs::hist_dst).
     struct Deferred { uint32_t slot; const float *src; float *dst; };
     std::vector<Deferred> deferred;
-    bool bank_time_slot(uint32_t n_slots, uint64_t n_times, uint32_t slot) const {
+    // Will execute() render exactly [idx, idx + n_times) for the staged part (steady state), or rebuild a look-back
+    // window first?  Same conditions as execute() uses (ring capacity, contiguity with what the rings hold).
+    bool steady_call(uint64_t idx, uint64_t n_times) const {
+        const StagedPlan &sp = plan.sp;
+        if (!sp.uses_rings()) return true;
+        uint64_t need = sp.lmax + n_times, cap = 1024;
+        while (cap < need) cap <<= 1;
+        if (cap > ring_cap || (size_t)sp.n_rings * ring_cap * sizeof(float) > d_rings.bytes) return false;
+        return plan.stage_valid && plan.stage_end == idx;
+    }
+    bool bank_time_slot(uint32_t n_slots, uint64_t n_times, uint32_t slot, uint64_t idx) const {
         if (!plan.valid || plan.version != mirror.version || plan.n_slots != n_slots) return false;
         if (n_times <= 2) return false;   // the shortest calls use bank_small_kernel, which does not append history
-        if (plan.sp.uses_rings() || !plan.sp.progs.empty()) return false;   // windows with look-back read the stored history
+        // a window with look-back reads the stored history, so the row must be there first; in steady state the bank
+        // launch (always ahead of the programs on the stream) reads the caller's row and appends it like any other
+        if ((plan.sp.uses_rings() || !plan.sp.progs.empty()) && !steady_call(idx, n_times)) return false;
         bool any = false;
         for (const BankStage &bs : plan.banks) {
             if (bs.grp.jit) {
@@ -312,7 +324,7 @@ struct fr_renderer {
             uint64_t stored = s.len - s.base;
             grow(s, stored + n_times, st);
             float *dst = s.buf.as<float>() + stored;
-            if (device_rows && rl == n_times && rl > 0 && bank_time_slot(n_slots, n_times, r)) {
+            if (device_rows && rl == n_times && rl > 0 && bank_time_slot(n_slots, n_times, r, idx)) {
                 deferred.push_back(Deferred{r, in_data + offs[r], dst});
             } else if (device_rows) {
                 if (rl) HIP_CHECK(hipMemcpyAsync(dst, in_data + offs[r], rl * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -505,7 +517,7 @@ struct fr_renderer {
                 a.time = di.data + (start - di.base);
                 a.time_valid = di.len > start ? di.len - start : 0;
             }
-            if (!ring)
+            if (b0 == idx && blen == n_times)   // (direct output, or a ring in steady state)
                 for (Deferred &d : deferred)
                     if (d.slot == bs.grp.input_slot) {   // read the caller's row; the first bank on this slot appends it
                         a.time = d.src;
@@ -597,6 +609,8 @@ struct fr_renderer {
             sc.done();
         }
 
+        for (const Deferred &d : deferred)
+            if (d.dst) throw Error(FR_ERR_DEVICE, "internal: an input row deferred to the bank launch was not appended");
         if (!sp.progs.empty()) {
             std::vector<DevInput> tab(sp.input_slots.size());
             for (size_t i = 0; i < tab.size(); ++i) tab[i] = dev_input(sp.input_slots[i]);

@@ -461,6 +461,39 @@ def test_independent_calls_overlap_on_two_streams(hip_lib, oracle_lib):
         assert same_bits(got[V], t[a - 3000:b - 3000]), first_diff(got[V], t[a - 3000:b - 3000])
 
 
+def test_ring_banks_append_history_in_steady_state(hip_lib, oracle_lib):
+    """Effects chain through the device entry point: once the delay rings are in steady state the bank launch reads
+    the caller's time row directly and appends it to the input history itself (no separate copy).  The history must be
+    complete afterwards: an edit adds a Delay of the time input reaching back over all those calls."""
+    import torch
+    V, T, calls = 3, 1024, 5
+    tree = synth.effects_tree(V, 64, taps=2, base_delay=300.0)
+    t = synth.time_ramp(0, (calls + 1) * T)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        d_t = torch.from_numpy(t).cuda()
+        d_out = torch.empty((V, T), dtype=torch.float32, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        for k in range(calls):
+            row = d_t[k * T:(k + 1) * T]
+            hip.fill_buffer_device(d_out.data_ptr(), V, T, k * T, row.data_ptr(), [0, T], s)
+            torch.cuda.synchronize()
+            exp = ref.fill_buffer(V, k * T, (k + 1) * T, [t[k * T:(k + 1) * T]])
+            assert same_bits(d_out.cpu().numpy(), exp), f"call {k}: " + first_diff(d_out.cpu().numpy(), exp)
+        for r in (hip, ref):
+            r.on_add_node(900001, "Delay")
+            r.on_add_edge(0, 900001, 0, 0)
+            r.on_add_edge(synth.CONST_HANDLE, 900001, f32_bits(float(calls * T - 7)), 1)
+            r.on_add_edge(900001, 0, 0, V)
+        a, b = calls * T, (calls + 1) * T
+        d_out2 = torch.empty((V + 1, T), dtype=torch.float32, device="cuda")
+        hip.fill_buffer_device(d_out2.data_ptr(), V + 1, T, a, d_t[a:b].data_ptr(), [0, T], s)
+        torch.cuda.synchronize()
+        exp = ref.fill_buffer(V + 1, a, b, [t[a:b]])
+        assert same_bits(d_out2.cpu().numpy(), exp), first_diff(d_out2.cpu().numpy(), exp)
+
+
 def test_device_calls_keep_input_history(hip_lib, oracle_lib):
     """With device-resident full rows the bank kernel itself appends the time row to the slot's history;
     a Delay on the same input must still see earlier calls' samples (tests/ext_input.rs:108-121 semantics)."""
