@@ -86,6 +86,10 @@ struct Planner {
     // Delay node n with a non-constant amount: can it be staged, and with what bound?
     bool dynamic_delay_ok(uint32_t n) {
         if (dyn_max.count(n)) return true;
+        if (is_leaf(g.nodes[n].a)) {   // an input or a constant delayed by a signal: read from the input history (kept in
+            dyn_max[n] = 0xFFFFFFFFull;   // full), no ring, so no bound is needed
+            return true;
+        }
         Range r = range(g.nodes[n].b);
         if (!(r.hi < 2147483648.0)) return false;   // unbounded (or NaN bound)
         dyn_max[n] = r.hi <= 0.0 ? 0 : (uint64_t)r.hi;

@@ -456,12 +456,14 @@ static void effects_chain_is_staged() {
 static void dynamic_delay_goes_to_pull() {
     Build b;
     uint32_t amt = b.op(FR_PRIM_MULTIPLY, In(0), Cf(0.25f));   // no bound can be proven for this amount
-    uint32_t d = b.op(FR_PRIM_DELAY, In(1), N(amt));
-    b.out(N(d), 0);
+    uint32_t src = b.op(FR_PRIM_MULTIPLY, In(1), Cf(2.0f));    // a computed signal: delaying it needs a ring, hence a bound
+    b.out(N(b.op(FR_PRIM_DELAY, N(src), N(amt))), 0);
     b.out(N(b.op(FR_PRIM_SUM2, In(1), Cf(1.0f))), 1);
-    check_graph(b, 2, 20, 2, true, "dynamic delay", [](const FlatGraph &, const StagedPlan &sp) {
+    b.out(N(b.op(FR_PRIM_DELAY, In(1), N(amt))), 2);           // an input delayed by the same amount: read from the history, no bound needed
+    b.out(N(b.op(FR_PRIM_DELAY, Cf(4.5f), N(amt))), 3);        // a constant delayed by it: a step at t = amount
+    check_graph(b, 4, 20, 3, true, "dynamic delay", [](const FlatGraph &, const StagedPlan &sp) {
         CHECK(sp.pull_rows.size() == 1 && sp.pull_rows[0] == 0);
-        CHECK(sp.progs.size() == 1);
+        CHECK(sp.progs.size() == 3);
     });
 }
 
@@ -846,15 +848,15 @@ static void bounded_signal_delays_are_staged() {
     uint32_t dct = b.op(FR_PRIM_DELAY, Cf(2.5f), N(b.op(FR_PRIM_MODULO, In(0), Cf(7.0f))));
     uint32_t neg = b.op(FR_PRIM_DELAY, In(0), N(b.op(FR_PRIM_SUM2, Cf(-4.0f), N(a3))));                               // [-4, 5]
     b.out(N(b.op(FR_PRIM_SUM2, N(din), N(b.op(FR_PRIM_SUM2, N(dct), N(neg))))), V);
-    // unbounded amount: stays with the pull interpreter
-    b.out(N(b.op(FR_PRIM_DELAY, In(1), N(b.op(FR_PRIM_MULTIPLY, In(0), Cf(0.5f))))), V + 1);
+    // unbounded amount on a computed signal: stays with the pull interpreter
+    b.out(N(b.op(FR_PRIM_DELAY, N(b.op(FR_PRIM_SUM2, In(1), Cf(1.0f))), N(b.op(FR_PRIM_MULTIPLY, In(0), Cf(0.5f))))), V + 1);
     auto inspect = [&](const FlatGraph &, const StagedPlan &sp) {
         CHECK(sp.pull_rows.size() == 1 && sp.pull_rows[0] == V + 1);
         CHECK(sp.lmax >= 70 + 43 && sp.lmax <= 70 + 50);
         CHECK(sp.fused_count == 0);        // a signal-delayed read of a program's ring can land inside the current launch
         size_t dyn = 0;
         for (const StageInstr &in : sp.instrs) dyn += (in.op == S_READ_DYN || in.op == S_READ_INPUT_DYN || in.op == S_STEP_DYN) ? 1 : 0;
-        CHECK(dyn == 2 * V + 3);
+        CHECK(dyn == 2 * V + 3);   // (the pulled row's Delay is not an instruction)
     };
     check_graph(b, V + 2, 100, 5, true, "bounded signal delays", inspect);
     check_graph(b, V + 2, 17, 9, true, "bounded signal delays, short calls");
