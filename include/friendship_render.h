@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 1u
+#define FR_ABI_VERSION 2u
 
 /* ---- status codes ------------------------------------------------------------------------- */
 typedef int32_t fr_status;
@@ -115,11 +115,33 @@ enum {
     FR_MODE_STAGED = 2             /* materialised stage pipeline, no fused oscillator banks      */
 };
 
+/* Which of the reference's two renderers to reproduce where they disagree (both unpinned by any reference
+ * test):
+ *   FR_SEMANTICS_REFERENCE  RefRenderer (src/render/reference.rs:197-248): Delay amount < 0 or NaN clamps to 0
+ *                           frames; Minimum is Rust's f32::min (NaN loses).  The named oracle; the default.
+ *   FR_SEMANTICS_SPARKLE    SparkleRenderer (src/render/sparkle.rs:492-498,531-542): Delay amount < 0 or NaN
+ *                           outputs 0.0; Minimum is select(fcmp ult a, b): a NaN operand returns `a`.
+ * A host that replaces `SparkleRenderer::default()` (tests/render_prim.rs:30) and wants its corner cases picks
+ * the second; everything the reference's tests pin is identical under both. */
+enum {
+    FR_SEMANTICS_REFERENCE = 0,
+    FR_SEMANTICS_SPARKLE = 1
+};
+
 typedef struct fr_config {
     uint32_t abi_version;          /* FR_ABI_VERSION                                              */
     int32_t device;                /* HIP device ordinal; -1 = current device                     */
     int32_t mode;                  /* FR_MODE_*                                                   */
     uint32_t flags;                /* reserved, 0                                                 */
+    int32_t semantics;             /* FR_SEMANTICS_*                                              */
+    uint32_t reserved;             /* 0                                                           */
+    uint64_t history_frames;       /* Input history kept per slot, in frames; 0 = everything since the last
+                                      seek, which is the reference's behaviour (reference.rs:25,70-73).  With a
+                                      cap, samples older than `head - history_frames` read as 0.0 -- exactly what
+                                      the reference returns for times before a seek point -- so a Delay (or a
+                                      later-added longer Delay) reaching further back than the cap sees silence
+                                      there.  The engine never trims below what the current plan's constant
+                                      delays and proven bounds need; the cap is rounded up to that.            */
 } fr_config;
 
 /* cfg may be NULL (device -1, FR_MODE_AUTO). */
@@ -137,6 +159,58 @@ fr_status fr_on_del_edge(fr_renderer *r, const fr_edge *edge);
 fr_status fr_on_add_nodes(fr_renderer *r, const uint32_t *handles,
                           const fr_effect *const *effects, size_t n);
 fr_status fr_on_add_edges(fr_renderer *r, const fr_edge *edges, size_t n);
+
+/* ---- multi-GPU: one process (and one renderer) per GPU --------------------------------------------
+ * Output slots are independent in the reference (reference.rs:78-82), so a job shards over `world`
+ * renderers with no change to the graph API: EVERY rank receives the SAME graph edits and makes the
+ * SAME fill_buffer calls (same n_slots, n_times, idx; same input rows).  Rank r owns the contiguous
+ * block of output rows fr_shard_rows() reports and renders exactly those; rows it does not own are left
+ * untouched in `out` (the host allocates zeros, src/dispatch.rs:149).
+ *   FR_SHARD_VOICES    every rank evaluates only what its own rows need.  No exchange.
+ *   FR_SHARD_PARTIALS  additionally, an oscillator bank needed by one rank only is cut at the top
+ *                      log2(world) levels of its Sum2 tree: rank r renders sub-tree r of EVERY such bank
+ *                      (a partial mix), and one exchange step -- recursive halving, log2(world) pairwise
+ *                      sends, each followed by the tree's own f32 add in the tree's own association --
+ *                      leaves the owner with the bank's value, bit-identical to the unsharded render.
+ *                      Effects behind the bank (envelopes, delay lines) then run on the owner.
+ *                      world must be a power of two.
+ * FR_SHARD_GATHER (flag): after rendering, rank 0's `out` also receives every other rank's rows.
+ * Transport of the exchange: the engine's own RCCL communicator over xGMI (pass the same
+ * fr_comm_unique_id() bytes on every rank), or a host-staged callback (`comm`; MPI, gloo, a test
+ * harness): the engine copies the ranges through pinned host memory around it.  Neither is needed in
+ * FR_SHARD_VOICES without FR_SHARD_GATHER. */
+enum {
+    FR_SHARD_NONE = 0,
+    FR_SHARD_VOICES = 1,
+    FR_SHARD_PARTIALS = 2
+};
+#define FR_SHARD_GATHER 1u
+#define FR_COMM_ID_BYTES 128
+
+typedef struct fr_comm {
+    void *ctx;
+    /* Blocking pairwise exchange of HOST buffers with rank `peer`: send send_bytes from `send`, receive
+     * recv_bytes into `recv` (either may be 0).  The peer makes the matching call.  Returns 0 on success. */
+    int32_t (*sendrecv)(void *ctx, uint32_t peer, const void *send, size_t send_bytes, void *recv,
+                        size_t recv_bytes);
+} fr_comm;
+
+typedef struct fr_shard {
+    uint32_t rank;
+    uint32_t world;                /* <= 64 */
+    int32_t mode;                  /* FR_SHARD_*                                                  */
+    uint32_t flags;                /* FR_SHARD_GATHER                                             */
+    const uint8_t *rccl_id;        /* FR_COMM_ID_BYTES bytes from fr_comm_unique_id, or NULL      */
+    const fr_comm *comm;           /* host-staged transport, or NULL; copied                      */
+} fr_shard;
+
+/* ncclGetUniqueId through the engine, so that a host needs no RCCL binding of its own: call on one rank,
+ * hand the bytes to the others by any means, pass them to fr_set_shard on every rank. */
+fr_status fr_comm_unique_id(uint8_t id[FR_COMM_ID_BYTES]);
+/* Collective when rccl_id is given (ncclCommInitRank): every rank calls it.  NULL or world <= 1 unshards. */
+fr_status fr_set_shard(fr_renderer *r, const fr_shard *shard);
+/* The block of output rows [*lo, *hi) this renderer owns when n_slots rows are rendered. */
+fr_status fr_shard_rows(const fr_renderer *r, uint32_t n_slots, uint32_t *lo, uint32_t *hi);
 
 /* Renderer::fill_buffer.  `out` is the row-major [n_slots, n_times] f32 buffer (Array2, allocated
  * by the caller, src/dispatch.rs:149); every element is overwritten.  `idx` is the absolute sample

@@ -12,8 +12,8 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 OUT = os.path.join(PKG_DIR, "libfriendship_hip.so")
-SOURCES = ["engine.cpp", "graph.cpp", "match.cpp", "stage.cpp", "jit.cpp", "leafjit.cpp", "stagejit.cpp", "kernels.hip"]
-HEADERS = ["graph.hpp", "kernels.hpp", "match.hpp", "stage.hpp", "jit.hpp", "leafshape.hpp", os.path.join("..", "..", "include", "friendship_render.h")]
+SOURCES = ["engine.cpp", "graph.cpp", "match.cpp", "stage.cpp", "jit.cpp", "leafjit.cpp", "stagejit.cpp", "comm_rccl.cpp", "kernels.hip"]
+HEADERS = ["graph.hpp", "kernels.hpp", "match.hpp", "stage.hpp", "jit.hpp", "leafshape.hpp", "comm.hpp", "range.hpp", os.path.join("..", "..", "include", "friendship_render.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-slp-vectorize", "-mllvm", "-simplifycfg-sink-common=false", "-Wall", "-Wextra"]
 
@@ -30,7 +30,7 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lhiprtc"]
+    cmd = [hipcc] + FLAGS + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lhiprtc", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

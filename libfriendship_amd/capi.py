@@ -31,8 +31,14 @@ FR_EFFECT_GRAPH = 7
 
 FR_MODE_AUTO, FR_MODE_PULL, FR_MODE_STAGED = 0, 1, 2
 MODES = {"auto": FR_MODE_AUTO, "pull": FR_MODE_PULL, "staged": FR_MODE_STAGED}
+FR_SEMANTICS_REFERENCE, FR_SEMANTICS_SPARKLE = 0, 1
+SEMANTICS = {"reference": FR_SEMANTICS_REFERENCE, "sparkle": FR_SEMANTICS_SPARKLE}
+FR_SHARD_NONE, FR_SHARD_VOICES, FR_SHARD_PARTIALS = 0, 1, 2
+SHARD_MODES = {"none": FR_SHARD_NONE, "voices": FR_SHARD_VOICES, "partials": FR_SHARD_PARTIALS}
+FR_SHARD_GATHER = 1
+FR_COMM_ID_BYTES = 128
 
-FR_ABI_VERSION = 1
+FR_ABI_VERSION = 2
 
 EDGE_DTYPE = np.dtype([("from", "<u4"), ("to", "<u4"), ("from_slot", "<u4"), ("to_slot", "<u4")])
 
@@ -56,7 +62,20 @@ fr_effect._fields_ = [
 
 
 class fr_config(C.Structure):
-    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("mode", C.c_int32), ("flags", C.c_uint32)]
+    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("mode", C.c_int32), ("flags", C.c_uint32),
+                ("semantics", C.c_int32), ("reserved", C.c_uint32), ("history_frames", C.c_uint64)]
+
+
+SENDRECV_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
+
+
+class fr_comm(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("sendrecv", SENDRECV_FN)]
+
+
+class fr_shard(C.Structure):
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("mode", C.c_int32), ("flags", C.c_uint32),
+                ("rccl_id", C.POINTER(C.c_uint8)), ("comm", C.POINTER(fr_comm))]
 
 
 class RenderError(RuntimeError):
@@ -162,6 +181,12 @@ class RendererLib:
         L.fr_set_timing.argtypes = [vp, C.c_int32]
         L.fr_get_timing.argtypes = [vp, C.c_char_p, P(C.c_double), P(C.c_uint64)]
         L.fr_reset_timing.argtypes = [vp]
+        L.fr_set_shard.argtypes = [vp, P(fr_shard)]
+        L.fr_set_shard.restype = C.c_int32
+        L.fr_shard_rows.argtypes = [vp, C.c_uint32, P(C.c_uint32), P(C.c_uint32)]
+        L.fr_shard_rows.restype = C.c_int32
+        L.fr_comm_unique_id.argtypes = [P(C.c_uint8)]
+        L.fr_comm_unique_id.restype = C.c_int32
         if L.fr_abi_version() != FR_ABI_VERSION:
             raise RuntimeError(f"{path}: ABI version {L.fr_abi_version()} != {FR_ABI_VERSION}")
 
@@ -172,14 +197,23 @@ class RendererLib:
     def status_string(self, s):
         return self.lib.fr_status_string(s).decode()
 
+    def comm_unique_id(self):
+        """ncclGetUniqueId through the engine: 128 bytes to hand to every rank's set_shard(rccl_id=...)."""
+        buf = (C.c_uint8 * FR_COMM_ID_BYTES)()
+        st = self.lib.fr_comm_unique_id(buf)
+        if st != FR_OK:
+            raise RenderError(st, self.status_string(st), "fr_comm_unique_id")
+        return bytes(buf)
+
 
 class Renderer:
     """Handle-owning wrapper: one method per entry point, arguments as in the reference's traits."""
 
-    def __init__(self, rlib, mode="auto", device=-1):
+    def __init__(self, rlib, mode="auto", device=-1, semantics="reference", history_frames=0):
         self.rlib = rlib
         self.L = rlib.lib
-        cfg = fr_config(FR_ABI_VERSION, device, MODES[mode] if isinstance(mode, str) else mode, 0)
+        cfg = fr_config(FR_ABI_VERSION, device, MODES[mode] if isinstance(mode, str) else mode, 0,
+                        SEMANTICS[semantics] if isinstance(semantics, str) else semantics, 0, history_frames)
         h = C.c_void_p()
         st = self.L.fr_renderer_create(C.byref(cfg), C.byref(h))
         if st != FR_OK:
@@ -207,6 +241,43 @@ class Renderer:
     def _check(self, st):
         if st != FR_OK:
             raise RenderError(st, self.rlib.status_string(st), self.L.fr_last_error(self.h).decode())
+
+    # --- sharding (fr_set_shard) ---
+    def set_shard(self, rank, world, mode="voices", gather=False, rccl_id=None, sendrecv=None):
+        """This renderer becomes rank `rank` of `world`.  Transport of the exchange step: `rccl_id` (bytes from
+        RendererLib.comm_unique_id(), the same on every rank: the engine's own RCCL communicator) or `sendrecv`, a
+        Python callable (peer, send: np.uint8 array view or None, recv: np.uint8 array view or None) -> None that
+        exchanges HOST buffers with `peer` (the engine stages device ranges through pinned memory around it)."""
+        sh = fr_shard()
+        sh.rank, sh.world = rank, world
+        sh.mode = SHARD_MODES[mode] if isinstance(mode, str) else mode
+        sh.flags = FR_SHARD_GATHER if gather else 0
+        keep = []
+        if rccl_id is not None:
+            idbuf = (C.c_uint8 * FR_COMM_ID_BYTES).from_buffer_copy(rccl_id)
+            sh.rccl_id = C.cast(idbuf, C.POINTER(C.c_uint8))
+            keep.append(idbuf)
+        if sendrecv is not None:
+            def thunk(_ctx, peer, send, send_bytes, recv, recv_bytes):
+                try:
+                    sv = np.ctypeslib.as_array((C.c_uint8 * send_bytes).from_address(send)) if send_bytes else None
+                    rv = np.ctypeslib.as_array((C.c_uint8 * recv_bytes).from_address(recv)) if recv_bytes else None
+                    sendrecv(int(peer), sv, rv)
+                    return 0
+                except Exception as e:  # noqa: BLE001 -- an exception must not unwind through the C frames
+                    self._comm_error = e
+                    return 1
+            cb = SENDRECV_FN(thunk)
+            comm = fr_comm(None, cb)
+            sh.comm = C.pointer(comm)
+            keep += [cb, comm]
+        self._shard_keep = keep   # the callback must outlive every later fill_buffer
+        self._check(self.L.fr_set_shard(self.h, C.byref(sh)))
+
+    def shard_rows(self, n_slots):
+        lo, hi = C.c_uint32(), C.c_uint32()
+        self._check(self.L.fr_shard_rows(self.h, n_slots, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
 
     # --- GraphWatcher (graphwatcher.rs:4-9) ---
     def on_add_node(self, handle, effect):
@@ -247,10 +318,12 @@ class Renderer:
         self._check(self.L.fr_on_add_edges(self.h, edges.ctypes.data, len(edges)))
 
     # --- Renderer::fill_buffer (renderer.rs:16) ---
-    def fill_buffer(self, n_slots, start, end, inputs=()):
+    def fill_buffer(self, n_slots, start, end, inputs=(), out=None):
         """Render [start, end) for output slots 0..n_slots; inputs = rows of a Jagged2<f32>."""
         n_times = end - start
-        out = np.zeros((n_slots, n_times), dtype=np.float32)  # Dispatch allocates zeros (dispatch.rs:149)
+        if out is None:
+            out = np.zeros((n_slots, n_times), dtype=np.float32)  # Dispatch allocates zeros (dispatch.rs:149)
+        assert out.dtype == np.float32 and out.shape == (n_slots, n_times) and out.flags.c_contiguous
         rows = [np.ascontiguousarray(r, dtype=np.float32).ravel() for r in inputs]
         offs = np.zeros(len(rows) + 1, dtype=np.uint64)
         if rows:

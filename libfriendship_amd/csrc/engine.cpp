@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "comm.hpp"
 #include "graph.hpp"
 #include "jit.hpp"
 #include "kernels.hpp"
@@ -98,6 +99,7 @@ struct BankStage {
 struct Plan {
     bool valid = false;
     uint64_t version = 0;
+    uint64_t shard_epoch = 0;            // fr_set_shard generation the plan was made for
     uint32_t n_slots = 0;
     uint32_t max_depth = 0;              // of the lowered graph (pull stack sizing)
     std::vector<BankStage> banks;
@@ -109,6 +111,7 @@ struct Plan {
     bool stage_valid = false;            // rings hold [stage_end - lmax, stage_end) of the current graph + history
     uint64_t stage_end = 0;
     std::vector<uint32_t> pull_rows;     // output rows evaluated by the pull interpreter
+    DevBuf d_split_dst;                  // partial-block sharding: destination (row, or ring | 1 << 31) per exchange workspace row
     DevBuf d_nodes, d_roots;             // pull: nodes (input slots remapped dense), roots per pull row
     std::vector<uint32_t> input_slots;   // dense input index -> external slot
     std::string json;
@@ -127,6 +130,8 @@ using namespace fr;
 struct fr_renderer {
     int device = 0;
     int mode = FR_MODE_AUTO;
+    int semantics = FR_SEMANTICS_REFERENCE;
+    uint64_t history_frames = 0;         // fr_config: 0 = keep everything since the last seek (the reference)
     hipStream_t stream = nullptr;
     Mirror mirror;
     // input history bookkeeping, same rules as reference.rs:47-75 (see oracle/ref_renderer.cpp)
@@ -150,8 +155,7 @@ struct fr_renderer {
     // Calls of a plan without delay lines, programs or pull rows touch only their own input rows and output buffer (and
     // append their own, disjoint part of the input history): on different streams they may overlap on the device.
     bool plan_is_stateless(uint32_t n_slots) const {
-        return plan.valid && plan.version == mirror.version && plan.n_slots == n_slots && !plan.sp.uses_rings() && plan.sp.progs.empty() &&
-               plan.pull_rows.empty();
+        return plan_current(n_slots) && !plan.sp.uses_rings() && plan.sp.progs.empty() && plan.pull_rows.empty() && plan.sp.split.empty();
     }
     void order_after_previous(hipStream_t st, bool this_independent = false) {
         if (!last_pending) return;
@@ -181,6 +185,103 @@ struct fr_renderer {
         last_stream = st;
         last_pending = true;
     }
+    // ---- sharding (friendship_render.h fr_shard): this renderer is rank `shard.rank` of `shard.world`, one per GPU ----
+    ShardSpec shard;
+    uint32_t shard_flags = 0;
+    uint64_t shard_epoch = 0;
+    std::unique_ptr<Transport> rccl;     // the engine's own communicator (device to device over xGMI), or
+    fr_comm host_comm{};                 // the host's callback (ranges staged through pinned memory)
+    bool has_host_comm = false;
+    DevBuf d_ws, d_xrecv;                // exchange workspace [split voices][window], receive buffer
+    PinnedBuf h_xsend, h_xrecv;
+    bool sharded() const { return shard.world > 1 && shard.mode != FR_SHARD_NONE; }
+    void my_rows(uint32_t n_slots, uint32_t &lo, uint32_t &hi) const {
+        lo = 0;
+        hi = n_slots;
+        if (sharded()) shard_row_range(shard.rank, shard.world, n_slots, lo, hi);
+    }
+    bool plan_current(uint32_t n_slots) const {
+        return plan.valid && plan.version == mirror.version && plan.n_slots == n_slots && plan.shard_epoch == shard_epoch;
+    }
+
+    // Pairwise exchange with `peer` on stream st (device pointers, counts in floats).
+    void xfer(uint32_t peer, const float *d_send, size_t n_send, float *d_recv, size_t n_recv, hipStream_t st) {
+        if (!n_send && !n_recv) return;
+        if (rccl) { rccl->sendrecv(peer, d_send, n_send, d_recv, n_recv, st); return; }
+        if (!has_host_comm) throw Error(FR_ERR_COMM, "the sharded plan needs an exchange but fr_set_shard was given no transport");
+        h_xsend.ensure(n_send * sizeof(float));
+        h_xrecv.ensure(n_recv * sizeof(float));
+        if (n_send) HIP_CHECK(hipMemcpyAsync(h_xsend.p, d_send, n_send * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));   // the send range is on the host; an earlier upload from h_xrecv is done
+        const int32_t rc = host_comm.sendrecv(host_comm.ctx, peer, h_xsend.p, n_send * sizeof(float), h_xrecv.p, n_recv * sizeof(float));
+        if (rc != 0) throw Error(FR_ERR_COMM, "transport callback failed with code " + std::to_string(rc) + " exchanging with rank " + std::to_string(peer));
+        if (n_recv) HIP_CHECK(hipMemcpyAsync(d_recv, h_xrecv.p, n_recv * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+
+    // The one exchange step of the path (FR_SHARD_PARTIALS): recursive halving over the ranks.  The workspace holds, for
+    // every split voice, this rank's sub-tree sum over the window; rows are ordered by the owner's bits, lowest bit
+    // first.  Step j pairs rank with rank ^ 2^j: each keeps the rows whose owner agrees with it in bit j, sends the
+    // rest, and adds what it receives -- left operand from the rank whose bit j is 0: that is the voice's Sum2 node j
+    // levels above the sub-tree roots, evaluated with the graph's own operands in the graph's own order.  After
+    // log2(world) steps each rank holds the finished voices it owns; the last add stores them where the unsharded
+    // plan would (ring or output row).
+    void run_exchange(float *d_dst, uint64_t n_times, uint64_t idx, uint64_t x0, uint64_t xlen, hipStream_t st) {
+        const std::vector<SplitVoice> &sv = plan.sp.split;
+        uint32_t k = 0;
+        while ((1u << k) < shard.world) ++k;
+        size_t lo = 0, hi = sv.size();
+        float *ws = d_ws.as<float>();
+        for (uint32_t j = 0; j < k; ++j) {
+            const uint32_t bit = 1u << j, peer = shard.rank ^ bit;
+            size_t mid = lo;
+            while (mid < hi && !(sv[mid].owner & bit)) ++mid;
+            const bool upper = (shard.rank & bit) != 0;
+            const size_t keep_lo = upper ? mid : lo, keep_hi = upper ? hi : mid;
+            const size_t send_lo = upper ? lo : mid, send_hi = upper ? mid : hi;
+            xfer(peer, ws + send_lo * xlen, (send_hi - send_lo) * xlen, d_xrecv.as<float>(), (keep_hi - keep_lo) * xlen, st);
+            ShardCombineArgs c{};
+            float *mine = ws + keep_lo * xlen;
+            c.lo = upper ? d_xrecv.as<float>() : mine;
+            c.hi = upper ? mine : d_xrecv.as<float>();
+            c.n_rows = (uint32_t)(keep_hi - keep_lo);
+            c.len = xlen;
+            if (j + 1 < k) {
+                c.dst_ws = mine;
+            } else {
+                c.dst = plan.d_split_dst.as<uint32_t>() + keep_lo;
+                c.out = d_dst;
+                c.out_stride = n_times;
+                c.out_skip = idx - x0;
+                c.rings = d_rings.as<float>();
+                c.ring_mask = ring_cap ? ring_cap - 1 : 0;
+                c.ring_t0 = x0;
+            }
+            Scope sc(this, &t_stage, st);
+            HIP_CHECK(launch_shard_combine(c, st));
+            sc.done();
+            lo = keep_lo;
+            hi = keep_hi;
+        }
+        for (size_t i = lo; i < hi; ++i)
+            if (sv[i].owner != shard.rank) throw Error(FR_ERR_COMM, "internal: exchange order does not match voice ownership");
+    }
+
+    // FR_SHARD_GATHER: every rank's rows to rank 0's buffer.
+    void gather_rows(float *d_dst, uint32_t n_slots, uint64_t n_times, hipStream_t st) {
+        if (!sharded() || !(shard_flags & FR_SHARD_GATHER)) return;
+        if (shard.rank == 0) {
+            for (uint32_t p = 1; p < shard.world; ++p) {
+                uint32_t lo, hi;
+                shard_row_range(p, shard.world, n_slots, lo, hi);
+                xfer(p, nullptr, 0, d_dst + (size_t)lo * n_times, (size_t)(hi - lo) * n_times, st);
+            }
+        } else {
+            uint32_t lo, hi;
+            my_rows(n_slots, lo, hi);
+            xfer(0, d_dst + (size_t)lo * n_times, (size_t)(hi - lo) * n_times, nullptr, 0, st);
+        }
+    }
+
     bool timing = false;
     // A/B switches (environment, read at create; defaults are the measured best):
     uint32_t bank_leaf_variant = 1;      // FR_BANK_LEAF=0: product-form leaves (kernels.hpp BankArgs::leaf_variant)
@@ -275,7 +376,7 @@ struct fr_renderer {
         return plan.stage_valid && plan.stage_end == idx;
     }
     bool bank_time_slot(uint32_t n_slots, uint64_t n_times, uint32_t slot, uint64_t idx) const {
-        if (!plan.valid || plan.version != mirror.version || plan.n_slots != n_slots) return false;
+        if (!plan_current(n_slots)) return false;
         if (n_times <= 2) return false;   // the shortest calls use bank_small_kernel, which does not append history
         // a window with look-back reads the stored history, so the row must be there first; in steady state the bank
         // launch (always ahead of the programs on the stream) reads the caller's row and appends it like any other
@@ -293,11 +394,65 @@ struct fr_renderer {
         return any;
     }
 
+    // What a failed call must put back: the input store is committed before the kernels run, and execute() can still
+    // fail (device errors, out of memory).  Without a seek the slots' lengths, the implicit segments and the vec count
+    // go back to what they were; after a seek the old samples may already be overwritten, so the store stays in the
+    // state the seek itself produces (everything zero before idx) -- the retry at the same idx seeks again anyway.
+    struct StoreSnapshot {
+        struct S { bool fed; uint64_t base, len; };
+        std::vector<S> slots;
+        std::vector<Seg> segs;
+        uint64_t n_vecs = 0;
+        bool seeked = false;
+        uint64_t idx = 0;
+    };
+    StoreSnapshot snapshot_store(uint64_t idx) const {
+        StoreSnapshot sn;
+        sn.slots.reserve(slots.size());
+        for (const InSlot &s : slots) sn.slots.push_back({s.fed, s.base, s.len});
+        sn.segs = segs;
+        sn.n_vecs = n_vecs;
+        sn.seeked = idx != head;
+        sn.idx = idx;
+        return sn;
+    }
+    void rollback_store(const StoreSnapshot &sn) {
+        deferred.clear();
+        plan.stage_valid = false;   // rings may hold part of the failed call's window
+        if (sn.seeked) {
+            for (InSlot &s : slots) { s.base = sn.idx; s.len = sn.idx; }
+            return;
+        }
+        for (size_t i = 0; i < slots.size(); ++i) {
+            if (i < sn.slots.size()) { slots[i].fed = sn.slots[i].fed; slots[i].base = sn.slots[i].base; slots[i].len = sn.slots[i].len; }
+            else { slots[i].fed = false; slots[i].base = slots[i].len = 0; }
+        }
+        segs = sn.segs;
+        n_vecs = sn.n_vecs;
+    }
+
     // `device_rows`: in_data is a device pointer (fr_fill_buffer_device).
     void store_inputs(uint32_t n_slots, uint64_t n_times, uint64_t idx, const float *in_data,
                       const uint64_t *offs, uint32_t n_rows, bool device_rows, hipStream_t st) {
         deferred.clear();
-        if (idx != head) {   // seek: forget history, act as if inputs were 0 before idx (renderer.rs:12-15)
+        const bool seek = idx != head;   // forget history, act as if inputs were 0 before idx (renderer.rs:12-15)
+        // validate everything before mutating so a refused call leaves the history intact: the lengths the rows must
+        // continue are those AFTER the seek (idx for every vec) and after the vec count grew (reference.rs:52-71)
+        {
+            const uint64_t want = (uint64_t)n_slots * n_times;
+            const uint64_t vecs_after = std::max(n_vecs, want);
+            const uint32_t rows = (uint32_t)std::min<uint64_t>(n_rows, vecs_after);
+            for (uint32_t r = 0; r < rows; ++r) {
+                uint64_t cur = idx;   // after a seek, and for vecs created by this call
+                if (!seek && r < n_vecs) cur = (r < slots.size() && slots[r].fed) ? slots[r].len : implicit_len(r);
+                if (cur != idx)
+                    throw Error(FR_ERR_INPUT_HISTORY, "input slot " + std::to_string(r) + " holds " + std::to_string(cur) +
+                                                          " samples, expected idx=" + std::to_string(idx));
+                if (offs[r + 1] < offs[r] || offs[r + 1] - offs[r] > n_times)
+                    throw Error(FR_ERR_INPUT_TOO_LONG, "input row " + std::to_string(r) + " longer than the range rendered");
+            }
+        }
+        if (seek) {
             for (InSlot &s : slots) { s.base = idx; s.len = idx; }
             segs.clear();
             if (n_vecs) segs.push_back({0, n_vecs, idx});
@@ -305,15 +460,6 @@ struct fr_renderer {
         uint64_t want = (uint64_t)n_slots * n_times;   // `buff.len()`, reference.rs:60 (element count, a quirk)
         if (n_vecs < want) { segs.push_back({n_vecs, want, idx}); n_vecs = want; }
         uint32_t rows = (uint32_t)std::min<uint64_t>(n_rows, n_vecs);   // zip stops at the shorter (:68)
-        // validate everything before mutating so a refused call leaves the history intact
-        for (uint32_t r = 0; r < rows; ++r) {
-            uint64_t cur = (r < slots.size() && slots[r].fed) ? slots[r].len : implicit_len(r);
-            if (cur != idx)
-                throw Error(FR_ERR_INPUT_HISTORY, "input slot " + std::to_string(r) + " holds " + std::to_string(cur) +
-                                                      " samples, expected idx=" + std::to_string(idx));
-            if (offs[r + 1] < offs[r] || offs[r + 1] - offs[r] > n_times)
-                throw Error(FR_ERR_INPUT_TOO_LONG, "input row " + std::to_string(r) + " longer than the range rendered");
-        }
         if (rows > slots.size()) slots.resize(rows);
         // (every host-buffer call ends with a stream synchronisation, so the staging buffer is idle here)
         if (!device_rows && rows) h_in_stage.ensure((size_t)rows * n_times * sizeof(float));
@@ -366,7 +512,9 @@ struct fr_renderer {
     void build_plan(uint32_t n_slots, hipStream_t st) {
         Plan p;
         p.version = mirror.version;
+        p.shard_epoch = shard_epoch;
         p.n_slots = n_slots;
+        const ShardSpec *shard_spec = sharded() ? &shard : nullptr;
         const auto t_begin = std::chrono::steady_clock::now();
         const FlatGraph &fg = lowering.update(mirror, n_slots);
         const double lower_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -376,7 +524,7 @@ struct fr_renderer {
             matcher.reset(new BankMatcher(fg, 20, use_jit, allow_template));
             matcher_gen = lowering.generation();
         }
-        p.sp = plan_stages(fg, mode == FR_MODE_AUTO, mode != FR_MODE_PULL, 20, use_jit, allow_template, matcher.get());
+        p.sp = plan_stages(fg, mode == FR_MODE_AUTO, mode != FR_MODE_PULL, 20, use_jit, allow_template, matcher.get(), shard_spec);
         std::vector<std::shared_ptr<JitKernel>> jits(p.sp.banks.size());
         if (use_jit) {
             try {
@@ -384,7 +532,7 @@ struct fr_renderer {
                     if (p.sp.banks[i].jit) jits[i] = jit_cache.get(p.sp.banks[i].shape, p.sp.banks[i].varying, p.sp.banks[i].literal_bits, p.sp.banks[i].alias);
             } catch (const Error &e) {   // hipRTC unavailable or the generated source did not compile: plan without it
                 jit_error = e.what();
-                p.sp = plan_stages(fg, true, true, 20, false);
+                p.sp = plan_stages(fg, true, true, 20, false, true, nullptr, shard_spec);
                 jits.assign(p.sp.banks.size(), nullptr);
             }
         }
@@ -406,6 +554,13 @@ struct fr_renderer {
             p.banks.push_back(std::move(bs));
         }
         p.sp.banks.clear();
+        if (!p.sp.split.empty()) {
+            std::vector<uint32_t> dst(p.sp.split.size());
+            for (size_t i = 0; i < dst.size(); ++i) dst[i] = p.sp.split[i].dst | (p.sp.split[i].to_ring ? 0x80000000u : 0u);
+            p.d_split_dst.ensure(dst.size() * sizeof(uint32_t));
+            HIP_CHECK(hipMemcpyAsync(p.d_split_dst.p, dst.data(), dst.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipStreamSynchronize(st));   // `dst` goes out of scope
+        }
         if (!p.sp.progs.empty()) {
             p.d_instrs.ensure(p.sp.instrs.size() * sizeof(StageInstr));
             p.d_progs.ensure(p.sp.progs.size() * sizeof(StageProg));
@@ -462,7 +617,7 @@ struct fr_renderer {
                << ",\"general_tree\":" << (g.general ? "true" : "false") << ",\"jit\":" << (g.jit ? "true" : "false")
                << ",\"leaf_ops\":" << (g.jit ? g.shape.ops.size() : 0) << ",\"leaf_params\":" << (g.jit ? g.k : 2)
                << ",\"input_slot\":" << g.input_slot << ",\"fast_ok\":" << (g.fast_ok ? "true" : "false")
-               << ",\"to_ring\":" << (g.to_ring ? "true" : "false")
+               << ",\"to_ring\":" << (g.to_ring ? "true" : "false") << ",\"to_exchange\":" << (g.to_ws ? "true" : "false")
                << ",\"param_bytes\":" << g.params.size() * sizeof(float) << "}";
         }
         js << "],\"stage_programs\":" << (p.sp.progs.size() - p.sp.fused_count) << ",\"stage_instrs\":" << p.sp.instrs.size()
@@ -472,6 +627,8 @@ struct fr_renderer {
            << ",\"rings\":" << p.sp.n_rings << ",\"max_lookback\":" << p.sp.lmax
            << ",\"jit_kernels_compiled\":" << jit_cache.compiled() << ",\"jit_compile_ms\":" << jit_cache.compile_ms()
            << ",\"pull_rows\":" << p.pull_rows.size()
+           << ",\"shard\":{\"rank\":" << shard.rank << ",\"world\":" << shard.world << ",\"mode\":" << (sharded() ? shard.mode : 0)
+           << ",\"split_voices\":" << p.sp.split.size() << ",\"transport\":\"" << (rccl ? "rccl" : has_host_comm ? "host-callback" : "none") << "\"}"
            << ",\"build_ms\":" << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count() << "}";
         ++plans_built;
         p.json = js.str();
@@ -479,9 +636,13 @@ struct fr_renderer {
         plan = std::move(p);
     }
 
+    void ensure_plan(uint32_t n_slots, hipStream_t st) {
+        if (!plan_current(n_slots)) build_plan(n_slots, st);
+    }
+
     // ---- execution --------------------------------------------------------------------------------
     void execute(float *d_dst, uint32_t n_slots, uint64_t n_times, uint64_t idx, hipStream_t st) {
-        if (!plan.valid || plan.version != mirror.version || plan.n_slots != n_slots) build_plan(n_slots, st);
+        ensure_plan(n_slots, st);
         if (n_slots == 0 || n_times == 0) return;
         const StagedPlan &sp = plan.sp;
 
@@ -503,10 +664,21 @@ struct fr_renderer {
             if (!(plan.stage_valid && plan.stage_end == idx)) w0 = idx > sp.lmax ? idx - sp.lmax : 0;
         }
         const uint64_t w_len = idx + n_times - w0;
+        // Split voices (partial-block sharding): every rank renders its sub-trees over the SAME window -- the look-back
+        // window when any split voice feeds a ring (lmax, ring capacity and validity are the same on every rank: same
+        // graph, same calls), else just this call's frames.
+        bool x_ring = false;
+        for (const SplitVoice &v : sp.split) x_ring = x_ring || v.to_ring;
+        const uint64_t x0 = x_ring ? w0 : idx, xlen = x_ring ? w_len : n_times;
+        if (!sp.split.empty()) {
+            used_scratch = true;
+            d_ws.ensure(sp.split.size() * xlen * sizeof(float));
+            d_xrecv.ensure(sp.split.size() * xlen * sizeof(float));
+        }
 
         for (BankStage &bs : plan.banks) {
-            const bool ring = bs.grp.to_ring;
-            const uint64_t b0 = ring ? w0 : idx, blen = ring ? w_len : n_times;
+            const bool ring = bs.grp.to_ring, ws = bs.grp.to_ws;
+            const uint64_t b0 = ring ? w0 : (ws ? x0 : idx), blen = ring ? w_len : (ws ? xlen : n_times);
             BankArgs a{};
             a.params = bs.d_params.as<float2>();
             // time-slot history for window [b0, b0 + blen): zero before the stored history (seek), zero beyond it
@@ -532,6 +704,9 @@ struct fr_renderer {
                 a.out_stride = ring_cap;
                 a.ring_mask = ring_cap - 1;
                 a.ring_t0 = b0;
+            } else if (ws) {
+                a.out = d_ws.as<float>();
+                a.out_stride = blen;
             } else {
                 a.out = d_dst;
                 a.out_stride = n_times;
@@ -611,6 +786,7 @@ struct fr_renderer {
 
         for (const Deferred &d : deferred)
             if (d.dst) throw Error(FR_ERR_DEVICE, "internal: an input row deferred to the bank launch was not appended");
+        if (!sp.split.empty()) run_exchange(d_dst, n_times, idx, x0, xlen, st);
         if (!sp.progs.empty()) {
             std::vector<DevInput> tab(sp.input_slots.size());
             for (size_t i = 0; i < tab.size(); ++i) tab[i] = dev_input(sp.input_slots[i]);
@@ -622,7 +798,8 @@ struct fr_renderer {
             // Steady state: every delayed ring read of the fused form reaches at least fused_max_frames back, so the call
             // is cut into sub-windows of that length, one fused launch each, when that takes fewer launches than levels.
             const size_t n_levels = sp.level_first.size() - 1;
-            const uint64_t n_sub = sp.fused_count ? (n_times + sp.fused_max_frames - 1) / sp.fused_max_frames : 0;
+            const uint64_t fused_step = std::max<uint64_t>(sp.fused_max_frames, 1);
+            const uint64_t n_sub = sp.fused_count ? (n_times - 1) / fused_step + 1 : 0;   // (n_times > 0 here; no overflow)
             const bool fused = sp.fused_count != 0 && w0 == idx && plan.stage_valid && n_sub < n_levels;
             auto launch_range = [&](uint32_t first, uint32_t count, uint64_t s0, uint64_t slen) {
                 for (uint32_t off = 0; off < count && plan.stage_jit; off += 65535u) {   // grid.y limit
@@ -664,8 +841,11 @@ struct fr_renderer {
                 }
             };
             if (fused) {
-                for (uint64_t s0 = idx; s0 < idx + n_times; s0 += sp.fused_max_frames)
-                    launch_range(sp.fused_first, sp.fused_count, s0, std::min<uint64_t>(sp.fused_max_frames, idx + n_times - s0));
+                for (uint64_t done = 0; done < n_times;) {   // by frames still to do: no sum that could wrap
+                    const uint64_t len = std::min<uint64_t>(fused_step, n_times - done);
+                    launch_range(sp.fused_first, sp.fused_count, idx + done, len);
+                    done += len;
+                }
             } else {
                 for (size_t l = 0; l < n_levels; ++l)
                     launch_range(sp.level_first[l], sp.level_first[l + 1] - sp.level_first[l], w0, w_len);
@@ -764,6 +944,8 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     if (cfg && cfg->abi_version != FR_ABI_VERSION) return FR_ERR_INVALID_ARG;
     int mode = cfg ? cfg->mode : FR_MODE_AUTO;
     if (mode < FR_MODE_AUTO || mode > FR_MODE_STAGED) return FR_ERR_INVALID_ARG;
+    if (cfg && (cfg->flags != 0 || cfg->reserved != 0)) return FR_ERR_INVALID_ARG;
+    if (cfg && cfg->semantics != FR_SEMANTICS_REFERENCE && cfg->semantics != FR_SEMANTICS_SPARKLE) return FR_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FR_ERR_NO_DEVICE;
     int dev = cfg ? cfg->device : -1;
@@ -779,6 +961,8 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     if (!r) return FR_ERR_OUT_OF_MEMORY;
     r->device = dev;
     r->mode = mode;
+    r->semantics = cfg ? cfg->semantics : FR_SEMANTICS_REFERENCE;
+    r->history_frames = cfg ? cfg->history_frames : 0;
     if (const char *lv = std::getenv("FR_BANK_LEAF")) r->bank_leaf_variant = (lv[0] == '1') ? 1u : 0u;
     if (const char *jv = std::getenv("FR_JIT")) r->allow_jit = jv[0] != '0';
     if (const char *tv = std::getenv("FR_BANK_TEMPLATE")) r->allow_template = tv[0] != '0';
@@ -833,6 +1017,9 @@ fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t 
         HIP_CHECK(hipSetDevice(r->device));
         hipStream_t st = r->stream;
         r->order_after_previous(st);
+        r->ensure_plan(n_slots, st);           // graph errors surface before the input store is touched
+        const auto snap = r->snapshot_store(idx);
+        try {
         r->store_inputs(n_slots, n_times, idx, in_data, in_row_offsets, n_in_rows, false, st);
         size_t bytes = (size_t)n_slots * n_times * sizeof(float);
         // (Rendering a long call as 2-4 sub-calls so that chunk c's D2H overlaps chunk c+1's kernels was tried: every
@@ -840,8 +1027,20 @@ fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t 
         //  231 / 242 / 277 us at 2 / 3 / 4 chunks for config C; profiles/r01_host_path.txt.)
         r->d_out.ensure(bytes);
         r->execute(r->d_out.as<float>(), n_slots, n_times, idx, st);
-        if (bytes) HIP_CHECK(hipMemcpyAsync(out, r->d_out.p, bytes, hipMemcpyDeviceToHost, st));
+        // sharded: only the rows this rank owns come back (rank 0 under FR_SHARD_GATHER: every row)
+        uint32_t row_lo, row_hi;
+        r->my_rows(n_slots, row_lo, row_hi);
+        if (r->sharded() && (r->shard_flags & FR_SHARD_GATHER)) {
+            r->gather_rows(r->d_out.as<float>(), n_slots, n_times, st);
+            if (r->shard.rank == 0) { row_lo = 0; row_hi = n_slots; }
+        }
+        const size_t off = (size_t)row_lo * n_times, cnt = (size_t)(row_hi - row_lo) * n_times;
+        if (cnt) HIP_CHECK(hipMemcpyAsync(out + off, r->d_out.as<float>() + off, cnt * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));   // synchronous contract: dispatch.rs:150-151
+        } catch (...) {
+            r->rollback_store(snap);
+            throw;
+        }
         r->last_pending = false;               // everything issued so far, on any stream, is complete (order_after_previous)
         r->head = idx + n_times;               // reference.rs:84
     });
@@ -854,14 +1053,78 @@ fr_status fr_fill_buffer_device(fr_renderer *r, float *d_out, uint32_t n_slots, 
         check_fill_args(d_out, n_slots, n_times, d_in_data, in_row_offsets, n_in_rows);
         HIP_CHECK(hipSetDevice(r->device));
         hipStream_t st = (hipStream_t)stream;
-        const bool independent = r->plan_is_stateless(n_slots) && idx == r->head;   // (a seek or a new plan orders everything)
+        // Independent of the previous call (may overlap with it on another stream): a plan without state, no seek, no new
+        // plan, and every row full length -- padding a short row reads the slot's last stored sample, which the previous
+        // call may still be writing.
+        bool independent = r->plan_is_stateless(n_slots) && idx == r->head;
+        for (uint32_t i = 0; independent && i < n_in_rows; ++i) independent = in_row_offsets[i + 1] - in_row_offsets[i] == n_times;
         r->order_after_previous(st, independent);
         r->used_scratch = false;
-        r->store_inputs(n_slots, n_times, idx, d_in_data, in_row_offsets, n_in_rows, true, st);
-        r->execute(d_out, n_slots, n_times, idx, st);
+        r->ensure_plan(n_slots, st);
+        const auto snap = r->snapshot_store(idx);
+        try {
+            r->store_inputs(n_slots, n_times, idx, d_in_data, in_row_offsets, n_in_rows, true, st);
+            r->execute(d_out, n_slots, n_times, idx, st);
+            r->gather_rows(d_out, n_slots, n_times, st);
+        } catch (...) {
+            r->rollback_store(snap);
+            throw;
+        }
         r->remember_async(st, independent && !r->used_scratch);
         r->head = idx + n_times;
     });
+}
+
+fr_status fr_comm_unique_id(uint8_t id[FR_COMM_ID_BYTES]) {
+    if (!id) return FR_ERR_INVALID_ARG;
+    try {
+        rccl_unique_id(id);
+        return FR_OK;
+    } catch (const Error &e) {
+        return e.code;
+    }
+}
+
+fr_status fr_set_shard(fr_renderer *r, const fr_shard *sh) {
+    return guarded(r, [&] {
+        HIP_CHECK(hipSetDevice(r->device));
+        HIP_CHECK(hipDeviceSynchronize());   // nothing of the previous arrangement is still in flight
+        r->last_pending = false;
+        ShardSpec spec;
+        uint32_t flags = 0;
+        std::unique_ptr<Transport> transport;
+        fr_comm comm{};
+        bool has_comm = false;
+        if (sh && sh->world > 1 && sh->mode != FR_SHARD_NONE) {
+            if (sh->mode != FR_SHARD_VOICES && sh->mode != FR_SHARD_PARTIALS) throw Error(FR_ERR_INVALID_ARG, "unknown shard mode");
+            if (sh->world > 64 || sh->rank >= sh->world) throw Error(FR_ERR_INVALID_ARG, "shard rank/world out of range (world <= 64)");
+            if (sh->mode == FR_SHARD_PARTIALS && (sh->world & (sh->world - 1)) != 0)
+                throw Error(FR_ERR_INVALID_ARG, "partial-block sharding needs a power-of-two world size");
+            if (sh->flags & ~FR_SHARD_GATHER) throw Error(FR_ERR_INVALID_ARG, "unknown shard flags");
+            spec.rank = sh->rank;
+            spec.world = sh->world;
+            spec.mode = sh->mode;
+            flags = sh->flags;
+            if (sh->comm) {
+                if (!sh->comm->sendrecv) throw Error(FR_ERR_INVALID_ARG, "fr_comm without a sendrecv function");
+                comm = *sh->comm;
+                has_comm = true;
+            }
+            if (sh->rccl_id) transport = make_rccl_transport(sh->rccl_id, sh->rank, sh->world);   // collective
+        }
+        r->shard = spec;
+        r->shard_flags = flags;
+        r->rccl = std::move(transport);
+        r->host_comm = comm;
+        r->has_host_comm = has_comm;
+        ++r->shard_epoch;                    // the plan depends on all of it
+    });
+}
+
+fr_status fr_shard_rows(const fr_renderer *r, uint32_t n_slots, uint32_t *lo, uint32_t *hi) {
+    if (!r || !lo || !hi) return FR_ERR_INVALID_ARG;
+    r->my_rows(n_slots, *lo, *hi);
+    return FR_OK;
 }
 
 const char *fr_last_error(const fr_renderer *r) { return r ? r->last_error.c_str() : "null renderer"; }

@@ -1084,6 +1084,39 @@ hipError_t launch_stage(const StageArgs &a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Partial-block exchange, one level of the voices' Sum2 trees (kernels.hpp ShardCombineArgs).  HBM-bound: 12 bytes per
+// frame of a row; rows are contiguous and lanes run over frames, so every access is a full 256-byte line per wave.
+__global__ void __launch_bounds__(256) shard_combine_kernel(ShardCombineArgs a) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t row = blockIdx.y;
+    if (t >= a.len) return;
+    const size_t e = (size_t)row * a.len + t;
+    const float v = a.lo[e] + a.hi[e];
+    if (a.dst_ws) { a.dst_ws[e] = v; return; }
+    const uint32_t d = a.dst[row];
+    if (d & 0x80000000u) a.rings[(size_t)(d & 0x7FFFFFFFu) * (a.ring_mask + 1) + ((a.ring_t0 + t) & a.ring_mask)] = v;
+    else if (t >= a.out_skip) a.out[(size_t)d * a.out_stride + (t - a.out_skip)] = v;
+}
+
+hipError_t launch_shard_combine(const ShardCombineArgs &a, hipStream_t s) {
+    if (a.n_rows == 0 || a.len == 0) return hipSuccess;
+    const uint64_t bx = (a.len + 255) / 256;
+    if (bx > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    for (uint32_t r0 = 0; r0 < a.n_rows; r0 += 65535u) {   // grid.y limit
+        ShardCombineArgs c = a;
+        c.n_rows = std::min<uint32_t>(a.n_rows - r0, 65535u);
+        c.lo += (size_t)r0 * a.len;
+        c.hi += (size_t)r0 * a.len;
+        if (c.dst_ws) c.dst_ws += (size_t)r0 * a.len;
+        if (c.dst) c.dst += r0;
+        hipLaunchKernelGGL(shard_combine_kernel, dim3((uint32_t)bx, c.n_rows), dim3(256), 0, s, c);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// ---------------------------------------------------------------------------------------------------
 __global__ void pad_kernel(float *dst, uint64_t n, const float *src_last) {
     float v = src_last ? *src_last : 0.0f;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = v;

@@ -129,6 +129,27 @@ struct StageArgs {
 };
 hipError_t launch_stage(const StageArgs &a, hipStream_t s);
 
+// One step of the partial-block exchange (friendship_render.h FR_SHARD_PARTIALS): row i, window frame t:
+//   v = lo[i][t] + hi[i][t]         the Sum2 node one level up: left sub-tree + right sub-tree, one f32 add
+// stored to dst_ws[i][t] (steps before the last; may alias lo or hi), or -- the last step, dst_ws == null -- where the
+// unsharded plan puts the voice: dst[i] bit 31 set: ring dst[i] & 0x7FFFFFFF at absolute frame ring_t0 + t; else
+// output row dst[i], frames t >= out_skip only (the look-back part of a window is not output).
+struct ShardCombineArgs {
+    const float *lo;
+    const float *hi;
+    float *dst_ws;
+    const uint32_t *dst;
+    float *out;
+    uint64_t out_stride;
+    uint64_t out_skip;
+    float *rings;
+    uint64_t ring_mask;
+    uint64_t ring_t0;
+    uint32_t n_rows;
+    uint64_t len;
+};
+hipError_t launch_shard_combine(const ShardCombineArgs &a, hipStream_t s);
+
 // Fills dst[0..n) with *src_last (or 0 when src_last is null): last-value padding of a short input
 // row (reference.rs:72-73) for the device-resident entry point.
 hipError_t launch_pad(float *dst, uint64_t n, const float *src_last, hipStream_t s);

@@ -411,13 +411,16 @@ void BankMatcher::retain_used() {
 }
 
 bool BankMatcher::try_voice(uint32_t root, VoiceMatch &out) {
+    const VoiceMatch *vm = match(root);
+    if (!vm) return false;
+    out = *vm;
+    return true;
+}
+
+const VoiceMatch *BankMatcher::match(uint32_t root) {
     used_[root] = true;
     auto it = memo_.find(root);
-    if (it != memo_.end()) {
-        if (it->second < 0) return false;
-        out = found_[(size_t)it->second];
-        return true;
-    }
+    if (it != memo_.end()) return it->second < 0 ? nullptr : &found_[(size_t)it->second];
     // height = number of Sum2 nodes on the leftmost path
     uint32_t h = 0, cur = root;
     while (g_.nodes[cur].op == OP_SUM2 && h <= max_log2_p_) { cur = g_.nodes[cur].a; ++h; }
@@ -429,9 +432,8 @@ bool BankMatcher::try_voice(uint32_t root, VoiceMatch &out) {
         vm.fast_ok = true;
         if (impl_->collect(root, h, vm.params, vm.input_slot, first, vm.fast_ok)) {
             memo_.emplace(root, (int64_t)found_.size());
-            found_.push_back(vm);
-            out = found_.back();
-            return true;
+            found_.push_back(std::move(vm));
+            return &found_.back();
         }
     }
     if (allow_template_ && g_.nodes[root].op == OP_SUM2) {   // not a balanced power-of-two tree: try the general schedule
@@ -440,8 +442,7 @@ bool BankMatcher::try_voice(uint32_t root, VoiceMatch &out) {
         if (impl_->emit_general(root, vm)) {
             memo_.emplace(root, (int64_t)found_.size());
             found_.push_back(std::move(vm));
-            out = found_.back();
-            return true;
+            return &found_.back();
         }
     }
     if (allow_jit_ && g_.nodes[root].op == OP_SUM2) {   // leaves of some other common shape: hipRTC specialisation
@@ -449,12 +450,11 @@ bool BankMatcher::try_voice(uint32_t root, VoiceMatch &out) {
         if (impl_->match_shape_voice(root, max_log2_p_, vm)) {
             memo_.emplace(root, (int64_t)found_.size());
             found_.push_back(std::move(vm));
-            out = found_.back();
-            return true;
+            return &found_.back();
         }
     }
     memo_.emplace(root, -1);
-    return false;
+    return nullptr;
 }
 
 }  // namespace fr

@@ -45,6 +45,8 @@ public:
     BankMatcher &operator=(const BankMatcher &) = delete;
     // Is the expression rooted at `root` a voice?  Results (including failures) are memoised per node.
     bool try_voice(uint32_t root, VoiceMatch &out);
+    // The same without the copy: the memoised match, or null.  The pointer is valid until the next match()/try_voice().
+    const VoiceMatch *match(uint32_t root);
     // A matcher kept across plans of the same (append-only, hash-consed) FlatGraph answers repeated roots from its
     // memo.  begin_plan() .. retain_used() bracket one plan: entries no plan has asked for since are dropped once
     // they outnumber the live ones.

@@ -26,6 +26,7 @@ namespace {
 
 constexpr uint32_t NO_RING = 0xFFFFFFFFu;
 constexpr size_t MAX_PROG_INSTR = 4096;
+constexpr uint64_t FUSED_UNBOUNDED = 1ull << 31;   // (delays of 2^31 frames or more are never staged)
 
 struct Planner {
     const FlatGraph &g;
@@ -185,8 +186,9 @@ struct Planner {
 
 // Adds a voice to the launch that shares its kind (balanced: partial count; general: all together), time slot
 // and destination kind.
-void add_voice(std::vector<BankLaunch> &banks, std::unordered_map<std::string, size_t> &grp, const VoiceMatch &vm, uint32_t row, bool ring) {
-    std::string key = std::to_string(vm.general ? 63u : vm.log2_p) + "/" + std::to_string(vm.input_slot) + (vm.general ? "g" : "") + (ring ? "r" : "");
+void add_voice(std::vector<BankLaunch> &banks, std::unordered_map<std::string, size_t> &grp, const VoiceMatch &vm, uint32_t row, bool ring,
+               bool ws = false) {
+    std::string key = std::to_string(vm.general ? 63u : vm.log2_p) + "/" + std::to_string(vm.input_slot) + (vm.general ? "g" : "") + (ring ? "r" : "") + (ws ? "w" : "");
     if (vm.jit) {   // same generated source (shape, which columns vary, literal values) and same inputs share a launch
         key += "j" + vm.shape.key();
         for (uint32_t sl : vm.shape.input_slots) key += "s" + std::to_string(sl);
@@ -197,7 +199,7 @@ void add_voice(std::vector<BankLaunch> &banks, std::unordered_map<std::string, s
     if (gi == grp.end()) {
         gi = grp.emplace(key, banks.size()).first;
         BankLaunch bl;
-        bl.log2_p = vm.log2_p; bl.input_slot = vm.input_slot; bl.to_ring = ring; bl.general = vm.general;
+        bl.log2_p = vm.log2_p; bl.input_slot = vm.input_slot; bl.to_ring = ring; bl.to_ws = ws; bl.general = vm.general;
         if (vm.general) { bl.group_off.push_back(0); bl.group_off.push_back(0); }
         if (vm.jit) { bl.jit = true; bl.shape = vm.shape; bl.varying = vm.varying; bl.literal_bits = vm.literal_bits; bl.alias = vm.alias; bl.k = vm.k; }
         banks.push_back(std::move(bl));
@@ -355,9 +357,18 @@ bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unorde
 }  // namespace
 
 StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p, bool allow_jit, bool allow_template,
-                       BankMatcher *reuse) {
+                       BankMatcher *reuse, const ShardSpec *shard) {
     StagedPlan sp;
     const uint32_t n_rows = (uint32_t)g.outputs.size();
+    // Sharding (friendship_render.h fr_shard).  FR_SHARD_VOICES: plan only what this rank's rows need.  FR_SHARD_PARTIALS:
+    // analyse the whole graph (every rank must arrive at the same list of split voices and the same look-back), then keep
+    // the programs this rank's rows need, its own sub-tree of every split voice, and the unsplit voices it needs.
+    const bool sharded = shard && shard->world > 1 && shard->mode != FR_SHARD_NONE;
+    const bool partials = sharded && shard->mode == FR_SHARD_PARTIALS;
+    const uint32_t my_rank = sharded ? shard->rank : 0, world = sharded ? shard->world : 1;
+    uint32_t my_lo = 0, my_hi = n_rows;
+    if (sharded) shard_row_range(my_rank, world, n_rows, my_lo, my_hi);
+    auto mine = [&](uint32_t row) { return row >= my_lo && row < my_hi; };
     std::unique_ptr<BankMatcher> own;
     BankMatcher *matcher = nullptr;
     if (allow_banks) {
@@ -370,10 +381,11 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
 
     std::vector<uint32_t> staged_rows;
     for (uint32_t row = 0; row < n_rows; ++row) {
+        if (sharded && !partials && !mine(row)) continue;
         uint32_t root = g.outputs[row];
         bool root_is_bank = P.is_voice(root);
         if (root_is_bank || (allow_programs && P.supported(root))) staged_rows.push_back(row);
-        else sp.pull_rows.push_back(row);
+        else if (mine(row)) sp.pull_rows.push_back(row);   // (another rank's pull row: that rank evaluates all of it)
     }
     for (uint32_t row : staged_rows) P.explore(g.outputs[row]);
     for (auto &kv : P.bank_of) P.cut.erase(kv.first);   // a Delay's source that is a voice is computed by the bank kernel
@@ -415,6 +427,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         fb.pull_rows = sp.pull_rows;
         std::unordered_map<std::string, size_t> grp;
         for (uint32_t row : staged_rows) {
+            if (!mine(row)) continue;
             auto it = P.bank_of.find(g.outputs[row]);
             if (it == P.bank_of.end()) { fb.pull_rows.push_back(row); continue; }
             const VoiceMatch &vm = it->second;
@@ -453,18 +466,114 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         sp.lmax = std::max(sp.lmax, L[n]);
     }
 
+    // Which ranks need each cut node / voice (partial-block sharding): everything reachable from the roots of a rank's
+    // rows without entering a voice.  One bit per rank.
+    std::unordered_map<uint32_t, uint64_t> need;
+    if (partials) {
+        for (uint32_t o = 0; o < world; ++o) {
+            uint32_t lo, hi;
+            shard_row_range(o, world, n_rows, lo, hi);
+            std::unordered_set<uint32_t> seen;
+            std::vector<uint32_t> st;
+            for (uint32_t row : staged_rows)
+                if (row >= lo && row < hi) st.push_back(g.outputs[row]);
+            while (!st.empty()) {
+                uint32_t n = st.back();
+                st.pop_back();
+                if (!seen.insert(n).second) continue;
+                if (P.bank_of.count(n)) { need[n] |= 1ull << o; continue; }
+                if (P.cut.count(n)) need[n] |= 1ull << o;   // (a root that is itself an input or a constant is a cut node too)
+                if (P.is_leaf(n)) continue;
+                const FlatNode &x = g.nodes[n];
+                st.push_back(x.a);
+                if (x.op != OP_DELAY || P.dyn_max.count(n)) st.push_back(x.b);
+            }
+        }
+    }
+    auto needed = [&](uint32_t n) {
+        if (!partials) return true;
+        auto it = need.find(n);
+        return it != need.end() && ((it->second >> my_rank) & 1ull) != 0;
+    };
+    // output rows this rank writes, per root
+    std::unordered_map<uint32_t, std::vector<uint32_t>> my_rows_of;
+    for (auto &kv : rows_of)
+        for (uint32_t row : kv.second)
+            if (mine(row)) my_rows_of[kv.first].push_back(row);
+
     // bank launches: voices that go straight to one output row, and voices that fill rings
     {
         std::unordered_map<std::string, size_t> grp;
         std::vector<uint32_t> bank_nodes;
         for (auto &kv : P.bank_of) bank_nodes.push_back(kv.first);
         std::sort(bank_nodes.begin(), bank_nodes.end());
+        uint32_t kbits = 0;
+        while ((1u << kbits) < world) ++kbits;
+        struct Split { uint32_t key, node; SplitVoice sv; VoiceMatch sub; };
+        std::vector<Split> splits;
         for (uint32_t n : bank_nodes) {
             const VoiceMatch &vm = P.bank_of[n];
             bool ring = needs_ring.count(n) != 0;
             auto ro = rows_of.find(n);
             if (!ring && ro == rows_of.end()) continue;   // unreachable
-            add_voice(sp.banks, grp, vm, ring ? ring_of[n] : ro->second[0], ring);
+            const uint64_t mask = partials ? need[n] : 0;
+            if (partials && mask != 0 && (mask & (mask - 1)) == 0) {
+                // needed by exactly one rank: cut it at the top log2(world) levels of its Sum2 tree; this rank renders
+                // sub-tree number `my_rank` of it.  A balanced template voice is cut by slicing its parameters (leaves are
+                // collected left to right); any other voice by matching the sub-roots themselves.
+                uint32_t owner = 0;
+                while (!((mask >> owner) & 1ull)) ++owner;
+                VoiceMatch sub;
+                bool ok_split = false;
+                if (!vm.general && !vm.jit && vm.log2_p >= kbits + 5) {
+                    sub.log2_p = vm.log2_p - kbits;
+                    sub.input_slot = vm.input_slot;
+                    sub.fast_ok = vm.fast_ok;
+                    const size_t per = (size_t)2 << sub.log2_p;
+                    sub.params.assign(vm.params.begin() + (ptrdiff_t)(per * my_rank), vm.params.begin() + (ptrdiff_t)(per * (my_rank + 1)));
+                    ok_split = true;
+                } else if (vm.general || vm.jit) {
+                    std::vector<uint32_t> subs{n};
+                    ok_split = true;
+                    for (uint32_t lv = 0; lv < kbits && ok_split; ++lv) {
+                        std::vector<uint32_t> nx;
+                        for (uint32_t x : subs) {
+                            if (g.nodes[x].op != OP_SUM2) { ok_split = false; break; }
+                            nx.push_back(g.nodes[x].a);
+                            nx.push_back(g.nodes[x].b);
+                        }
+                        subs.swap(nx);
+                    }
+                    for (size_t i = 0; ok_split && i < subs.size(); ++i) ok_split = matcher->match(subs[i]) != nullptr;
+                    if (ok_split) sub = *matcher->match(subs[my_rank]);
+                }
+                if (ok_split) {
+                    uint32_t rev = 0;   // exchange order: by the owner's bits, lowest first, so every step's ranges are contiguous
+                    for (uint32_t b = 0; b < kbits; ++b) rev |= ((owner >> b) & 1u) << (kbits - 1 - b);
+                    Split sp1;
+                    sp1.key = rev;
+                    sp1.node = n;
+                    sp1.sv.owner = owner;
+                    sp1.sv.to_ring = ring;
+                    sp1.sv.dst = ring ? ring_of[n] : ro->second[0];
+                    sp1.sub = std::move(sub);
+                    splits.push_back(std::move(sp1));
+                    continue;
+                }
+            }
+            if (!needed(n)) continue;
+            if (!ring) {
+                auto mr = my_rows_of.find(n);
+                if (mr == my_rows_of.end()) continue;
+                add_voice(sp.banks, grp, vm, mr->second[0], false);
+            } else {
+                add_voice(sp.banks, grp, vm, ring_of[n], true);
+            }
+        }
+        std::stable_sort(splits.begin(), splits.end(), [](const Split &a, const Split &b) { return a.key != b.key ? a.key < b.key : a.node < b.node; });
+        for (size_t i = 0; i < splits.size(); ++i) {
+            sp.split.push_back(splits[i].sv);
+            add_voice(sp.banks, grp, splits[i].sub, (uint32_t)i, false, true);
         }
     }
 
@@ -475,12 +584,13 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
     extra.reserve(n_rows);
     uint32_t max_level = 0;
     for (uint32_t m : cuts) {
-        auto ro = rows_of.find(m);
-        int32_t row0 = ro != rows_of.end() ? (int32_t)ro->second[0] : -1;
+        if (!needed(m)) continue;
+        auto ro = my_rows_of.find(m);
+        int32_t row0 = ro != my_rows_of.end() ? (int32_t)ro->second[0] : -1;
         pend.push_back({level[m], m, &built[m], needs_ring.count(m) ? ring_of[m] : NO_RING, row0});
         max_level = std::max(max_level, level[m]);
     }
-    for (auto &kv : rows_of) {
+    for (auto &kv : my_rows_of) {
         bool bank = P.bank_of.count(kv.first) != 0;
         size_t first_extra = (bank && !needs_ring.count(kv.first)) ? kv.second.size() : (bank ? 0 : 1);
         for (size_t i = first_extra; i < kv.second.size(); ++i) {
@@ -540,17 +650,18 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
             fprogs.push_back(pg);
         };
         for (uint32_t m : cuts) {
-            auto ro = rows_of.find(m);
+            if (!needed(m)) continue;
+            auto ro = my_rows_of.find(m);
             bool sink = !same_frame_used.count(m);
             // a non-sink with output rows still needs those rows written: compute it as its own (fused) program too
-            if (!sink && ro == rows_of.end()) continue;
+            if (!sink && ro == my_rows_of.end()) continue;
             ProgBuild pb;
             if (!build_program(g, P, m, dense_input, sp.input_slots, pb, true, &needs_ring, &min_delay)) { fits = false; break; }
-            emit(pb, needs_ring.count(m) ? ring_of[m] : NO_RING, ro != rows_of.end() ? (int32_t)ro->second[0] : -1);
-            if (ro != rows_of.end())
+            emit(pb, needs_ring.count(m) ? ring_of[m] : NO_RING, ro != my_rows_of.end() ? (int32_t)ro->second[0] : -1);
+            if (ro != my_rows_of.end())
                 for (size_t i = 1; i < ro->second.size(); ++i) emit(pb, NO_RING, (int32_t)ro->second[i]);   // extra rows: recompute
         }
-        for (auto &kv : rows_of) {   // bank roots that live in a ring: copy programs, as in the level form
+        for (auto &kv : my_rows_of) {   // bank roots that live in a ring: copy programs, as in the level form
             if (!P.bank_of.count(kv.first) || !needs_ring.count(kv.first)) continue;
             for (uint32_t row : kv.second) {
                 ProgBuild pb;
@@ -563,7 +674,8 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         if (fits && !fprogs.empty() && min_delay >= 64) {
             sp.fused_first = (uint32_t)sp.progs.size();
             sp.fused_count = (uint32_t)fprogs.size();
-            sp.fused_max_frames = min_delay;
+            // no delayed read of a program ring at all (min_delay untouched): a steady call of any length is one launch
+            sp.fused_max_frames = std::min<uint64_t>(min_delay, FUSED_UNBOUNDED);
             sp.instrs.insert(sp.instrs.end(), finstrs.begin(), finstrs.end());
             sp.progs.insert(sp.progs.end(), fprogs.begin(), fprogs.end());
         }

@@ -1,6 +1,7 @@
 // stage.hpp -- plan of the staged (materialised) evaluation: fused banks + per-cut-node register programs.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <memory>
 #include <vector>
@@ -17,6 +18,7 @@ struct BankLaunch {
     uint32_t input_slot = 0;
     bool fast_ok = true;
     bool to_ring = false;            // rows are ring indices (window with look-back) instead of output rows
+    bool to_ws = false;              // rows index the exchange workspace (partial-block sharding: this rank's sub-trees)
     std::vector<uint32_t> rows;      // destination row per voice
     std::vector<float> params;       // balanced: [voices][P]{w, -4*amp}; general: [groups][8]{w, -4*amp}
     bool general = false;            // voices are arbitrary Sum2 trees evaluated by schedule (match.hpp VoiceMatch)
@@ -32,8 +34,36 @@ struct BankLaunch {
     uint32_t k = 0;
 };
 
+// How the job is split over `world` renderers, one per GPU (friendship_render.h fr_shard).  Output rows are owned in
+// contiguous blocks; every rank plans from the same graph with the same code, so what must agree between ranks -- the
+// list of split voices and its order, the look-back window -- agrees by construction.
+struct ShardSpec {
+    uint32_t rank = 0, world = 1;
+    int mode = FR_SHARD_NONE;
+};
+inline void shard_row_range(uint32_t rank, uint32_t world, uint32_t n_rows, uint32_t &lo, uint32_t &hi) {
+    const uint32_t q = n_rows / world, r = n_rows % world;
+    lo = rank * q + std::min(rank, r);
+    hi = lo + q + (rank < r ? 1u : 0u);
+}
+inline uint32_t shard_row_owner(uint32_t row, uint32_t world, uint32_t n_rows) {
+    const uint32_t q = n_rows / world, r = n_rows % world;
+    const uint32_t big = r * (q + 1);   // rows held by the ranks that own q + 1 rows
+    return row < big ? row / (q + 1) : r + (q ? (row - big) / q : 0);
+}
+
+// A bank voice cut at the top log2(world) levels of its Sum2 tree (FR_SHARD_PARTIALS): row i of the exchange
+// workspace.  Every rank renders its own sub-tree of it; after the exchange the owner holds the voice's value and
+// stores it where the unsharded plan would have: ring `dst` (to_ring) or output row `dst`.
+struct SplitVoice {
+    uint32_t owner = 0;
+    bool to_ring = false;
+    uint32_t dst = 0;
+};
+
 struct StagedPlan {
     std::vector<BankLaunch> banks;
+    std::vector<SplitVoice> split;         // exchange workspace rows, in exchange order (same on every rank)
     std::vector<StageInstr> instrs;
     std::vector<StageProg> progs;          // ordered by level
     std::vector<uint32_t> level_first;     // level l = progs[level_first[l] .. level_first[l+1])
@@ -53,6 +83,6 @@ struct StagedPlan {
 // (incremental re-planning after a graph edit: unchanged voices are answered from its memo).
 class BankMatcher;
 StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p, bool allow_jit = false,
-                       bool allow_template = true, BankMatcher *reuse = nullptr);
+                       bool allow_template = true, BankMatcher *reuse = nullptr, const ShardSpec *shard = nullptr);
 
 }  // namespace fr

@@ -15,6 +15,14 @@
 //   * Delay amount NaN: `NaN as u64` = 0 (saturating-cast Rust; UB on 2017 nightlies).
 //   * Delay amount < 0: clamps to 0 (RefRenderer, reference.rs:206-207), NOT SparkleRenderer's
 //     "return 0.0" (sparkle.rs:531-534).
+// fr_config.semantics = FR_SEMANTICS_SPARKLE switches exactly the two places where the reference's second
+// renderer, SparkleRenderer, computes something else (also unpinned by any reference test):
+//   * Minimum = select(fcmp ult a, b, a, b) (sparkle.rs:492-498): NaN in either operand returns `a`;
+//   * Delay amount `ult 0` (negative or NaN) returns 0.0 from the function (sparkle.rs:525-542).
+//
+// Sharding (fr_set_shard): the oracle renders the rows a rank owns by plain evaluation -- output slots are
+// independent (reference.rs:78-82), so that IS the unsharded result for those rows -- and leaves the rest
+// untouched; FR_SHARD_GATHER moves rows to rank 0 through the host callback.  It never splits a voice.
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
 // The product library (libfriendship_hip.so) never links, loads or calls it.
@@ -66,6 +74,7 @@ struct InputGetter {
 struct NodeMap {
     std::unordered_map<uint32_t, Node> nodes;
     std::vector<MaybeEdge> output_edges;
+    bool sparkle = false;   // FR_SEMANTICS_SPARKLE (set on every nested map by make_node)
 
     // reference.rs:141-153
     void add_edge(const Edge &e) {
@@ -140,6 +149,7 @@ float NodeMap::get_edge_value(uint64_t time, const Edge &edge, const InputGetter
         need_slot0();
         float delay_frames = get_maybe_edge_value(time, inb(node, 1), gi);
         if (delay_frames >= 18446744073709551616.0f) return 0.0f;  // >= 2^64, :202-205
+        if (sparkle && !(delay_frames >= 0.0f)) return 0.0f;       // sparkle.rs:531-534: `ult 0` (negative or NaN) -> ret 0
         uint64_t delay_int;
         if (delay_frames < 0.0f) delay_int = 0;                      // :206-207
         else if (delay_frames != delay_frames) delay_int = 0;        // NaN as u64 == 0
@@ -174,6 +184,7 @@ float NodeMap::get_edge_value(uint64_t time, const Edge &edge, const InputGetter
         need_slot0();
         float l = get_maybe_edge_value(time, inb(node, 0), gi);
         float r = get_maybe_edge_value(time, inb(node, 1), gi);
+        if (sparkle) return (l < r || l != l || r != r) ? l : r;   // sparkle.rs:495-496: select(fcmp ult l, r, l, r)
         return rust_min(l, r);
     }
     case FR_PRIM_MODULO: {  // :249-262
@@ -214,6 +225,21 @@ struct fr_renderer {
     uint64_t head = 0;        // reference.rs:28
     unsigned threads = 1;
     std::string last_error;
+    bool sparkle = false;
+    // fr_set_shard
+    uint32_t rank = 0, world = 1, shard_flags = 0;
+    int shard_mode = FR_SHARD_NONE;
+    fr_comm comm{};
+    bool has_comm = false;
+    void my_rows(uint32_t n_slots, uint32_t &lo, uint32_t &hi) const { rows_of(rank, n_slots, lo, hi); }
+    void rows_of(uint32_t rk, uint32_t n_slots, uint32_t &lo, uint32_t &hi) const {
+        lo = 0;
+        hi = n_slots;
+        if (world <= 1 || shard_mode == FR_SHARD_NONE) return;
+        const uint32_t q = n_slots / world, r = n_slots % world;
+        lo = rk * q + (rk < r ? rk : r);
+        hi = lo + q + (rk < r ? 1u : 0u);
+    }
 
     uint64_t implicit_len(uint64_t slot) const {
         for (const Seg &s : segs) if (slot >= s.first && slot < s.last) return s.len;
@@ -237,19 +263,20 @@ struct fr_renderer {
     }
 
     // reference.rs:98-113
-    static void make_node(Node &dst, const fr_effect *e, int depth) {
+    static void make_node(Node &dst, const fr_effect *e, int depth, bool sparkle = false) {
         if (!e) throw Panic(FR_ERR_INVALID_ARG, "null effect");
         if (depth > 256) throw Panic(FR_ERR_INVALID_ARG, "effect nesting too deep");
         if (e->kind < 0 || e->kind > FR_EFFECT_GRAPH) throw Panic(FR_ERR_INVALID_ARG, "bad effect kind");
         dst.kind = e->kind;
         if (e->kind != FR_EFFECT_GRAPH) return;
         dst.user = std::make_unique<NodeMap>();
+        dst.user->sparkle = sparkle;
         if ((e->n_nodes && (!e->node_handles || !e->node_effects)) || (e->n_edges && !e->edges))
             throw Panic(FR_ERR_INVALID_ARG, "composite effect with null arrays");
         for (uint32_t i = 0; i < e->n_nodes; ++i) {
             if (e->node_handles[i] == 0) throw Panic(FR_ERR_INVALID_ARG, "node handle 0 is reserved");
             Node n;
-            make_node(n, e->node_effects[i], depth + 1);
+            make_node(n, e->node_effects[i], depth + 1, sparkle);
             dst.user->nodes[e->node_handles[i]] = std::move(n);
         }
         for (uint32_t i = 0; i < e->n_edges; ++i) dst.user->add_edge(e->edges[i]);
@@ -293,6 +320,8 @@ struct fr_renderer {
     }
 
     void render(float *out, uint32_t n_slots, uint64_t n_times, uint64_t idx) {  // :77-84
+        uint32_t row_lo, row_hi;
+        my_rows(n_slots, row_lo, row_hi);
         auto rows = [&](uint32_t s0, uint32_t s1) {
             for (uint32_t slot = s0; slot < s1; ++slot)
                 for (uint64_t time = idx; time < idx + n_times; ++time)
@@ -300,8 +329,8 @@ struct fr_renderer {
         };
         unsigned nt = threads < 1 ? 1 : threads;
         if (nt > n_slots) nt = n_slots ? n_slots : 1;
-        if (nt <= 1) {
-            rows(0, n_slots);
+        if (nt <= 1 || row_lo != 0 || row_hi != n_slots) {
+            rows(row_lo, row_hi);
         } else {
             // Output slots are independent (the loop of reference.rs:78 carries no state).  Used only
             // for the "all host cores" baseline figure; default is the reference's single thread.
@@ -355,8 +384,12 @@ extern "C" {
 fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     if (!out) return FR_ERR_INVALID_ARG;
     if (cfg && cfg->abi_version != FR_ABI_VERSION) return FR_ERR_INVALID_ARG;
+    if (cfg && cfg->semantics != FR_SEMANTICS_REFERENCE && cfg->semantics != FR_SEMANTICS_SPARKLE) return FR_ERR_INVALID_ARG;
     *out = new (std::nothrow) fr_renderer();
-    return *out ? FR_OK : FR_ERR_OUT_OF_MEMORY;
+    if (!*out) return FR_ERR_OUT_OF_MEMORY;
+    (*out)->sparkle = cfg && cfg->semantics == FR_SEMANTICS_SPARKLE;   // (history_frames: the oracle keeps everything)
+    (*out)->nodes.sparkle = (*out)->sparkle;
+    return FR_OK;
 }
 
 void fr_renderer_destroy(fr_renderer *r) { delete r; }
@@ -365,7 +398,7 @@ fr_status fr_on_add_node(fr_renderer *r, uint32_t handle, const fr_effect *effec
     return guarded(r, [&] {
         if (handle == 0) throw Panic(FR_ERR_INVALID_ARG, "node handle 0 is reserved for graph I/O");
         Node n;
-        fr_renderer::make_node(n, effect, 0);
+        fr_renderer::make_node(n, effect, 0, r->sparkle);
         r->nodes.nodes[handle] = std::move(n);  // HashMap::insert replaces
     });
 }
@@ -425,7 +458,45 @@ fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t 
         r->store_inputs(n_slots, n_times, idx, in_data, in_row_offsets, n_in_rows);
         r->render(out, n_slots, n_times, idx);
         r->head = idx + n_times;  // :84
+        if (r->world > 1 && r->shard_mode != FR_SHARD_NONE && (r->shard_flags & FR_SHARD_GATHER)) {
+            if (!r->has_comm) throw Panic(FR_ERR_COMM, "FR_SHARD_GATHER needs a host transport");
+            auto xfer = [&](uint32_t peer, const float *snd, size_t ns, float *rcv, size_t nr) {
+                if (r->comm.sendrecv(r->comm.ctx, peer, snd, ns * sizeof(float), rcv, nr * sizeof(float)) != 0)
+                    throw Panic(FR_ERR_COMM, "transport callback failed");
+            };
+            uint32_t lo, hi;
+            if (r->rank == 0) {
+                for (uint32_t p = 1; p < r->world; ++p) {
+                    r->rows_of(p, n_slots, lo, hi);
+                    xfer(p, nullptr, 0, out + (size_t)lo * n_times, (size_t)(hi - lo) * n_times);
+                }
+            } else {
+                r->my_rows(n_slots, lo, hi);
+                xfer(0, out + (size_t)lo * n_times, (size_t)(hi - lo) * n_times, nullptr, 0);
+            }
+        }
     });
+}
+
+fr_status fr_comm_unique_id(uint8_t *) { return FR_ERR_UNSUPPORTED; }   // (RCCL is the product's transport)
+
+fr_status fr_set_shard(fr_renderer *r, const fr_shard *sh) {
+    return guarded(r, [&] {
+        r->rank = 0; r->world = 1; r->shard_mode = FR_SHARD_NONE; r->shard_flags = 0; r->has_comm = false;
+        if (!sh || sh->world <= 1 || sh->mode == FR_SHARD_NONE) return;
+        if ((sh->mode != FR_SHARD_VOICES && sh->mode != FR_SHARD_PARTIALS) || sh->world > 64 || sh->rank >= sh->world)
+            throw Panic(FR_ERR_INVALID_ARG, "bad shard description");
+        if (sh->mode == FR_SHARD_PARTIALS && (sh->world & (sh->world - 1))) throw Panic(FR_ERR_INVALID_ARG, "world must be a power of two");
+        if (sh->rccl_id) throw Panic(FR_ERR_UNSUPPORTED, "the CPU oracle has no RCCL transport");
+        r->rank = sh->rank; r->world = sh->world; r->shard_mode = sh->mode; r->shard_flags = sh->flags;
+        if (sh->comm) { r->comm = *sh->comm; r->has_comm = true; }
+    });
+}
+
+fr_status fr_shard_rows(const fr_renderer *r, uint32_t n_slots, uint32_t *lo, uint32_t *hi) {
+    if (!r || !lo || !hi) return FR_ERR_INVALID_ARG;
+    r->my_rows(n_slots, *lo, *hi);
+    return FR_OK;
 }
 
 fr_status fr_fill_buffer_device(fr_renderer *r, float *, uint32_t, uint64_t, uint64_t, const float *,

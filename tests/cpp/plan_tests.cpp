@@ -189,6 +189,7 @@ struct StagedSim {
     std::vector<std::map<uint64_t, float>> rings;
     bool valid = false;
     uint64_t end = 0;
+    uint64_t fused_launches = 0;
     explicit StagedSim(const StagedPlan &p) : sp(p), rings(p.n_rings) {}
 
     void run_progs(uint32_t first, uint32_t count, uint64_t w0, uint64_t wlen, uint64_t idx, uint64_t T, const Inputs &in, std::vector<float> &out) {
@@ -252,12 +253,17 @@ struct StagedSim {
                 }
             }
         size_t n_levels = sp.level_first.empty() ? 0 : sp.level_first.size() - 1;
-        uint64_t n_sub = sp.fused_count ? (T + sp.fused_max_frames - 1) / sp.fused_max_frames : 0;
+        const uint64_t fstep = std::max<uint64_t>(sp.fused_max_frames, 1);
+        uint64_t n_sub = sp.fused_count ? (T - 1) / fstep + 1 : 0;
         bool fused = !force_levels && sp.fused_count && w0 == idx && valid && n_sub < n_levels;
         if (used_fused) *used_fused = fused;
         if (fused) {
-            for (uint64_t s0 = idx; s0 < idx + T; s0 += sp.fused_max_frames)
-                run_progs(sp.fused_first, sp.fused_count, s0, std::min<uint64_t>(sp.fused_max_frames, idx + T - s0), idx, T, in, out);
+            for (uint64_t done = 0; done < T;) {
+                const uint64_t len = std::min<uint64_t>(fstep, T - done);
+                run_progs(sp.fused_first, sp.fused_count, idx + done, len, idx, T, in, out);
+                done += len;
+                ++fused_launches;
+            }
         } else {
             for (size_t l = 0; l < n_levels; ++l)
                 run_progs(sp.level_first[l], sp.level_first[l + 1] - sp.level_first[l], w0, wlen, idx, T, in, out);
@@ -453,6 +459,38 @@ static void effects_chain_is_staged() {
     check_graph(b, 3, 33, 7, true, "effects chain, short calls");
 }
 
+// A non-bank root wired to two output rows with no delayed read of a program ring: the fused form has no frame limit
+// (fused_max_frames used to stay at ~0 and the engine's sub-window arithmetic wrapped: idx + 1 launches per call).
+static void shared_root_without_delays_is_one_launch() {
+    Build b;
+    uint32_t g = b.op(FR_PRIM_SUM2, N(b.op(FR_PRIM_MULTIPLY, In(0), Cf(0.5f))), In(1));   // a master gain sent to L and R
+    b.out(N(g), 0);
+    b.out(N(g), 1);
+    Mirror m;
+    b.apply(m);
+    FlatGraph fg = lower(m, 2);
+    StagedPlan sp = plan_stages(fg, true, true, 20);
+    CHECK(sp.fused_count > 0);
+    CHECK(sp.fused_max_frames >= 4800 && sp.fused_max_frames <= (1ull << 40));
+    StagedSim sim(sp);
+    Inputs hist(2);
+    const uint64_t T = 4800;
+    for (int c = 0; c < 3; ++c) {
+        uint64_t idx = (uint64_t)c * T;
+        for (uint64_t i = 0; i < T; ++i) { hist[0].push_back((float)(idx + i)); hist[1].push_back((float)(i % 7)); }
+        std::vector<float> out(2 * T, -1.0f);
+        bool uf = false;
+        const uint64_t before = sim.fused_launches;
+        sim.call(idx, T, hist, out, false, &uf);
+        if (c > 0) { CHECK(uf); CHECK(sim.fused_launches - before == 1); }   // steady state: exactly one launch
+        for (uint64_t i = 0; i < T; ++i) {
+            float e = flat_eval(fg, fg.outputs[0], idx + i, hist);
+            CHECK(same_bits(out[i], e) && same_bits(out[T + i], e));
+        }
+    }
+    check_graph(b, 2, 64, 4, true, "shared root");
+}
+
 static void dynamic_delay_goes_to_pull() {
     Build b;
     uint32_t amt = b.op(FR_PRIM_MULTIPLY, In(0), Cf(0.25f));   // no bound can be proven for this amount
@@ -581,11 +619,15 @@ struct JitSim {
                 }
             }
         size_t n_levels = sp.level_first.empty() ? 0 : sp.level_first.size() - 1;
-        uint64_t n_sub = sp.fused_count ? (T + sp.fused_max_frames - 1) / sp.fused_max_frames : 0;
+        const uint64_t fstep = std::max<uint64_t>(sp.fused_max_frames, 1);
+        uint64_t n_sub = sp.fused_count ? (T - 1) / fstep + 1 : 0;
         bool fused = sp.fused_count && w0 == idx && valid && n_sub < n_levels;
         if (fused) {
-            for (uint64_t s0 = idx; s0 < idx + T; s0 += sp.fused_max_frames)
-                launch(sp.fused_first, sp.fused_count, s0, std::min<uint64_t>(sp.fused_max_frames, idx + T - s0), idx, T, in, out);
+            for (uint64_t done = 0; done < T;) {
+                const uint64_t len = std::min<uint64_t>(fstep, T - done);
+                launch(sp.fused_first, sp.fused_count, idx + done, len, idx, T, in, out);
+                done += len;
+            }
         } else {
             for (size_t l = 0; l < n_levels; ++l)
                 launch(sp.level_first[l], sp.level_first[l + 1] - sp.level_first[l], w0, wlen, idx, T, in, out);
@@ -1056,6 +1098,7 @@ int main(int argc, char **argv) {
         {"lowering_folds_constants", lowering_folds_constants}, {"lowering_errors", lowering_errors},
         {"random_graphs_lower_correctly", random_graphs_lower_correctly}, {"banks_are_recognised", banks_are_recognised},
         {"effects_chain_is_staged", effects_chain_is_staged}, {"dynamic_delay_goes_to_pull", dynamic_delay_goes_to_pull},
+        {"shared_root_without_delays_is_one_launch", shared_root_without_delays_is_one_launch},
         {"composite_instances_are_interned", composite_instances_are_interned},
         {"stage_programs_compile_to_source", stage_programs_compile_to_source},
         {"incremental_lowering_equals_from_scratch", incremental_lowering_equals_from_scratch},

@@ -1,0 +1,61 @@
+// sim_hip.cpp -- TEST INFRASTRUCTURE ONLY.  Host-memory stand-ins for the HIP runtime calls engine.cpp makes, so that
+// the engine's HOST logic (input store, planning, windows and rings, sharding and its exchange schedule) can be
+// exercised on a machine without a GPU: "device" memory is malloc'ed host memory, streams run synchronously.
+// Linked only into tests/cpp/_build/libfr_simengine.so (tests/sim_tools.py); the product library links the real
+// libamdhip64 and has no CPU path.
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+
+struct ihipStream_t { int dummy; };
+struct ihipEvent_t { std::chrono::steady_clock::time_point t; };
+
+extern "C" {
+
+std::atomic<uint64_t> fr_sim_live_bytes{0};     // (device allocations are not tracked by size; kept for symmetry)
+std::atomic<uint64_t> fr_sim_allocs{0}, fr_sim_frees{0};
+
+const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : (e == hipErrorOutOfMemory ? "out of memory" : "simulated HIP error"); }
+hipError_t hipGetLastError(void) { return hipSuccess; }
+hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
+    std::memset(p, 0, sizeof *p);
+    std::strcpy(p->gcnArchName, "gfx950:sim");
+    return hipSuccess;
+}
+hipError_t hipMalloc(void **p, size_t n) {
+    *p = std::malloc(n ? n : 1);
+    if (!*p) return hipErrorOutOfMemory;
+    std::memset(*p, 0xA5, n);   // uninitialised device memory is not zero: make a read of it show
+    ++fr_sim_allocs;
+    return hipSuccess;
+}
+hipError_t hipFree(void *p) { if (p) ++fr_sim_frees; std::free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
+hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }
+hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t) { if (n) std::memmove(dst, src, n); return hipSuccess; }
+hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind) { if (n) std::memmove(dst, src, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t) { if (n) std::memset(dst, v, n); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new ihipStream_t{0}; return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t *e) { *e = new ihipEvent_t{}; return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new ihipEvent_t{}; return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+
+}  // extern "C"

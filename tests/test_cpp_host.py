@@ -9,10 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "cpp", "render_tests.cpp")
 BIN = os.path.join(ROOT, "tests", "cpp", "_build", "render_tests")
 HDR = os.path.join(ROOT, "libfriendship_amd", "host", "friendship.hpp")
+ABI = os.path.join(ROOT, "include", "friendship_render.h")
 
 
 def build():
-    if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+    if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(p) for p in (SRC, HDR, ABI)):
         os.makedirs(os.path.dirname(BIN), exist_ok=True)
         subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", "-o", BIN, SRC, "-ldl"], check=True)
     return BIN
@@ -44,11 +45,11 @@ def test_engine_host_logic_against_oracle(oracle_lib):
     """tests/cpp/plan_tests.cpp: the lowered graph and the staged plan (banks, rings, level and fused programs,
     general-tree schedules), executed by small CPU interpreters in the test, equal the oracle bit for bit; the source
     generated for compiled stage programs, built with g++, does too."""
-    deps = [PLAN_SRC] + [os.path.join(CSRC, f) for f in ("graph.cpp", "graph.hpp", "match.cpp", "match.hpp", "stage.cpp", "stage.hpp", "stagejit.cpp", "leafjit.cpp", "range.hpp", "jit.hpp", "kernels.hpp")]
+    deps = [PLAN_SRC, ABI] + [os.path.join(CSRC, f) for f in ("graph.cpp", "graph.hpp", "match.cpp", "match.hpp", "stage.cpp", "stage.hpp", "stagejit.cpp", "leafjit.cpp", "range.hpp", "jit.hpp", "kernels.hpp")]
     if not os.path.exists(PLAN_BIN) or os.path.getmtime(PLAN_BIN) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(PLAN_BIN), exist_ok=True)
         subprocess.run(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
                         "-Wno-subobject-linkage", "-o", PLAN_BIN, PLAN_SRC, "-ldl"], check=True)
     env = dict(os.environ, FRIENDSHIP_ORACLE_LIB=oracle_lib.path)
     p = subprocess.run([PLAN_BIN], env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and "13 passed; 0 failed" in p.stdout, p.stdout + p.stderr
+    assert p.returncode == 0 and "14 passed; 0 failed" in p.stdout, p.stdout + p.stderr
