@@ -6,18 +6,28 @@ the whole tree, all 64 voice rows), 48 kHz synthetic tree, plus achieved rates a
 
 A "step" is one `fill_buffer` call of T = 4800 frames (0.1 s of audio) over the full tree, through the
 C ABI's device-resident entry point: the time-ramp input and the output buffer are already in HBM when
-the timed region starts (PCIe-inclusive figures are in DESIGN.md, never in `value`).
+the timed region starts.  The K-step timed loop (barrier + synchronize on both sides, max over ranks) is
+repeated R times; `ms_per_step` / `value` are the MEDIAN repeat, min and max are reported beside it.
+The reference-shaped host-buffer call (`fr_fill_buffer`: host rows in, host buffer out, synchronous) is
+timed separately as `host_api` -- PCIe- and sync-inclusive, never `value`.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the job is striped over time -- rank r
-renders its own contiguous stripe of frames of the same tree.  The evaluator is a pure function of
-(graph, input history, t) (reference src/render/reference.rs:178-266), so stripes are independent: no
-data-path collective, weak scaling, value = frames rendered by all ranks / max-over-ranks time.
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank receives the SAME graph through
+the ordinary ABI and `fr_set_shard` makes it rank r of N -- sharding is a property of the engine.
+  voices   (default) rank r renders its block of the 64 output rows: strong scaling, no collective.
+  partials (default from 16384 partials per voice up: BASELINE configs[4]) every voice's Sum2 tree is cut
+           at its top log2(N) levels, rank r renders block r of every voice, one recursive-halving exchange
+           over the engine's own RCCL communicator (xGMI) sums the blocks in the tree's own association and
+           leaves every rank with the finished voices it owns.  Strong scaling, bit-exact.
+  time     an extra: N independent replicas rendering different frames of the same tree (weak scaling).
+`value` = frames rendered by the job / max-over-ranks time.
 
 Prints ONE JSON line on stdout (rank 0); diagnostics go to stderr.
 """
 import argparse
+import glob
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -29,14 +39,28 @@ sys.path.insert(0, ROOT)
 # MI355X ceilings (/opt/skills/guides/MI355X_MICROARCH.md: chip-level parameters, cycle constants)
 HBM_PEAK_GBS = 8000.0                       # spec; 6290 measured copy
 VALU_LANE_RATE = 256 * 4 * 32 * 2.4e9       # f32 VALU lane-ops/s: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12
-FMA_PEAK_TFLOPS = 157.3                     # the same rate counted as FMA (2 flops); unusable here, see DESIGN.md
 OPS_EXECUTED_PER_PF = 6                     # VALU ops the fused kernel issues per partial-frame: mul, fract, fma, fma, mul + 1 tree add
 ISSUE_SLOTS_PER_PF = 7                      # v_fract_f32 issues at half rate on gfx950 (measured 4.07 vs 2.2 cyc, profiles/r01_valu_rate.txt)
 OPS_GRAPH_PER_PF = 12                       # primitive nodes the reference evaluates per partial-frame (11 + Sum2)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_bank_pmc_summary.json")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def shader_clock_mhz():
+    """Current shader clock of the busiest amdgpu card from sysfs (the line marked '*'), or None."""
+    best = None
+    for path in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
+        try:
+            for line in open(path):
+                if "*" in line:
+                    mhz = float(line.split(":")[1].strip().split("M")[0])
+                    best = mhz if best is None else max(best, mhz)
+        except Exception:
+            pass
+    return best
 
 
 def cpu_baseline(tree, V, P, frames_1t, frames_mt):
@@ -92,20 +116,25 @@ def run():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="how many times the K-step timed loop runs (median reported); 0 = as many as make the timed loops "
+                         "last about 0.6 s in all, at least 3, at most 50")
     ap.add_argument("--voices", type=int, default=64)
     ap.add_argument("--partials", type=int, default=4096)
     ap.add_argument("--frames", type=int, default=4800, help="frames per fill_buffer call (T)")
     ap.add_argument("--mode", default="auto", choices=["auto", "pull"])
-    ap.add_argument("--shard", default="time", choices=["time", "voices", "partials"],
-                    help="how N > 1 ranks split the job (libfriendship_amd/shard.py): time stripes (weak scaling, no exchange; "
-                         "default), voices (strong, no exchange), partial blocks (strong, RCCL all-gather + tree-order sum)")
+    ap.add_argument("--shard", default="auto", choices=["auto", "voices", "partials", "time"],
+                    help="how N > 1 ranks split the job (fr_set_shard): voices (strong scaling, no exchange; the default), "
+                         "partials (the default from 16384 partials per voice: partial blocks + one RCCL exchange), "
+                         "time (an extra: independent replicas on different frames, weak scaling)")
     ap.add_argument("--tree", default="additive", choices=["additive", "effects", "chorus"],
                     help="additive = BASELINE configs[2] shape (the headline); effects = configs[3] shape (detune + ADSR + "
                          "4-tap delay chain), a diagnostic run: use with --voices 128 --partials 1024 --no-cpu-baseline; "
                          "chorus = every voice through a Delay with a SIGNAL amount (LFO) + the 4-tap chain, also a diagnostic")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl is RCCL on ROCm (default)")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="initialise torch.distributed even with one rank and take the partial-shard exchange path (RCCL plumbing check)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl is RCCL on ROCm (default): torch.distributed for the barrier and the engine's own RCCL "
+                         "communicator for the exchange; gloo = rehearsal on a one-GPU box (exchange through the host callback)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (plumbing check)")
     ap.add_argument("--wrap-voices", type=int, default=0,
                     help="effects tree only, shape sweeps: fundamentals repeat every N voices (synth.voice_params wrap); the "
                          "survey's 55*2^(v/12) puts voices beyond v~150 above any representable pitch (identically zero mixes)")
@@ -113,10 +142,8 @@ def run():
                     help="issue consecutive steps round-robin on this many HIP streams (each with its own output buffer): calls "
                          "of a plan without delay state are independent and the engine lets them overlap on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extras", "--short-blocks", dest="short_blocks", action="store_true",
-                    help="after the timed region also time (a) the same steps overlapped on two streams -> `overlapped_calls` and "
-                         "(b) 64- and 512-frame calls (SURVEY.md 8d) -> `short_blocks`; off by default so that the default command "
-                         "launches only the timed workload's kernels (rocprof summaries)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed workload's kernels (for rocprof runs): no host_api, short_blocks or overlapped_calls legs")
     ap.add_argument("--cpu-frames", type=int, default=144,
                     help="frames the CPU path renders single-threaded for cpu_baseline and the parity check (about 12 s)")
     args = ap.parse_args()
@@ -146,30 +173,57 @@ def run():
             dist.init_process_group("gloo")
 
     V, P, T, K, W = args.voices, args.partials, args.frames, args.steps, args.warmup
+    shard_mode = args.shard
+    if shard_mode == "auto":
+        shard_mode = "partials" if P >= 16384 and world > 1 and (world & (world - 1)) == 0 else "voices"
+    if world == 1:
+        shard_mode = "none"
     t_build = time.perf_counter()
-    from libfriendship_amd import shard
-    shard_mode = args.shard if use_dist else "time"
-    # seeded synthetic tree, ~12 primitive nodes per partial; under voices/partials sharding each rank
-    # holds only its sub-graph
-    if args.tree in ("effects", "chorus"):
-        assert world == 1, "the effects and chorus trees are single-GPU diagnostics"
-        tree = synth.effects_tree(V, P, wrap=args.wrap_voices or None) if args.tree == "effects" else synth.chorus_tree(V, P, taps=4)
-        shard_info = {"partials": (0, P), "voices": (0, V), "mode": "time"}
+    # Seeded synthetic tree, ~12 primitive nodes per partial plus the harmonics / detune / sample-rate
+    # arithmetic as Multiply / Divide nodes over constants (N3, N4: the reference has only the seven primitives).  EVERY
+    # rank installs the whole tree: what a rank renders is decided by the engine (fr_set_shard), not by graph surgery.
+    if args.tree == "effects":
+        tree = synth.effects_tree(V, P, wrap=args.wrap_voices or None, params_as_nodes=True)
+    elif args.tree == "chorus":
+        tree = synth.chorus_tree(V, P, taps=4)
     else:
-        tree, shard_info = shard.additive_tree_shard(V, P, rank, world, shard_mode)
-    full_tree = tree if shard_mode == "time" else None
-    V_local = tree["n_outputs"]
+        tree = synth.additive_tree(V, P, params_as_nodes=True)
     hip = libfriendship_amd.HipRenderer(mode=args.mode, device=local_rank)
     synth.install(hip, tree)
     log(f"[rank {rank}] graph: {len(tree['handles'])} nodes, {len(tree['edges'])} edges, "
         f"installed in {time.perf_counter() - t_build:.1f}s")
 
-    # this rank's stripe of frames; every step's time-ramp row is already resident in HBM.  The ramp is the f32 frame
-    # number, exact below 2^24, so its VALUES wrap at 2^23 (idx itself, a u64, keeps counting); rows live in a ring of
-    # at most 64 steps so that any --steps fits in memory.
-    n_calls = W + K
-    stripe0 = rank * n_calls * T if shard_mode == "time" else 0
-    ring_steps = min(n_calls, 64)
+    transport = "none"
+    if world > 1 and shard_mode in ("voices", "partials"):
+        if args.backend == "nccl":
+            # the engine's own communicator: rank 0 draws the id, torch.distributed carries the 128 bytes
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(libfriendship_amd.hip_lib().comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            hip.set_shard(rank, world, shard_mode, rccl_id=bytes(idt.cpu().numpy().tobytes()))
+            transport = "rccl"
+        else:
+            def sendrecv(peer, send, recv):   # rehearsal: host buffers over gloo
+                reqs, rt = [], None
+                if send is not None:
+                    reqs.append(dist.isend(torch.from_numpy(send.copy()), peer))
+                if recv is not None:
+                    rt = torch.empty(recv.size, dtype=torch.uint8)
+                    reqs.append(dist.irecv(rt, peer))
+                for q in reqs:
+                    q.wait()
+                if recv is not None:
+                    recv[:] = rt.numpy()
+            hip.set_shard(rank, world, shard_mode, sendrecv=sendrecv)
+            transport = "host-callback (gloo)"
+    row_lo, row_hi = hip.shard_rows(V)
+
+    # Every step's time-ramp row is already resident in HBM.  The ramp is the f32 frame number, exact below 2^24, so
+    # its VALUES wrap at 2^23 (idx itself, a u64, keeps counting); rows live in a ring of at most 64 steps.
+    R_MAX = 50
+    stripe0 = rank * (W + (R_MAX + 2) * K + 64) * T if shard_mode == "time" else 0
+    ring_steps = min(W + K, 64)
     WRAP = 1 << 23
 
     def ramp_row(k):
@@ -177,37 +231,30 @@ def run():
         return (np.arange(f0, f0 + T, dtype=np.int64) % WRAP).astype(np.float32)
 
     d_time = torch.from_numpy(np.concatenate([ramp_row(k) for k in range(ring_steps)])).cuda()
-    if n_calls > ring_steps:   # later steps reuse ring rows: keep their values consistent with ramp_row(k) only modulo the ring
-        log(f"[rank {rank}] {n_calls} calls share a ring of {ring_steps} resident input rows")
-    d_out = torch.empty((max(V_local, 1), T), dtype=torch.float32, device="cuda")
+    d_out = torch.empty((max(V, 1), T), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     n_streams = max(1, args.streams)
     side_streams = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else []
     side_outs = [torch.empty_like(d_out) for _ in range(n_streams)] if n_streams > 1 else []
-    d_mixes = [torch.empty_like(d_out) for _ in range(world)] if shard_mode == "partials" else None
 
     def step(k):
-        r = k % ring_steps
-        row = d_time[r * T:(r + 1) * T]
-        if side_streams and shard_mode != "partials":
-            hip.fill_buffer_device(side_outs[k % n_streams].data_ptr(), V_local, T, stripe0 + k * T, row.data_ptr(), [0, T],
+        row = d_time[(k % ring_steps) * T:][:T]
+        if side_streams:
+            hip.fill_buffer_device(side_outs[k % n_streams].data_ptr(), V, T, stripe0 + k * T, row.data_ptr(), [0, T],
                                    side_streams[k % n_streams].cuda_stream)
-            return side_outs[k % n_streams]
-        hip.fill_buffer_device(d_out.data_ptr(), V_local, T, stripe0 + k * T, row.data_ptr(), [0, T], stream)
-        if shard_mode == "partials":
-            # the one exchange step of the path: every rank's partial mix to every rank (RCCL over xGMI), then the
-            # top log2(N) levels of the voices' Sum2 trees, pairwise in the graph's own order (bit-exact)
-            if args.backend == "nccl":
-                dist.all_gather(d_mixes, d_out)
-                return shard.combine_partial_mixes(d_mixes)
-            host = [torch.empty(d_out.shape, dtype=torch.float32) for _ in range(world)]   # gloo rehearsal: via host
-            dist.all_gather(host, d_out.cpu())
-            return shard.combine_partial_mixes(host)
-        return d_out
+            return
+        hip.fill_buffer_device(d_out.data_ptr(), V, T, stripe0 + k * T, row.data_ptr(), [0, T], stream)
 
     def barrier():
         if use_dist:
             dist.barrier()
+
+    def max_over_ranks(x):
+        if not use_dist:
+            return x
+        te = torch.tensor([x], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        return float(te.item())
 
     t0 = time.perf_counter()
     for k in range(W):           # first call also lowers the graph and uploads the bank parameters
@@ -215,82 +262,106 @@ def run():
     torch.cuda.synchronize()
     log(f"[rank {rank}] warmup ({W} steps incl. lowering): {time.perf_counter() - t0:.2f}s; plan: {hip.plan()}")
 
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(W, W + K):
-        step(k)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    def timed_loop(k0):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(k0, k0 + K):
+            step(k)
+        torch.cuda.synchronize()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
 
-    last = (side_outs[(W + K - 1) % n_streams] if side_streams and shard_mode != "partials" else d_out).cpu().numpy()
+    times = [timed_loop(W)]
+    R = args.repeats or int(min(R_MAX, max(3, np.ceil(0.6 / max(times[0], 1e-6)))))
+    if use_dist:   # every rank must run the same number of loops
+        rt = torch.tensor([R], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.broadcast(rt, 0)
+        R = int(rt.item())
+    clocks = []
+    for r_i in range(1, R):
+        times.append(timed_loop(W + r_i * K))
+        c = shader_clock_mhz()
+        if c:
+            clocks.append(c)
+    elapsed = statistics.median(times)
+    next_k = W + R * K
+    last = (side_outs[(next_k - 1) % n_streams] if side_streams else d_out).cpu().numpy()
 
-    # kernel-level timing for the roofline: same steps again with HIP events around every launch, recorded
-    # on the stream the kernels run on (engine-side, fr_set_timing); a seek back to the stripe start.
+    # kernel-level timing for the roofline: K more steps with HIP events around every launch, recorded on the
+    # stream the kernels run on (engine-side, fr_set_timing)
     hip.set_timing(True)
     hip.reset_timing()
-    for k in range(W, W + K):   # the first of these is a seek back to the stripe's first timed frame
+    for k in range(next_k, next_k + K):
         step(k)
     torch.cuda.synchronize()
     bank_ms, bank_launches = hip.get_timing("bank")
     all_ms, all_launches = hip.get_timing("all")
     plan = hip.plan()
     hip.set_timing(False)
+    next_k += K
+    barrier()
 
-    # the drop-in entry point (host buffers in, host buffer out: H2D of the ramp, D2H of [V,T] f32, sync per call);
-    # reported as an extra, never as `value`
-    host_rate = None
-    if rank == 0:
-        hip.fill_buffer(V_local, stripe0, stripe0 + T, [ramp_row(0)])
+    extras = not args.no_extras and rank == 0 and world == 1 and elapsed / K < 5e-3
+    # The drop-in entry point, Renderer::fill_buffer as dispatch.rs:150 calls it: host rows in, host buffer out,
+    # synchronous.  >= 100 warm calls.
+    host_api = None
+    if extras:
+        n_host = 120
+        rows = [ramp_row(next_k + i) for i in range(n_host + 10)]
+        hout = np.zeros((V, T), dtype=np.float32)
+        for i in range(10):
+            hip.fill_buffer(V, stripe0 + (next_k + i) * T, stripe0 + (next_k + i + 1) * T, [rows[i]], out=hout)
         th = time.perf_counter()
-        for k in range(1, 6):
-            hip.fill_buffer(V_local, stripe0 + k * T, stripe0 + (k + 1) * T, [ramp_row(k)])
-        host_rate = 5 * T / (time.perf_counter() - th) / 1e6
+        for i in range(10, 10 + n_host):
+            hip.fill_buffer(V, stripe0 + (next_k + i) * T, stripe0 + (next_k + i + 1) * T, [rows[i]], out=hout)
+        dt = time.perf_counter() - th
+        host_api = {"value": n_host * T / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt / n_host * 1e3, "calls": n_host,
+                    "what": "fr_fill_buffer: pageable host rows in, pageable host [V,T] buffer out, synchronous (the reference's "
+                            "Renderer::fill_buffer contract, dispatch.rs:150-151); PCIe- and sync-inclusive"}
+        next_k += n_host + 10
 
-    # independent calls overlapped on two streams (an extra, never `value`): for a plan without delay state the engine
-    # lets consecutive calls issued on different streams run concurrently, which fills the tail of each launch
+    # independent calls overlapped on two streams (an extra, never `value`)
     overlapped = None
-    if args.short_blocks and rank == 0 and world == 1 and n_streams == 1 and not plan.get("rings") and not plan.get("stage_programs") and not plan.get("pull_rows"):
+    if extras and n_streams == 1 and not plan.get("rings") and not plan.get("stage_programs") and not plan.get("pull_rows"):
         s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
         o2 = [torch.empty_like(d_out), torch.empty_like(d_out)]
-        base_k = 2 * (W + K) + 4
 
         def step2(k):
             row = d_time[(k % ring_steps) * T:][:T]
-            hip.fill_buffer_device(o2[k % 2].data_ptr(), V_local, T, stripe0 + k * T, row.data_ptr(), [0, T], s2[k % 2].cuda_stream)
+            hip.fill_buffer_device(o2[k % 2].data_ptr(), V, T, stripe0 + k * T, row.data_ptr(), [0, T], s2[k % 2].cuda_stream)
 
-        for k in range(base_k, base_k + W):      # the first of these is a seek forward
+        for k in range(next_k, next_k + W):
             step2(k)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        for k in range(base_k + W, base_k + W + K):
+        for k in range(next_k + W, next_k + W + K):
             step2(k)
         torch.cuda.synchronize()
         e2 = time.perf_counter() - t2
+        next_k += W + K
         overlapped = {"streams": 2, "value": K * T / e2 / 1e6, "unit": "Msamples/s", "ms_per_step": e2 / K * 1e3,
                       "note": "same K steps issued round-robin on 2 HIP streams with separate output buffers; kernels of consecutive "
                               "calls overlap, so per-launch durations are not comparable with the sequential run above"}
 
-    # short blocks ("also report T in {64, 512}"): latency of one call through the device entry point
+    # short blocks ("also report T in {64, 512}"): one call through the device entry point, back to back
     short_blocks = None
-    if args.short_blocks and rank == 0 and world == 1 and elapsed / K < 5e-3:   # (not when a call takes milliseconds: pull-mode diagnostics)
+    if extras:
         short_blocks = {}
+        pf_rate = VALU_LANE_RATE / OPS_EXECUTED_PER_PF
         for tb in (64, 512):
-            base = stripe0 + (n_calls + 8) * T
-            for k in range(220):
+            base = stripe0 + (next_k + 8) * T
+            for k in range(520):
                 if k == 20:
                     torch.cuda.synchronize()
                     tb0 = time.perf_counter()
                 row = d_time[(k * tb) % (T - tb + 1):][:tb]   # any resident f32 row of the right length will do for timing
-                hip.fill_buffer_device(d_out.data_ptr(), V_local, tb, base + k * tb, row.data_ptr(), [0, tb], stream)
+                hip.fill_buffer_device(d_out.data_ptr(), V, tb, base + k * tb, row.data_ptr(), [0, tb], stream)
             torch.cuda.synchronize()
-            us = (time.perf_counter() - tb0) / 200 * 1e6
-            short_blocks[str(tb)] = {"us_per_call": us, "msamples_per_s": tb / us}
+            us = (time.perf_counter() - tb0) / 500 * 1e6
+            short_blocks[str(tb)] = {"us_per_call": us, "msamples_per_s": tb / us,
+                                     "valu_frac": (float(V) * P * tb / pf_rate) / (us * 1e-6)}
+            next_k += 8 + (520 * tb) // T + 1
 
     if rank != 0:
         if use_dist:
@@ -299,12 +370,20 @@ def run():
 
     frames_total = (world if shard_mode == "time" else 1) * K * T
     value = frames_total / elapsed / 1e6
-    k_lo, k_hi = shard_info["partials"]
-    pf_per_launch = float(V_local) * (k_hi - k_lo) * T
+    # what THIS rank's dominant launch covers
+    if shard_mode == "voices":
+        pf_per_launch = float(row_hi - row_lo) * P * T
+        v_launch, p_launch = row_hi - row_lo, P
+    elif shard_mode == "partials":
+        pf_per_launch = float(V) * (P // world) * T
+        v_launch, p_launch = V, P // world
+    else:
+        pf_per_launch = float(V) * P * T
+        v_launch, p_launch = V, P
     dom_ms, dom_n, dom_name = (bank_ms, bank_launches, "bank_kernel") if bank_launches else (all_ms, all_launches, "pull_kernel")
     avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
     # algorithmic HBM bytes per launch, closed-form model of SURVEY.md 8d: parameters read once + ramp in + samples out
-    bytes_per_launch = V_local * (k_hi - k_lo) * 8 + 4 * T + 4 * V_local * T
+    bytes_per_launch = v_launch * p_launch * 8 + 4 * T + 4 * v_launch * T
     valu_rate = OPS_EXECUTED_PER_PF * pf_per_launch / avg_s if avg_s > 0 else 0.0
     roofline = {
         "bound": "valu",
@@ -330,56 +409,76 @@ def run():
                 "note": "block rendering keeps partial state in registers/SGPRs for 4800 frames: HBM is not the bound"},
     }
 
+    workloads = {"additive": f"additive tree, {P} partials x {V} voices, 48 kHz, {T}-frame fill_buffer calls (BASELINE.json configs[2]"
+                             f"{'' if (V, P) == (64, 4096) else ' shape, other size'}); harmonics and /sr as graph nodes",
+                 "effects": f"harmonics + detune + ADSR + 4-tap delay chain, {P} partials x {V} voices (BASELINE.json configs[3] shape)",
+                 "chorus": f"chorus (Delay with an LFO amount) + 4-tap delay chain, {P} partials x {V} voices (diagnostic)"}
+    shardings = {"none": "single GPU",
+                 "time": "time stripes: independent replicas on different frames, no collective",
+                 "voices": "voices: fr_set_shard(FR_SHARD_VOICES), rank r renders its block of output rows, no collective",
+                 "partials": "partials: fr_set_shard(FR_SHARD_PARTIALS), rank r renders block r of every voice's partials; recursive-halving "
+                             "exchange (log2 N pairwise RCCL send/recv + the tree's own f32 add per level), bit-exact"}
     result = {
         "metric": "Msamples/sec at 4096 partials x 64 voices; achieved HBM GB/s vs roofline",
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
         "scaling": "weak" if shard_mode == "time" else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": (f"additive tree, {P} partials x {V} voices, 48 kHz, {T}-frame fill_buffer calls "
-                                f"(BASELINE.json configs[2])" if args.tree == "additive" else
-                                f"harmonics + detune + ADSR + 4-tap delay chain, {P} partials x {V} voices (BASELINE.json configs[3] shape)"
-                                if args.tree == "effects" else
-                                f"chorus (Delay with an LFO amount) + 4-tap delay chain, {P} partials x {V} voices (diagnostic)"),
-                   "voices": V, "partials": P, "frames_per_call": T,
-                   "sharding": {"time": "time stripes, one per GPU, no collective",
-                                "voices": "voices split over GPUs, no collective",
-                                "partials": "partial blocks of every voice split over GPUs; RCCL all-gather of [V,T] partial "
-                                            "mixes + tree-order f32 sum"}[shard_mode] if world > 1 else "single GPU",
-                   "engine_mode": args.mode, "plan": plan},
+        "config": {"workload": workloads[args.tree], "voices": V, "partials": P, "frames_per_call": T,
+                   "sharding": shardings[shard_mode], "transport": transport, "engine_mode": args.mode, "plan": plan},
+        "repeats": {"n": R, "statistic": "median of R timed loops of K steps each", "ms_per_step_min": min(times) / K * 1e3,
+                    "ms_per_step_max": max(times) / K * 1e3, "ms_per_step_all": [t / K * 1e3 for t in times],
+                    "timed_seconds_total": sum(times),
+                    "shader_clock_mhz": {"samples": len(clocks), "median": statistics.median(clocks) if clocks else None,
+                                         "min": min(clocks) if clocks else None, "source": "sysfs pp_dpm_sclk after each loop"}},
         "partial_frames_per_s": K * T * float(V) * P * (world if shard_mode == "time" else 1) / elapsed,
         "roofline": roofline,
-        "host_buffer_api_msamples_per_s": host_rate,
+        "host_api": host_api,
         "short_blocks": short_blocks,
         "overlapped_calls": overlapped,
     }
-    # HBM traffic per launch from PMC counters: rocprofv3 cannot wrap a process from inside it, so the figure is
-    # read from the committed summary of the separate --pmc passes of this same command (profiles/).
-    pmc_path = os.path.join(ROOT, "profiles", "r01_bank_pmc_summary.json")
-    if (V, P, T) == (64, 4096, 4800) and os.path.exists(pmc_path):
-        try:
-            with open(pmc_path) as f:
-                pmc = json.load(f)
-            roofline["traffic"] = pmc["derived"]["hbm_traffic_bytes"]
-            roofline["traffic_source"] = "profiles/r01_bank_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        except Exception:
-            pass
+    # HBM traffic per launch from PMC counters: rocprofv3 cannot wrap a process from inside it, so the figure is read from
+    # the committed summary of the separate --pmc passes of this same command (tools/collect_profiles.sh), which records
+    # the commit it was taken at.
+    if (V, P, T) == (64, 4096, 4800) and world == 1:
+        for path in (PMC_SUMMARY, PMC_SUMMARY.replace("r02", "r01")):
+            if not os.path.exists(path):
+                continue
+            try:
+                with open(path) as f:
+                    pmc = json.load(f)
+                roofline["traffic"] = pmc["derived"]["hbm_traffic_bytes"]
+                roofline["traffic_source"] = (f"{os.path.relpath(path, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                                              f"taken at commit {pmc.get('commit', 'of round 1')})")
+                break
+            except Exception:
+                pass
 
     if not args.no_cpu_baseline and world == 1:
         try:
-            one, many, cpu_out = cpu_baseline(full_tree, V, P, args.cpu_frames, 4 * args.cpu_frames)
+            one, many, cpu_out = cpu_baseline(tree, V, P, args.cpu_frames, 4 * args.cpu_frames)
             result["cpu_baseline"] = one
             result["cpu_baseline_all_cores"] = many
-            # parity of the bench's own output against the CPU path on the sampled frames (stripe 0 only)
+            # parity of the bench's own paths against the CPU path on the sampled frames: the host-buffer entry point
+            # (a fresh renderer, frames [0, cpu_frames)) and the device entry point
             chk = libfriendship_amd.HipRenderer(mode=args.mode, device=local_rank)
-            synth.install(chk, full_tree)
+            synth.install(chk, tree)
             got = chk.fill_buffer(V, 0, args.cpu_frames, [synth.time_ramp(0, args.cpu_frames)])
-            result["parity"] = {"frames_checked": args.cpu_frames, "voices": V,
-                                "bit_exact": bool(np.array_equal(got.view(np.uint32), cpu_out.view(np.uint32)))}
             chk.close()
+            chk = libfriendship_amd.HipRenderer(mode=args.mode, device=local_rank)
+            synth.install(chk, tree)
+            d_chk = torch.empty((V, args.cpu_frames), dtype=torch.float32, device="cuda")
+            d_row = torch.from_numpy(synth.time_ramp(0, args.cpu_frames)).cuda()
+            chk.fill_buffer_device(d_chk.data_ptr(), V, args.cpu_frames, 0, d_row.data_ptr(), [0, args.cpu_frames], stream)
+            torch.cuda.synchronize()
+            got_dev = d_chk.cpu().numpy()
+            chk.close()
+            result["parity"] = {"frames_checked": args.cpu_frames, "voices": V,
+                                "bit_exact": bool(np.array_equal(got.view(np.uint32), cpu_out.view(np.uint32))),
+                                "device_entry_bit_exact": bool(np.array_equal(got_dev.view(np.uint32), cpu_out.view(np.uint32)))}
         except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
             result["cpu_baseline"] = {"error": repr(e)}
-    result["checksum"] = float(np.abs(last.astype(np.float64)).sum())
+    result["checksum"] = float(np.abs(last[row_lo:row_hi].astype(np.float64)).sum())
     if use_dist:
         dist.destroy_process_group()
     return json.dumps(result)

@@ -12,8 +12,10 @@ Definitions (t = external input slot 0, the f32 frame ramp; C(x) = F32Constant e
              y = Multiply(Multiply(C(-16), u), Sum2(C(0.5), Multiply(C(-1), absu)))     parabolic sine
              leaf = Multiply(C(amp), y)                                                   11 nodes
   voice    : balanced binary Sum2 tree over the voice's leaves (adjacent pairs, level by level)
-  harmonics: w_k = (f0 * (k+1) [* (1+detune_k)]) / sr, either folded on the host in f32 (default) or
-             carried as constant Multiply/Divide nodes (`constants_in_graph=True`) for the engine to fold
+  harmonics: f = Multiply(C(f0), C(k+1))  [N3];  detune: f' = Multiply(f, C(1+delta))  [N4];  w = Divide(f', C(sr))
+             -- as graph NODES with `params_as_nodes=True` (the reference has only the seven primitives, so this is how
+             harmonics and detune reach a renderer; the engine folds them at lowering with the same exactly-rounded
+             f32 ops), or pre-folded in numpy (same roundings, fewer nodes; the default for small tests)
   envelope : ADSR from Minimum/Sum2/Multiply/Divide of t, Multiply(env, mix)
   delay    : K feed-forward taps y = Sum2(x, Multiply(C(g), Delay(x, C(d)))) in series (N6)
 """
@@ -103,12 +105,29 @@ def IN(slot):
     return ("in", slot)
 
 
-def partial_leaves(g, w, amp, time_slot=0):
-    """The 11-node partial oscillator for every (w, amp); returns leaf handles (same shape, flattened)."""
-    w = np.asarray(w, dtype=np.float32).ravel()
+def harmonic_nodes(g, p):
+    """N3 + N4 as primitive nodes: for every partial f = Multiply(C(f0_v), C(k+1)), [f = Multiply(f, C(1 + delta))],
+    w = Divide(f, C(sr)).  `p` = voice_params(...).  Returns the handles of the w nodes, flattened [V * P]."""
+    V, P = p["w"].shape
+    n = V * P
+    f0 = np.broadcast_to(p["f0"], (V, P)).ravel()
+    k1 = np.broadcast_to(p["k1"], (V, P)).ravel()
+    f = g.binop(K_MUL, C(f0), C(k1), n)
+    if p["delta"] is not None:
+        f = g.binop(K_MUL, f, C((np.float32(1.0) + p["delta"]).astype(np.float32).ravel()), n)
+    return g.binop(K_DIV, f, C(np.full(n, p["sr"], dtype=np.float32)), n)
+
+
+def partial_leaves(g, w, amp, time_slot=0, w_nodes=None):
+    """The 11-node partial oscillator for every (w, amp); returns leaf handles (same shape, flattened).  With
+    `w_nodes` (handles, e.g. from harmonic_nodes) the phase increment is a node's output instead of a constant."""
     amp = np.asarray(amp, dtype=np.float32).ravel()
-    n = len(w)
-    x = g.binop(K_MUL, IN(time_slot), C(w), n)
+    n = len(amp)
+    if w_nodes is not None:
+        x = g.binop(K_MUL, IN(time_slot), np.asarray(w_nodes, dtype=np.uint32).ravel(), n)
+    else:
+        w = np.asarray(w, dtype=np.float32).ravel()
+        x = g.binop(K_MUL, IN(time_slot), C(w), n)
     ph = g.binop(K_MOD, x, C(np.float32(1.0)), n)
     u = g.binop(K_SUM2, ph, C(np.float32(-0.5)), n)
     nu = g.binop(K_MUL, C(np.float32(-1.0)), u, n)
@@ -175,11 +194,18 @@ def voice_params(n_voices, n_partials, seed, detune=False, sr=48000.0, wrap=None
     return {"f0": f0, "k1": k1, "delta": delta, "w": w, "amp": amp.astype(np.float32), "sr": np.float32(sr)}
 
 
-def additive_tree(n_voices, n_partials, seed=0x5EED0002, detune=False, sr=48000.0, time_slot=0):
-    """configs B/C (and the oscillator part of D/E): V voices x P partials, one output slot per voice."""
+def additive_tree(n_voices, n_partials, seed=0x5EED0002, detune=False, sr=48000.0, time_slot=0, params_as_nodes=False, voices=None):
+    """configs B/C (and the oscillator part of D/E): V voices x P partials, one output slot per voice.
+    `voices`: keep only these voices of the V (output slot i = voice voices[i]) -- a sub-tree of the same job, for
+    checking a few voices of a tree too big for the CPU oracle."""
     p = voice_params(n_voices, n_partials, seed, detune, sr)
+    if voices is not None:
+        sel = np.asarray(voices, dtype=np.int64)
+        p = dict(p, f0=p["f0"][sel], w=p["w"][sel], amp=p["amp"][sel], delta=None if p["delta"] is None else p["delta"][sel])
+        n_voices = len(sel)
     g = GraphArrays()
-    leaves = partial_leaves(g, p["w"], p["amp"], time_slot).reshape(n_voices, n_partials)
+    wn = harmonic_nodes(g, p) if params_as_nodes else None
+    leaves = partial_leaves(g, p["w"], p["amp"], time_slot, wn).reshape(n_voices, n_partials)
     roots = sum_tree(g, leaves)
     g.edge(roots, 0, 0, np.arange(n_voices, dtype=np.uint32))
     t = g.finish(n_voices)
@@ -217,11 +243,12 @@ def delay_chain(g, x, taps=4, base_delay=2400.0):
 
 
 def effects_tree(n_voices, n_partials, seed=0x5EED0003, detune=True, envelope=True, taps=4, base_delay=2400.0,
-                 sr=48000.0, time_slot=0, wrap=None):
+                 sr=48000.0, time_slot=0, wrap=None, params_as_nodes=False):
     """config D: harmonics + per-partial detune + ADSR envelope + delay chain, one output slot per voice."""
     p = voice_params(n_voices, n_partials, seed, detune, sr, wrap)
     g = GraphArrays()
-    leaves = partial_leaves(g, p["w"], p["amp"], time_slot).reshape(n_voices, n_partials)
+    wn = harmonic_nodes(g, p) if params_as_nodes else None
+    leaves = partial_leaves(g, p["w"], p["amp"], time_slot, wn).reshape(n_voices, n_partials)
     x = sum_tree(g, leaves)
     if envelope:
         env = adsr_envelope(g, time_slot=time_slot)

@@ -1,8 +1,9 @@
-"""One rank of a sharded render (launched by tests/test_distributed.py, world size 2 or 4, gloo).
+"""One rank of a sharded render (launched by tests/test_distributed.py; gloo).
 
-Usage: dist_worker.py <rank> <world> <port> <mode> <lib: oracle|hip> <V> <P> <T> <outdir>
-Each rank renders its shard through the C ABI, the ranks exchange over torch.distributed, and every rank checks the
-assembled result bit-for-bit against an unsharded oracle render of the full tree."""
+Usage: dist_worker.py <rank> <world> <port> <shard mode> <lib: sim|hip> <case> <outdir>
+Every rank creates a renderer on `lib`, receives the SAME graph through the ordinary ABI, calls fr_set_shard with a
+host-callback transport that carries the exchange over torch.distributed (gloo), renders the same calls, and checks the
+rows it owns bit-for-bit against an unsharded oracle render of the full graph."""
 import os
 import sys
 
@@ -15,12 +16,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-    mode, libname = sys.argv[4], sys.argv[5]
-    V, P, T = int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])
-    outdir = sys.argv[9]
+    mode, libname, case, outdir = sys.argv[4], sys.argv[5], sys.argv[6], sys.argv[7]
     import torch
     import torch.distributed as dist
-    from libfriendship_amd import shard, synth
+    from libfriendship_amd import synth
     from libfriendship_amd.capi import Renderer, RendererLib
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -30,38 +29,84 @@ def main():
         import libfriendship_amd
         lib = libfriendship_amd.hip_lib()
     else:
-        lib = oracle
+        import sim_tools
+        lib = RendererLib(sim_tools.OUT)       # built once by the launching test
 
-    tree, info = shard.additive_tree_shard(V, P, rank, world, mode, seed=77, detune=True)
-    if mode == "time":
-        start, end = shard.time_stripe(rank, world, T, base=1000)
+    def sendrecv(peer, send, recv):
+        """The exchange step's transport: host buffers over gloo."""
+        reqs, rt = [], None
+        if send is not None:
+            reqs.append(dist.isend(torch.from_numpy(send.copy()), peer))
+        if recv is not None:
+            rt = torch.empty(recv.size, dtype=torch.uint8)
+            reqs.append(dist.irecv(rt, peer))
+        for q in reqs:
+            q.wait()
+        if recv is not None:
+            recv[:] = rt.numpy()
+
+    edits = []
+    if case == "additive":
+        V, T = 5, 48
+        tree = synth.additive_tree(V, 64 * world, seed=77, detune=True)
+        install = lambda r: synth.install(r, tree)
+        calls = [(1000, 1000 + T), (1000 + T, 1000 + 2 * T)]
+    elif case == "effects":      # config D's shape: voices -> envelope -> delay chain; contiguous calls, a seek, an edit
+        V, T = 4, 64
+        tree = synth.effects_tree(V, 64 * world, taps=3, base_delay=40.0)
+        install = lambda r: synth.install(r, tree)
+        calls = [(0, T), (T, 2 * T), (2 * T, 3 * T), (7000, 7000 + T), (7000 + T, 7000 + 2 * T), (7000 + 2 * T, 7000 + 3 * T)]
+        e = tree["edges"]
+        last = [int(x) for x in e[(e[:, 1] == 0) & (e[:, 3] == V - 1)][0]]
+        prev = [int(x) for x in e[(e[:, 1] == 0) & (e[:, 3] == V - 2)][0]]
+        edits = [(5, [("del", last), ("add", [prev[0], 0, 0, V - 1])])]      # before call 5
+    elif case == "random":       # arbitrary graphs (composites, signal delays, pull rows)
+        import randgraph
+        V, T = 5, 40
+        steps, _ = randgraph.random_graph(4242, n_nodes=30, n_inputs=2, n_outputs=V)
+        install = lambda r: randgraph.install_steps(r, steps)
+        calls = [(0, T), (T, 2 * T), (900, 900 + T)]
     else:
-        start, end = 1000, 1000 + T
-    with Renderer(lib) as r:
-        synth.install(r, tree)
-        local = r.fill_buffer(tree["n_outputs"], start, end, [synth.time_ramp(start, end)])
+        raise SystemExit(f"unknown case {case}")
 
-    # unsharded reference, on the CPU oracle
-    full_tree = synth.additive_tree(V, P, seed=77, detune=True)
-    n_frames = T * world if mode == "time" else T
-    with Renderer(oracle) as ref:
-        synth.install(ref, full_tree)
-        expect = ref.fill_buffer(V, 1000, 1000 + n_frames, [synth.time_ramp(1000, 1000 + n_frames)])
-
-    if mode == "partials":
-        mixes = shard.all_gather_mixes(torch.from_numpy(local), world)
-        got = shard.combine_partial_mixes(mixes).numpy()
-    elif mode == "voices":
-        parts = [None] * world
-        dist.all_gather_object(parts, local)
-        got = np.concatenate(parts, axis=0)
-    else:
-        parts = [torch.empty((V, T), dtype=torch.float32) for _ in range(world)]
-        dist.all_gather(parts, torch.from_numpy(local))
-        got = np.concatenate([p.numpy() for p in parts], axis=1)
-    ok = got.shape == expect.shape and np.array_equal(got.view(np.uint32), expect.view(np.uint32))
+    rng = np.random.default_rng(9)
+    ok, why = True, ""
+    with Renderer(lib) as r, Renderer(oracle) as ref:
+        install(r)
+        install(ref)
+        r.set_shard(rank, world, mode, sendrecv=sendrecv)
+        lo, hi = r.shard_rows(V)
+        for ci, (start, end) in enumerate(calls):
+            for when, ops in edits:
+                if when == ci:
+                    for kind, ed in ops:
+                        for x in (r, ref):
+                            (x.on_del_edge if kind == "del" else x.on_add_edge)(*ed)
+            rows = [synth.time_ramp(start, end), (rng.normal(size=end - start) * 3).astype(np.float32)]
+            exp = ref.fill_buffer(V, start, end, rows)
+            out = np.full((V, end - start), np.float32(-777.0))
+            got = r.fill_buffer(V, start, end, rows, out=out)
+            mine = got[lo:hi].view(np.uint32) == exp[lo:hi].view(np.uint32)
+            mine |= np.isnan(got[lo:hi]) & np.isnan(exp[lo:hi])
+            others = np.ones(V, bool)
+            others[lo:hi] = False
+            if not mine.all():
+                ok, why = False, f"call {ci} [{start},{end}): rows {lo}..{hi} differ from the unsharded oracle"
+            elif not np.all(got[others] == np.float32(-777.0)):
+                ok, why = False, f"call {ci}: wrote rows it does not own"
+            if not ok:
+                break
+        plan = r.plan()
+    def owner(row):   # contiguous blocks, sizes differing by at most one (fr_shard_rows)
+        q, rem = divmod(V, world)
+        return row // (q + 1) if row < rem * (q + 1) else rem + (row - rem * (q + 1)) // max(q, 1)
+    # the edit leaves the last voice unreachable and makes voice V-2 feed rows V-2 and V-1: needed by two ranks (and then
+    # rendered whole by both) when those rows have different owners
+    want = V if not edits else (V - 1 if owner(V - 2) == owner(V - 1) else V - 2)
+    if ok and mode == "partials" and case != "random" and plan["shard"]["split_voices"] != want:
+        ok, why = False, f"expected {want} split voices: {plan['shard']}"
     with open(os.path.join(outdir, f"rank{rank}.txt"), "w") as f:
-        f.write("ok" if ok else f"MISMATCH shape {got.shape} vs {expect.shape}")
+        f.write("ok" if ok else why)
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)

@@ -326,6 +326,111 @@ def test_config_c_full_size_sampled_against_oracle(hip_lib, oracle_lib):
             assert same_bits(got[:, c:c + 1], exp), f"frame {c}: " + first_diff(got[:, c:c + 1], exp)
 
 
+def test_config_e_full_size_sampled_against_oracle(hip_lib, oracle_lib):
+    """BASELINE configs[4] in its named size, 16384 partials x 256 voices (4.2 M partials, a 50 M-node primitive graph),
+    on one GPU: sampled frames of sampled voices against the oracle.  Voices are independent (reference.rs:78-82), so
+    the oracle gets the sub-tree of just those voices.  With the survey's f0 = 55 * 2^(v/12) every voice above v ~ 150
+    is identically zero (every t*w >= 2^23): those take the kernel's zero-sign path for every frame, so some of them are
+    sampled too, signs of zero included."""
+    V, P, T = 256, 16384, 4800
+    picks = [0, 37, 101, 149, 150, 151, 160, 200, 255]
+    tree = synth.additive_tree(V, P)
+    sub = synth.additive_tree(V, P, voices=picks)
+    t = synth.time_ramp(0, T)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        del tree
+        synth.install(ref, sub)
+        got = hip.fill_buffer(V, 0, T, [t])
+        plan = hip.plan()
+        assert plan["pull_rows"] == 0 and [(b["voices"], b["partials"]) for b in plan["banks"]] == [(V, P)], plan
+        rng = np.random.default_rng(0)
+        cols = np.unique(np.concatenate([[0, 1, 63, 64, T - 1], rng.integers(0, T, 3)]))
+        for c in cols:   # one oracle call per sampled frame (a seek each; this graph has no Delay)
+            exp = ref.fill_buffer(len(picks), int(c), int(c) + 1, [t[c:c + 1]])
+            assert same_bits(got[picks, c:c + 1], exp), f"frame {c}: " + first_diff(got[picks, c:c + 1], exp)
+        silent = got[200:]
+        assert not silent.any() and np.abs(got[:100]).max() > 0.1
+
+
+@pytest.mark.parametrize("V,P,detune", [(4, 1024, True), (64, 256, False)])
+def test_harmonics_and_detune_as_graph_nodes(hip_lib, oracle_lib, V, P, detune):
+    """N3 / N4: harmonics f0*(k+1), detune *(1+delta) and /sr arrive as Multiply / Divide nodes over
+    constants -- the reference has only the seven primitives.  The engine folds them at lowering with exactly-rounded
+    f32 ops, still recognises every voice as a bank, and equals the oracle evaluating the same node graph."""
+    T = 96
+    tree = synth.additive_tree(V, P, seed=21, detune=detune, params_as_nodes=True)
+    t = synth.time_ramp(4800, 4800 + T)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        got = hip.fill_buffer(V, 4800, 4800 + T, [t])
+        plan = hip.plan()
+        assert plan["pull_rows"] == 0 and plan["stage_programs"] == 0, plan
+        assert [(b["voices"], b["partials"]) for b in plan["banks"]] == [(V, P)], plan
+        if V * P * T <= 1 << 19:
+            exp = ref.fill_buffer(V, 4800, 4800 + T, [t])
+            assert same_bits(got, exp), first_diff(got, exp)
+        else:
+            for c in (0, 17, T - 1):
+                exp = ref.fill_buffer(V, 4800 + c, 4800 + c + 1, [t[c:c + 1]])
+                assert same_bits(got[:, c:c + 1], exp), f"frame {c}: " + first_diff(got[:, c:c + 1], exp)
+
+
+def test_config_d_nodes_form_keeps_its_plan(hip_lib):
+    """Config D with harmonics + detune as nodes plans exactly like the numpy-folded form and renders the same bits."""
+    V, P, T = 16, 256, 600
+    a_tree = synth.effects_tree(V, P, params_as_nodes=True, base_delay=100.0)
+    b_tree = synth.effects_tree(V, P, base_delay=100.0)
+    t = synth.time_ramp(0, T)
+    with Renderer(hip_lib) as a, Renderer(hip_lib) as b:
+        synth.install(a, a_tree)
+        synth.install(b, b_tree)
+        assert same_bits(a.fill_buffer(V, 0, T, [t]), b.fill_buffer(V, 0, T, [t]))
+        pa, pb = a.plan(), b.plan()
+        for key in ("banks", "stage_programs", "rings", "max_lookback", "pull_rows", "fused_programs"):
+            assert pa[key] == pb[key], (key, pa[key], pb[key])
+
+
+def test_shared_root_on_two_rows_is_one_launch_per_call(hip_lib, oracle_lib):
+    """a non-bank root on two output rows with no delayed read: the fused steady-state form must be ONE
+    launch per contiguous call whatever idx is (the sub-window count used to wrap: idx + 1 launches)."""
+    with Renderer(hip_lib) as r, Renderer(oracle_lib) as ref:
+        for x in (r, ref):
+            x.on_add_node(1, "F32Constant")
+            x.on_add_node(2, "Multiply")
+            x.on_add_node(3, "Sum2")
+            x.on_add_edge(0, 2, 0, 0)
+            x.on_add_edge(1, 2, f32_bits(0.5), 1)
+            x.on_add_edge(2, 3, 0, 0)
+            x.on_add_edge(0, 3, 1, 1)
+            x.on_add_edge(3, 0, 0, 0)
+            x.on_add_edge(3, 0, 0, 1)
+        T = 4800
+        rng = np.random.default_rng(0)
+        r.set_timing(True)
+        for k in range(4):
+            rows = [synth.time_ramp(k * T, (k + 1) * T), rng.normal(size=T).astype(np.float32)]
+            r.reset_timing()
+            got = r.fill_buffer(2, k * T, (k + 1) * T, rows)
+            _, n = r.get_timing("stage")
+            assert same_bits(got, ref.fill_buffer(2, k * T, (k + 1) * T, rows))
+            if k > 0:
+                assert n == 1, f"call {k} at idx {k * T}: {n} stage launches"
+
+
+def test_failed_call_leaves_the_input_store_intact(hip_lib, oracle_lib):
+    """ADVICE r1 (medium), on the device: see tests/test_sim_engine.py for the host-logic form."""
+    import test_sim_engine
+    test_sim_engine.test_failed_call_leaves_the_input_store_intact(hip_lib, oracle_lib)
+
+
+def test_rccl_is_loadable_and_hands_out_an_id(hip_lib):
+    """fr_comm_unique_id = ncclGetUniqueId through the engine's lazily loaded RCCL (one rank cannot exercise more)."""
+    a, b = hip_lib.comm_unique_id(), hip_lib.comm_unique_id()
+    assert len(a) == 128 and a != b and any(a)
+
+
 # ---- boundary behaviour on the HIP engine ---------------------------------------------------------------
 def test_hip_error_codes(hip_lib):
     with Renderer(hip_lib) as r:

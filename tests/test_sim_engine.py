@@ -70,3 +70,103 @@ def test_bank_general_partial_counts(sim, oracle_lib, V, P, T):
 
 def test_chorus_signal_delay_is_staged(sim, oracle_lib):
     G.test_chorus_signal_delay_is_staged(sim, oracle_lib, 3, 32, 100, 2)
+
+
+def _launches(sim, cls):
+    import ctypes
+    sim.lib.fr_sim_launch_count.restype = ctypes.c_uint64
+    return sim.lib.fr_sim_launch_count(cls)
+
+
+def test_shared_root_on_two_rows_is_one_launch_per_call(sim, oracle_lib):
+    """A non-bank root wired to two output rows (a master gain sent to L and R), no delayed read anywhere: the fused
+    steady-state form has no frame limit.  The sub-window count used to wrap and the engine issued idx + 1 launches per
+    contiguous call."""
+    STAGE = 2
+    with Renderer(sim) as r, Renderer(oracle_lib) as ref:
+        for x in (r, ref):
+            x.on_add_node(1, "F32Constant")
+            x.on_add_node(2, "Multiply")
+            x.on_add_node(3, "Sum2")
+            x.on_add_edge(0, 2, 0, 0)
+            x.on_add_edge(1, 2, f32_bits(0.5), 1)
+            x.on_add_edge(2, 3, 0, 0)
+            x.on_add_edge(0, 3, 1, 1)
+            x.on_add_edge(3, 0, 0, 0)
+            x.on_add_edge(3, 0, 0, 1)
+        T = 4800
+        rng = np.random.default_rng(0)
+        for k in range(4):
+            rows = [synth.time_ramp(k * T, (k + 1) * T), rng.normal(size=T).astype(np.float32)]
+            before = _launches(sim, STAGE)
+            got = r.fill_buffer(2, k * T, (k + 1) * T, rows)
+            n = _launches(sim, STAGE) - before
+            assert same_bits(got, ref.fill_buffer(2, k * T, (k + 1) * T, rows))
+            plan = r.plan()
+            assert plan["fused_programs"] > 0 and plan["fused_max_frames"] >= T, plan
+            if k > 0:
+                assert n == 1, f"call {k} at idx {k * T}: {n} stage launches"
+
+
+def test_failed_call_leaves_the_input_store_intact(sim, oracle_lib):
+    """A call that fails AFTER validation of its rows (here: the graph has a cycle, found when the plan is built) must not
+    commit the rows: once the graph is fixed, the retry at the same idx succeeds and sees the history of the calls
+    before it."""
+    with Renderer(sim) as r, Renderer(oracle_lib) as ref:
+        for x in (r, ref):
+            x.on_add_node(1, "F32Constant")
+            x.on_add_node(2, "Delay")      # out = in0 delayed by 3
+            x.on_add_node(3, "Sum2")
+            x.on_add_edge(0, 2, 0, 0)
+            x.on_add_edge(1, 2, f32_bits(3.0), 1)
+            x.on_add_edge(2, 3, 0, 0)
+            x.on_add_edge(0, 3, 0, 1)
+            x.on_add_edge(3, 0, 0, 0)
+        a = np.arange(8, dtype=np.float32) + 1
+        assert same_bits(r.fill_buffer(1, 0, 8, [a]), ref.fill_buffer(1, 0, 8, [a]))
+        # break the graph: 3 -> 4 -> 3
+        r.on_add_node(4, "Multiply")
+        r.on_add_edge(3, 4, 0, 0)
+        r.on_add_edge(4, 3, 0, 1)
+        b = np.arange(8, dtype=np.float32) + 100
+        with pytest.raises(RenderError) as ei:
+            r.fill_buffer(1, 8, 16, [b])
+        assert ei.value.status == FR_ERR_CYCLE
+        with pytest.raises(RenderError):           # still broken: same answer, still nothing committed
+            r.fill_buffer(1, 8, 16, [b])
+        r.on_add_edge(0, 3, 0, 1)                  # repair
+        got = r.fill_buffer(1, 8, 16, [b])         # the retry at the same idx: no FR_ERR_INPUT_HISTORY
+        assert same_bits(got, ref.fill_buffer(1, 8, 16, [b]))
+        # a refused row (too long) leaves the store intact as well
+        with pytest.raises(RenderError):
+            r.fill_buffer(1, 16, 20, [np.zeros(9, np.float32)])
+        c = np.arange(4, dtype=np.float32)
+        assert same_bits(r.fill_buffer(1, 16, 20, [c]), ref.fill_buffer(1, 16, 20, [c]))
+        # a row that does not continue its slot's history is refused before anything changes: slot 1 was created by the
+        # first call (at idx 0) and never fed, so it still holds 0 samples (reference.rs:60-69)
+        # (the reference panics half-way through its rows there; only the engine promises an untouched store)
+        with pytest.raises(RenderError) as ei:
+            r.fill_buffer(1, 20, 24, [c, c])
+        assert ei.value.status == FR_ERR_INPUT_HISTORY
+        assert same_bits(r.fill_buffer(1, 20, 24, [c]), ref.fill_buffer(1, 20, 24, [c]))
+
+
+@pytest.mark.parametrize("detune", [False, True])
+def test_harmonics_and_detune_as_graph_nodes(sim, oracle_lib, detune):
+    """N3 / N4: harmonics f0*(k+1), detune *(1+delta) and /sr reach the renderer as Multiply / Divide nodes
+    over constants.  Lowering folds them with exactly-rounded f32 ops, the voices are still recognised as banks, and the
+    result equals both the oracle on the same node graph and the numpy-folded form of the tree."""
+    V, P, T = 3, 64, 80
+    nodes = synth.additive_tree(V, P, seed=5, detune=detune, params_as_nodes=True)
+    folded = synth.additive_tree(V, P, seed=5, detune=detune)
+    assert len(nodes["handles"]) == len(folded["handles"]) + V * P * (3 if detune else 2)
+    t = synth.time_ramp(100, 100 + T)
+    with Renderer(sim) as a, Renderer(sim) as b, Renderer(oracle_lib) as ref:
+        synth.install(a, nodes)
+        synth.install(b, folded)
+        synth.install(ref, nodes)
+        got = a.fill_buffer(V, 100, 100 + T, [t])
+        plan = a.plan()
+        assert plan["pull_rows"] == 0 and [(x["voices"], x["partials"]) for x in plan["banks"]] == [(V, P)], plan
+        assert same_bits(got, ref.fill_buffer(V, 100, 100 + T, [t]))
+        assert same_bits(got, b.fill_buffer(V, 100, 100 + T, [t]))
