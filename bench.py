@@ -320,6 +320,19 @@ def run():
                     "what": "fr_fill_buffer: pageable host rows in, pageable host [V,T] buffer out, synchronous (the reference's "
                             "Renderer::fill_buffer contract, dispatch.rs:150-151); PCIe- and sync-inclusive"}
         next_k += n_host + 10
+        # the same calls for a host that reuses its sample buffer and has page-locked it (fr_host_register, optional)
+        hip.host_register(hout)
+        rows = [ramp_row(next_k + i) for i in range(n_host + 10)]
+        for i in range(10):
+            hip.fill_buffer(V, stripe0 + (next_k + i) * T, stripe0 + (next_k + i + 1) * T, [rows[i]], out=hout)
+        th = time.perf_counter()
+        for i in range(10, 10 + n_host):
+            hip.fill_buffer(V, stripe0 + (next_k + i) * T, stripe0 + (next_k + i + 1) * T, [rows[i]], out=hout)
+        dt = time.perf_counter() - th
+        hip.host_unregister(hout)
+        host_api["registered_buffer"] = {"value": n_host * T / dt / 1e6, "ms_per_step": dt / n_host * 1e3,
+                                         "what": "same, output buffer page-locked once with fr_host_register (a host that reuses it)"}
+        next_k += n_host + 10
 
     # independent calls overlapped on two streams (an extra, never `value`)
     overlapped = None

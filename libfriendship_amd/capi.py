@@ -185,6 +185,10 @@ class RendererLib:
         L.fr_set_shard.restype = C.c_int32
         L.fr_shard_rows.argtypes = [vp, C.c_uint32, P(C.c_uint32), P(C.c_uint32)]
         L.fr_shard_rows.restype = C.c_int32
+        L.fr_host_register.argtypes = [vp, vp, C.c_size_t]
+        L.fr_host_register.restype = C.c_int32
+        L.fr_host_unregister.argtypes = [vp, vp]
+        L.fr_host_unregister.restype = C.c_int32
         L.fr_comm_unique_id.argtypes = [P(C.c_uint8)]
         L.fr_comm_unique_id.restype = C.c_int32
         if L.fr_abi_version() != FR_ABI_VERSION:
@@ -219,6 +223,7 @@ class Renderer:
         if st != FR_OK:
             raise RenderError(st, rlib.status_string(st), "fr_renderer_create")
         self.h = h
+        self._offs1 = np.zeros(2, dtype=np.uint64)
         self._keep = []  # effects passed in stay alive as long as the renderer (not required by the ABI)
 
     def close(self):
@@ -241,6 +246,13 @@ class Renderer:
     def _check(self, st):
         if st != FR_OK:
             raise RenderError(st, self.rlib.status_string(st), self.L.fr_last_error(self.h).decode())
+
+    def host_register(self, array):
+        """Page-lock a numpy buffer the caller reuses as `out=` / input rows (fr_host_register)."""
+        self._check(self.L.fr_host_register(self.h, array.ctypes.data, array.nbytes))
+
+    def host_unregister(self, array):
+        self._check(self.L.fr_host_unregister(self.h, array.ctypes.data))
 
     # --- sharding (fr_set_shard) ---
     def set_shard(self, rank, world, mode="voices", gather=False, rccl_id=None, sendrecv=None):
@@ -324,15 +336,24 @@ class Renderer:
         if out is None:
             out = np.zeros((n_slots, n_times), dtype=np.float32)  # Dispatch allocates zeros (dispatch.rs:149)
         assert out.dtype == np.float32 and out.shape == (n_slots, n_times) and out.flags.c_contiguous
-        rows = [np.ascontiguousarray(r, dtype=np.float32).ravel() for r in inputs]
-        offs = np.zeros(len(rows) + 1, dtype=np.uint64)
-        if rows:
-            offs[1:] = np.cumsum([len(r) for r in rows])
-            data = np.concatenate(rows) if offs[-1] else np.zeros(1, np.float32)
+        if (len(inputs) == 1 and isinstance(inputs[0], np.ndarray) and inputs[0].dtype == np.float32 and inputs[0].ndim == 1
+                and inputs[0].flags.c_contiguous and len(inputs[0])):
+            # the usual call (one ready-made row): no marshalling copies, so that timing this method times the library
+            data = inputs[0]
+            offs = self._offs1
+            offs[1] = len(data)
+            n_rows = 1
         else:
-            data = np.zeros(1, np.float32)
+            rows = [np.ascontiguousarray(r, dtype=np.float32).ravel() for r in inputs]
+            offs = np.zeros(len(rows) + 1, dtype=np.uint64)
+            if rows:
+                offs[1:] = np.cumsum([len(r) for r in rows])
+                data = np.concatenate(rows) if offs[-1] else np.zeros(1, np.float32)
+            else:
+                data = np.zeros(1, np.float32)
+            n_rows = len(rows)
         self._check(self.L.fr_fill_buffer(self.h, out.ctypes.data, n_slots, n_times, start,
-                                          data.ctypes.data, offs.ctypes.data, len(rows)))
+                                          data.ctypes.data, offs.ctypes.data, n_rows))
         return out
 
     def fill_buffer_device(self, d_out_ptr, n_slots, n_times, idx, d_in_ptr, row_offsets, stream=0):

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
@@ -64,6 +65,7 @@ struct DevBuf {
 // Page-locked host staging memory (DMA without the runtime's own bounce copies; async copies stay async).
 struct PinnedBuf {
     void *p = nullptr;
+    void *dev = nullptr;     // the same memory as the GPU addresses it (mapped: kernels read and write it over PCIe)
     size_t bytes = 0;
     PinnedBuf() = default;
     PinnedBuf(const PinnedBuf &) = delete;
@@ -72,13 +74,15 @@ struct PinnedBuf {
     void ensure(size_t n) {
         if (n <= bytes) return;
         if (p) (void)hipHostFree(p);
-        p = nullptr;
+        p = dev = nullptr;
         bytes = 0;
         size_t want = std::max(n, (size_t)4096);
-        HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocMapped));
+        HIP_CHECK(hipHostGetDevicePointer(&dev, p, 0));
         bytes = want;
     }
     template <class T> T *as() const { return (T *)p; }
+    template <class T> T *as_dev() const { return (T *)dev; }
 };
 
 // One external input slot's history on the device (reference.rs:25 `inputs[slot]`).
@@ -142,8 +146,16 @@ struct fr_renderer {
     uint64_t head = 0;
     Plan plan;
     DevBuf d_out, d_in_table, d_stack_node, d_stack_time, d_stack_val, d_bank_ws;
-    // host-buffer entry point: input rows go up through pinned staging (one region per row, no sync between rows)
-    PinnedBuf h_in_stage;
+    // host-buffer entry point: input rows go up through pinned staging (one region per row, no sync between rows); the
+    // finished frames come down through h_out_stage, which the kernels write DIRECTLY (mapped pinned memory: the stores
+    // travel over PCIe while the launch is still computing), then one wait and one CPU copy into the caller's buffer
+    PinnedBuf h_in_stage, h_out_stage;
+    // FR_HOST_MAPPED (A/B): bit 0 = kernels write the output through the mapping, bit 1 = the bank kernel reads the
+    // input row through the mapping; 0 = the staged copies of round 1 (H2D row, D2H of the whole buffer)
+    bool host_out_mapped = false, host_rows_mapped = true;
+    bool host_trace = false;             // FR_HOST_TRACE=1: phase times of fr_fill_buffer on stderr at destroy
+    double trace_us[3] = {0, 0, 0};
+    uint64_t trace_n = 0;
     // Device-entry calls return before their work is done; a following call on ANOTHER stream (or the host entry
     // point, which uses the renderer's own stream) must still see this one's history, rings and plan uploads.
     hipEvent_t ev_last = nullptr;
@@ -309,6 +321,10 @@ struct fr_renderer {
             for (auto &pr : tc->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
         if (ev_last) (void)hipEventDestroy(ev_last);
+        if (host_trace && trace_n)
+            std::fprintf(stderr, "fr_fill_buffer phases over %llu calls (mapped out %d, mapped in %d): issue %.1f us, %s %.1f us, %s %.1f us\n",
+                         (unsigned long long)trace_n, (int)host_out_mapped, (int)host_rows_mapped, trace_us[0] / trace_n,
+                         host_out_mapped ? "wait" : "D2H issue", trace_us[1] / trace_n, host_out_mapped ? "CPU copy" : "wait", trace_us[2] / trace_n);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -491,7 +507,13 @@ struct fr_renderer {
                 float *stage = h_in_stage.as<float>() + (size_t)r * n_times;
                 if (rl) std::memcpy(stage, in_data + offs[r], rl * sizeof(float));
                 std::fill(stage + rl, stage + n_times, pad);
-                HIP_CHECK(hipMemcpyAsync(dst, stage, n_times * sizeof(float), hipMemcpyHostToDevice, st));
+                if (host_rows_mapped && n_times > 0 && bank_time_slot(n_slots, n_times, r, idx)) {
+                    // no copy at all: the bank kernel reads the row through the mapping and appends it to the history in
+                    // HBM itself (as it does for device-resident rows)
+                    deferred.push_back(Deferred{r, h_in_stage.as_dev<float>() + (size_t)r * n_times, dst});
+                } else {
+                    HIP_CHECK(hipMemcpyAsync(dst, stage, n_times * sizeof(float), hipMemcpyHostToDevice, st));
+                }
             }
             s.len += n_times;
         }
@@ -967,6 +989,12 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     if (const char *jv = std::getenv("FR_JIT")) r->allow_jit = jv[0] != '0';
     if (const char *tv = std::getenv("FR_BANK_TEMPLATE")) r->allow_template = tv[0] != '0';
     if (const char *mv = std::getenv("FR_BANK_MULTI")) r->allow_multi = mv[0] != '0';
+    if (const char *tv2 = std::getenv("FR_HOST_TRACE")) r->host_trace = tv2[0] == '1';
+    if (const char *hv = std::getenv("FR_HOST_MAPPED")) {
+        const int m = std::atoi(hv);
+        r->host_out_mapped = (m & 1) != 0;
+        r->host_rows_mapped = (m & 2) != 0;
+    }
     if (const char *sv = std::getenv("FR_STAGE_JIT")) r->stage_jit_mode = sv[0] == '0' ? 0 : (sv[0] == '1' ? 1 : 2);
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {
         delete r;
@@ -1025,18 +1053,49 @@ fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t 
         // (Rendering a long call as 2-4 sub-calls so that chunk c's D2H overlaps chunk c+1's kernels was tried: every
         //  extra sub-call costs ~35 us of launch/sync overhead and smaller, less efficient launches -- 197 us became
         //  231 / 242 / 277 us at 2 / 3 / 4 chunks for config C; profiles/r01_host_path.txt.)
-        r->d_out.ensure(bytes);
-        r->execute(r->d_out.as<float>(), n_slots, n_times, idx, st);
         // sharded: only the rows this rank owns come back (rank 0 under FR_SHARD_GATHER: every row)
         uint32_t row_lo, row_hi;
         r->my_rows(n_slots, row_lo, row_hi);
-        if (r->sharded() && (r->shard_flags & FR_SHARD_GATHER)) {
-            r->gather_rows(r->d_out.as<float>(), n_slots, n_times, st);
-            if (r->shard.rank == 0) { row_lo = 0; row_hi = n_slots; }
+        const bool gather = r->sharded() && (r->shard_flags & FR_SHARD_GATHER);
+        // (Pipelining the call -- row groups chained over a copy stream with events, or two halves on two streams of
+        //  different priority -- was measured and is slower: every cross-stream hand-off costs tens of microseconds on this
+        //  stack, profiles/r02_host_path.txt.  What helps is not moving bytes twice.)
+        using clk = std::chrono::steady_clock;
+        const auto t_a = clk::now();
+        if (r->host_out_mapped && !gather) {
+            // kernels store finished frames straight into mapped pinned memory; one wait, one copy to the caller's buffer
+            r->h_out_stage.ensure(bytes);
+            r->execute(r->h_out_stage.as_dev<float>(), n_slots, n_times, idx, st);
+            const auto t_b = clk::now();
+            HIP_CHECK(hipStreamSynchronize(st));   // synchronous contract: dispatch.rs:150-151
+            const auto t_c = clk::now();
+            const size_t off = (size_t)row_lo * n_times, cnt = (size_t)(row_hi - row_lo) * n_times;
+            if (cnt) std::memcpy(out + off, r->h_out_stage.as<float>() + off, cnt * sizeof(float));
+            if (r->host_trace) {
+                r->trace_us[0] += std::chrono::duration<double, std::micro>(t_b - t_a).count();
+                r->trace_us[1] += std::chrono::duration<double, std::micro>(t_c - t_b).count();
+                r->trace_us[2] += std::chrono::duration<double, std::micro>(clk::now() - t_c).count();
+                ++r->trace_n;
+            }
+        } else {
+            r->d_out.ensure(bytes);
+            r->execute(r->d_out.as<float>(), n_slots, n_times, idx, st);
+            if (gather) {
+                r->gather_rows(r->d_out.as<float>(), n_slots, n_times, st);
+                if (r->shard.rank == 0) { row_lo = 0; row_hi = n_slots; }
+            }
+            const size_t off = (size_t)row_lo * n_times, cnt = (size_t)(row_hi - row_lo) * n_times;
+            const auto t_b = clk::now();
+            if (cnt) HIP_CHECK(hipMemcpyAsync(out + off, r->d_out.as<float>() + off, cnt * sizeof(float), hipMemcpyDeviceToHost, st));
+            const auto t_c = clk::now();
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (r->host_trace) {
+                r->trace_us[0] += std::chrono::duration<double, std::micro>(t_b - t_a).count();
+                r->trace_us[1] += std::chrono::duration<double, std::micro>(t_c - t_b).count();
+                r->trace_us[2] += std::chrono::duration<double, std::micro>(clk::now() - t_c).count();
+                ++r->trace_n;
+            }
         }
-        const size_t off = (size_t)row_lo * n_times, cnt = (size_t)(row_hi - row_lo) * n_times;
-        if (cnt) HIP_CHECK(hipMemcpyAsync(out + off, r->d_out.as<float>() + off, cnt * sizeof(float), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));   // synchronous contract: dispatch.rs:150-151
         } catch (...) {
             r->rollback_store(snap);
             throw;
@@ -1072,6 +1131,21 @@ fr_status fr_fill_buffer_device(fr_renderer *r, float *d_out, uint32_t n_slots, 
         }
         r->remember_async(st, independent && !r->used_scratch);
         r->head = idx + n_times;
+    });
+}
+
+fr_status fr_host_register(fr_renderer *r, void *p, size_t bytes) {
+    return guarded(r, [&] {
+        if (!p || !bytes) throw Error(FR_ERR_INVALID_ARG, "empty range");
+        HIP_CHECK(hipSetDevice(r->device));
+        HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    });
+}
+
+fr_status fr_host_unregister(fr_renderer *r, void *p) {
+    return guarded(r, [&] {
+        HIP_CHECK(hipSetDevice(r->device));
+        HIP_CHECK(hipHostUnregister(p));
     });
 }
 

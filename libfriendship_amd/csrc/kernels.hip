@@ -303,8 +303,13 @@ __device__ __forceinline__ bool leaves_all_negzero(const float2 *params, uint32_
 // exactly -0.0 (AND and OR of the bit patterns both equal to the sign bit).  Not inlined: its registers must not
 // disturb the hot loop's allocation (an inlined second loop made the kernel 1.6x slower, profiles/r01_bank_variants.txt).
 template <bool FAST>
-__device__ __attribute__((noinline)) bool wave_leaves_all_negzero(const float *params, uint32_t ngroups, float t) {
+__device__ __attribute__((noinline)) bool wave_leaves_all_negzero(const float *params, uint32_t ngroups, float t, unsigned long long lanes) {
+    // `lanes`: the frames of the tile whose answer is wanted (those whose sum came out zero).  A lane's answer is
+    // settled as soon as it meets one leaf that is not -0, so the scan stops once that has happened in every wanted
+    // lane -- for a silent voice (amplitudes 0: leaves are +-0 with t-dependent signs; or every t*w beyond 2^23: all
+    // leaves +0) that is after the first pair of groups, and the voice costs one pass like a sounding one, not two.
     const_f32_ptr p = (const_f32_ptr)params;
+    const bool wanted = (lanes >> (threadIdx.x & 63u)) & 1ull;
     uint32_t all_and = 0xFFFFFFFFu, all_or = 0u;
     ParamGroup pa, pb;
     load_group(pa, p, 0);
@@ -325,6 +330,10 @@ __device__ __attribute__((noinline)) bool wave_leaves_all_negzero(const float *p
             __builtin_amdgcn_s_waitcnt(0xC07F);
             if (g + 2 < ngroups) load_group(pa, p, g + 2);
             fold(pb);
+        }
+        if (__ballot(wanted && all_and == 0x80000000u && all_or == 0x80000000u) == 0ull) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // (a prefetched group may still be landing in pa)
+            return false;
         }
     }
     return all_and == 0x80000000u && all_or == 0x80000000u;
@@ -415,8 +424,8 @@ __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tile
         for (int f = 0; f < F; ++f) {
             unsigned long long m = zmask[f];          // workgroup-uniform
             if (__builtin_popcountll(m) > 4) {        // many zeros in this tile: settle all 64 frames in one pass
-                bool mine = fast ? wave_leaves_all_negzero<true>(params, ngroups, t[f])
-                                 : wave_leaves_all_negzero<false>(params, ngroups, t[f]);
+                bool mine = fast ? wave_leaves_all_negzero<true>(params, ngroups, t[f], m)
+                                 : wave_leaves_all_negzero<false>(params, ngroups, t[f], m);
                 sm[wave][f][lane] = mine ? 1.0f : 0.0f;   // (the sums in sm were consumed before the barrier above)
                 __syncthreads();
                 if (wave == 0 && ((m >> lane) & 1ull)) {
@@ -483,8 +492,8 @@ __global__ void __launch_bounds__(256) bank_multi_kernel(BankArgs a, uint32_t ti
                 unsigned long long zm = __ballot(live && res[f] == 0.0f);
                 if (zm == 0ull) continue;
                 if (__builtin_popcountll(zm) > 4) {
-                    const bool all = fast ? wave_leaves_all_negzero<true>((const float *)vparams, ngroups, t[f])
-                                          : wave_leaves_all_negzero<false>((const float *)vparams, ngroups, t[f]);
+                    const bool all = fast ? wave_leaves_all_negzero<true>((const float *)vparams, ngroups, t[f], zm)
+                                          : wave_leaves_all_negzero<false>((const float *)vparams, ngroups, t[f], zm);
                     if ((zm >> lane) & 1ull) orow[bank_out_index(a, ti)] = all ? -0.0f : 0.0f;
                     continue;
                 }
@@ -837,7 +846,7 @@ __global__ void __launch_bounds__(256) gbank_kernel(BankArgs a, uint32_t tiles, 
             if (kk >= 5u) {
                 const uint32_t gq = 1u << (kk - 5u);
                 const float *q = fp + ((size_t)goff + (size_t)wave * gq) * 16u;
-                ok = (fast ? wave_leaves_all_negzero<true>(q, gq, t) : wave_leaves_all_negzero<false>(q, gq, t)) && ok;
+                ok = ok && (fast ? wave_leaves_all_negzero<true>(q, gq, t, zm) : wave_leaves_all_negzero<false>(q, gq, t, zm));
                 goff += 1u << (kk - 3u);
             } else {
                 if (wave == 0u) {
@@ -949,7 +958,7 @@ __global__ void __launch_bounds__(256) gbank_multi_kernel(BankArgs a, uint32_t t
                 const uint32_t kk = a.groups[i0 + i] & 15u;
                 if (kk > 3u) {
                     const float *q = (const float *)vparams + (size_t)goff * 16u;
-                    ok = (fast ? wave_leaves_all_negzero<true>(q, 1u << (kk - 3u), t) : wave_leaves_all_negzero<false>(q, 1u << (kk - 3u), t)) && ok;
+                    ok = ok && (fast ? wave_leaves_all_negzero<true>(q, 1u << (kk - 3u), t, zm) : wave_leaves_all_negzero<false>(q, 1u << (kk - 3u), t, zm));
                     goff += 1u << (kk - 3u);
                 } else {
                     for (uint32_t l = 0; l < (1u << kk); ++l) {

@@ -170,3 +170,31 @@ def test_harmonics_and_detune_as_graph_nodes(sim, oracle_lib, detune):
         assert plan["pull_rows"] == 0 and [(x["voices"], x["partials"]) for x in plan["banks"]] == [(V, P)], plan
         assert same_bits(got, ref.fill_buffer(V, 100, 100 + T, [t]))
         assert same_bits(got, b.fill_buffer(V, 100, 100 + T, [t]))
+
+
+def test_host_entry_point_two_interleaved_banks(sim, oracle_lib):
+    """fr_fill_buffer on a pure bank plan with two banks (different partial counts) interleaved over the rows: the first
+    bank launch reads the staged input row through the mapping and appends it to the history, the second reads it too;
+    a short (padded) row in the middle."""
+    g = synth.GraphArrays()
+    p = synth.voice_params(16, 64, 9, True)
+    a = synth.sum_tree(g, synth.partial_leaves(g, p["w"][:8, :32], p["amp"][:8, :32]).reshape(8, 32))
+    b = synth.sum_tree(g, synth.partial_leaves(g, p["w"][8:], p["amp"][8:]).reshape(8, 64))
+    rows = np.arange(16, dtype=np.uint32)
+    g.edge(a, 0, 0, rows[0::2])      # banks interleaved over the rows
+    g.edge(b, 0, 0, rows[1::2])
+    tree = g.finish(16)
+    T = 4100
+    with Renderer(sim) as r, Renderer(oracle_lib) as ref:
+        synth.install(r, tree)
+        synth.install(ref, tree)
+        for k, rl in enumerate((T, T - 100, T)):
+            t = synth.time_ramp(k * T, k * T + rl)
+            got = r.fill_buffer(16, k * T, (k + 1) * T, [t])
+            plan = r.plan()
+            assert len(plan["banks"]) == 2 and plan["pull_rows"] == 0
+            cols = [0, 1, 63, 64, T - 101, T - 100, T - 1]
+            for c in cols:   # the oracle evaluates sampled frames (a Delay-free graph: random access by seek)
+                tt = t[c:c + 1] if c < rl else t[-1:]
+                exp = ref.fill_buffer(16, k * T + c, k * T + c + 1, [tt])
+                assert same_bits(got[:, c:c + 1], exp), f"call {k} frame {c}"
