@@ -145,7 +145,7 @@ struct fr_renderer {
     std::vector<Seg> segs;
     uint64_t head = 0;
     Plan plan;
-    DevBuf d_out, d_in_table, d_stack_node, d_stack_time, d_stack_val, d_bank_ws;
+    DevBuf d_out, d_in_table, d_stack_node, d_stack_time, d_stack_val, d_bank_ws, d_tickets;
     // host-buffer entry point: input rows go up through pinned staging (one region per row, no sync between rows); the
     // finished frames come down through h_out_stage, which the kernels write DIRECTLY (mapped pinned memory: the stores
     // travel over PCIe while the launch is still computing), then one wait and one CPU copy into the caller's buffer
@@ -393,7 +393,13 @@ struct fr_renderer {
     }
     bool bank_time_slot(uint32_t n_slots, uint64_t n_times, uint32_t slot, uint64_t idx) const {
         if (!plan_current(n_slots)) return false;
-        if (n_times <= 2) return false;   // the shortest calls use bank_small_kernel, which does not append history
+        // (bank_small_kernel, used for the shortest calls of shapes the short-call kernel does not take, does not append)
+        for (const BankStage &bs : plan.banks) {
+            if (bs.grp.jit || bs.grp.general || bs.grp.input_slot != slot) continue;
+            uint32_t c, f, w, small, vpw;
+            bank_shape(bs.grp.log2_p, (uint32_t)bs.grp.rows.size(), n_times, c, f, w, small, vpw);
+            if (small == 1) return false;
+        }
         // a window with look-back reads the stored history, so the row must be there first; in steady state the bank
         // launch (always ahead of the programs on the stream) reads the caller's row and appends it like any other
         if ((plan.sp.uses_rings() || !plan.sp.progs.empty()) && !steady_call(idx, n_times)) return false;
@@ -794,12 +800,20 @@ struct fr_renderer {
                 a.voices_per_wave = 0;
                 a.frames_per_lane = 1;
             }
-            if (a.small_call && a.hist_dst) throw Error(FR_ERR_DEVICE, "internal: deferred history append on a short call");
+            if (a.small_call == 1 && a.hist_dst) throw Error(FR_ERR_DEVICE, "internal: deferred history append on a short call");
             a.leaf_variant = bank_leaf_variant;
             if (a.chunk_log2 != a.log2_p) {
                 used_scratch = true;
                 d_bank_ws.ensure(((size_t)a.n_voices << (a.log2_p - a.chunk_log2)) * blen * sizeof(float));
                 a.ws = d_bank_ws.as<float>();
+                if (a.small_call == 2) {   // arrival counters of the in-launch combine: zero between launches (the kernel resets them)
+                    const size_t need = (size_t)a.n_voices * ((blen + 63) / 64) * sizeof(uint32_t);
+                    if (need > d_tickets.bytes) {
+                        d_tickets.ensure(need * 2);
+                        HIP_CHECK(hipMemsetAsync(d_tickets.p, 0, d_tickets.bytes, st));
+                    }
+                    a.tickets = d_tickets.as<uint32_t>();
+                }
             }
             Scope sc(this, &t_bank, st);
             HIP_CHECK(launch_bank(a, st));

@@ -3,6 +3,7 @@
 // evaluator (reference src/render/reference.rs:197-262) rounds exactly once and so must we.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.hpp"
@@ -583,6 +584,127 @@ __global__ void __launch_bounds__(256) bank_combine_kernel(BankArgs a) {
     a.out[(size_t)a.rows[voice] * a.out_stride + bank_out_index(a, ti)] = result;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Short calls.  With few (voice, tile) pairs -- a 64-frame block of config C is 64 of them -- the time-major kernel
+// above leaves most of the chip idle and each wave walks its 512 partials as a chain of scalar loads: one
+// s_load_dwordx16 per 8 partials, ~150 ns each with nothing else on the SIMD to hide it (measured: 11 us per call for
+// any call of 8..256 frames, tools/short_call_probe.py).  Here instead
+//   * a voice is cut into `nchunks` chunks, one workgroup of NW waves each, so that hundreds of workgroups exist and a
+//     wave's chain of parameter loads is a handful of groups long, with several waves per SIMD to overlap them;
+//     (staging the chunk's parameters in LDS and reading them back as broadcast ds_read_b128 was built first: a
+//     wave-uniform value broadcast to 64 lanes costs the LDS the full 1 KiB of return bandwidth per instruction, and the
+//     kernel ran 2-6x SLOWER than the scalar-load form, profiles/r02_short_calls.txt);
+//   * lanes still run over frames and a wave still sums its partials in the graph's own association (same bank_group
+//     carry chain), the NW wave sums meet in LDS, and the chunk sums meet in HBM: every workgroup stores its 64 chunk
+//     sums write-through (sc1), waits for them, and takes a ticket (agent-scope atomic add); the workgroup whose add
+//     comes last reads all chunks back (sc1 loads) and adds them in tree order.  One launch, no grid barrier
+//     (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores -> vmcnt(0) -> one lane's atomic add -> the last
+//     adder loads sc1).
+// ---------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) bank_short_kernel(BankArgs a, uint32_t tiles) {
+    __shared__ float sm[NW][64];
+    __shared__ unsigned long long zshared;
+    const uint32_t clog = a.log2_p - a.chunk_log2, nchunks = 1u << clog;
+    const uint32_t chunk = blockIdx.x & (nchunks - 1u);   // the chunks of one (voice, tile) are neighbours in the grid
+    const uint32_t vt = blockIdx.x >> clog;
+    const uint32_t voice = vt / tiles, tile = vt - voice * tiles;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t ti = (uint64_t)tile * 64u + lane;
+    const bool live = ti < a.n_times;
+    const float t = bank_time(a, ti);
+    if (a.hist_dst && voice == 0u && chunk == 0u && wave == 0u && ti < a.time_valid) a.hist_dst[ti] = t;   // (every tile of voice 0)
+    const bool fast = a.fast_ok && __all(t >= 0.0f && t <= 4294967296.0f);   // the same 64 frames in every wave
+
+    const uint32_t Pc = 1u << a.chunk_log2;
+    const uint32_t Pw = Pc / NW, ngroups = Pw >> 3;
+    uint32_t levels = 0;
+    while ((1u << levels) < ngroups) ++levels;
+    const float *mine = (const float *)(a.params + ((size_t)voice << a.log2_p) + (size_t)chunk * Pc + (size_t)wave * Pw);
+    const float tt[1] = {t};
+    float r_wave[1];
+    if (fast) bank_wave_sum<1, true, false>(mine, ngroups, levels, tt, r_wave);
+    else bank_wave_sum<1, false, false>(mine, ngroups, levels, tt, r_wave);
+    sm[wave][lane] = r_wave[0];
+    __syncthreads();
+    float r = 0.0f;
+    if (wave == 0u) {   // the NW wave sums in tree order: adjacent pairs, level by level
+        float s[NW];
+        static_for<0, NW>([&](auto w) { s[w] = sm[w][lane]; });
+        static_for<0, NW / 2>([&](auto i) { s[i] = s[2 * i] + s[2 * i + 1]; });
+        if constexpr (NW >= 4) static_for<0, NW / 4>([&](auto i) { s[i] = s[2 * i] + s[2 * i + 1]; });
+        if constexpr (NW >= 8) static_for<0, NW / 8>([&](auto i) { s[i] = s[2 * i] + s[2 * i + 1]; });
+        if constexpr (NW >= 16) static_for<0, NW / 16>([&](auto i) { s[i] = s[2 * i] + s[2 * i + 1]; });
+        r = s[0];
+        const unsigned long long z = __ballot(live && r == 0.0f);
+        if (lane == 0u) zshared = z;
+    }
+    __syncthreads();
+    const unsigned long long zm = zshared;                // workgroup-uniform
+    if (zm != 0ull) {   // the sign of a zero chunk sum: -0 iff every leaf of the chunk is -0 in the graph's arithmetic
+        const bool ok = fast ? wave_leaves_all_negzero<true>(mine, ngroups, t, zm) : wave_leaves_all_negzero<false>(mine, ngroups, t, zm);
+        sm[wave][lane] = ok ? 1.0f : 0.0f;
+        __syncthreads();
+        if (wave == 0u && ((zm >> lane) & 1ull)) {
+            bool all = true;
+            static_for<0, NW>([&](auto w) { all = all && sm[w][lane] != 0.0f; });
+            r = all ? -0.0f : 0.0f;
+        }
+    }
+    if (wave != 0u) return;
+    float *orow = a.out + (size_t)a.rows[voice] * a.out_stride;
+    if (nchunks == 1u) {
+        if (live) orow[bank_out_index(a, ti)] = r;
+        return;
+    }
+    // publish this chunk's sums, take a ticket; the last workgroup of the (voice, tile) to arrive adds the chunks up
+    const size_t vstride = (size_t)a.n_voices * a.n_times;
+    float *slot = a.ws + (size_t)voice * a.n_times;
+    if (live) __hip_atomic_store(slot + (size_t)chunk * vstride + ti, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t old = 0u;
+    if (lane == 0u) old = __hip_atomic_fetch_add(a.tickets + vt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != nchunks - 1u) return;
+    if (live) {
+        // binary-counter carry over the chunks (nchunks = 2^clog <= 256): level k holds the finished left sibling of
+        // height k; named registers, so nothing is indexed dynamically (no scratch)
+        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f, c4 = 0.0f, c5 = 0.0f, c6 = 0.0f, c7 = 0.0f, c8 = 0.0f;
+        for (uint32_t c = 0; c < nchunks; ++c) {
+            float v = c == chunk ? r : __hip_atomic_load(slot + (size_t)c * vstride + ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            do {
+                if (!(c & 1u)) { c0 = v; break; } v = c0 + v;
+                if (!(c & 2u)) { c1 = v; break; } v = c1 + v;
+                if (!(c & 4u)) { c2 = v; break; } v = c2 + v;
+                if (!(c & 8u)) { c3 = v; break; } v = c3 + v;
+                if (!(c & 16u)) { c4 = v; break; } v = c4 + v;
+                if (!(c & 32u)) { c5 = v; break; } v = c5 + v;
+                if (!(c & 64u)) { c6 = v; break; } v = c6 + v;
+                if (!(c & 128u)) { c7 = v; break; } v = c7 + v;
+                c8 = v;
+            } while (0);
+        }
+        float result = c8;   // after the last chunk (all ones) the chain stopped at level clog
+        result = clog == 7u ? c7 : result; result = clog == 6u ? c6 : result; result = clog == 5u ? c5 : result;
+        result = clog == 4u ? c4 : result; result = clog == 3u ? c3 : result; result = clog == 2u ? c2 : result;
+        result = clog == 1u ? c1 : result;
+        orow[bank_out_index(a, ti)] = result;
+    }
+    if (lane == 0u) __hip_atomic_store(a.tickets + vt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+}
+
+template <int NW>
+static hipError_t launch_bank_short(const BankArgs &a, hipStream_t s) {
+    const uint64_t tiles = (a.n_times + 63) / 64;
+    const uint64_t nb = (tiles * a.n_voices) << (a.log2_p - a.chunk_log2);
+    if (nb == 0) return hipSuccess;
+    if (nb > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((bank_short_kernel<NW>), dim3((uint32_t)nb), dim3(64 * NW), 0, s, a, (uint32_t)tiles);
+    return hipGetLastError();
+}
+
 // Workgroups launch_bank uses for this shape.
 uint64_t bank_blocks(const BankArgs &a) {
     uint64_t f = a.frames_per_lane;
@@ -620,12 +742,39 @@ static hipError_t launch_bank_f(const BankArgs &a, hipStream_t s) {
 //    pass (T = 32: 13.9 us vs 31 us) and beats the lanes-over-partials kernel from T = 8 up (13.8 vs 17.4 us;
 //    T = 32: 13.9 vs 37 us); lanes-over-partials only ties at T = 1 (11.4 us), so it is used for T <= 2;
 //  * voices larger than one workgroup's capacity (8192 / 16384 partials) are split into chunks.
+static bool short_kernel_enabled() {   // FR_BANK_SHORT=0: A/B against the time-major kernel
+    static const bool on = [] { const char *e = std::getenv("FR_BANK_SHORT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane,
                 uint32_t &waves_per_group, uint32_t &small_call, uint32_t &voices_per_wave) {
     frames_per_lane = 1;
     voices_per_wave = 0;
-    small_call = (n_times <= 2 && log2_p >= 8 && n_voices <= 65535u) ? 1u : 0u;
-    if (small_call) {
+    small_call = 0;
+    {
+        // short calls: few (voice, tile) pairs.  Chunks of >= 512 partials until there are ~256 workgroups of 16 waves.
+        // Measured at 64 x 4096 (tools/short_call_probe.py, profiles/r02_short_calls.txt), us per call, this kernel vs the
+        // time-major one: T <= 64: 7.4 vs 11.2; 128: 8.3 vs 11.4; 256: 10.6 vs 11.6; 512: 19.5 vs 17.8 -- hence pairs <= 320.
+        // 512 or 1024 workgroups (more, smaller chunks) cost 2-3 us more in ticket traffic; 8 waves +0.3 us, 4 waves +2.4.
+        const uint64_t pairs = ((n_times + 63) / 64) * n_voices;
+        if (short_kernel_enabled() && pairs <= 320 && log2_p >= 9 && log2_p <= 20 && pairs > 0) {
+            static const uint64_t target = [] { const char *e = std::getenv("FR_SHORT_WGS"); return e ? (uint64_t)std::atoi(e) : 256ull; }();
+            static const uint32_t nw = [] { const char *e = std::getenv("FR_SHORT_NW"); return e ? (uint32_t)std::atoi(e) : 16u; }();
+            uint32_t c = log2_p;
+            uint64_t wgs = pairs;
+            while (c > 9 && (wgs < target || c > 13)) { --c; wgs *= 2; }
+            if (log2_p - c <= 8) {
+                chunk_log2 = c;
+                waves_per_group = nw;
+                while ((1u << c) / waves_per_group < 8u) waves_per_group /= 2;   // a wave needs a whole group of 8
+                small_call = 2;
+                return;
+            }
+        }
+    }
+    if (n_times <= 2 && log2_p >= 8 && n_voices <= 65535u) {   // lanes over partials (only where the short-call kernel does not apply)
+        small_call = 1;
         chunk_log2 = 8;
         waves_per_group = 4;
         return;
@@ -672,6 +821,17 @@ void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &
 }
 
 hipError_t launch_bank(const BankArgs &a, hipStream_t s) {
+    if (a.small_call == 2) {   // short calls: chunks over workgroups, LDS-staged parameters, in-launch combine
+        if (a.chunk_log2 < 7 || a.chunk_log2 > 13 || a.chunk_log2 > a.log2_p || a.log2_p - a.chunk_log2 > 8) return hipErrorInvalidValue;
+        if (a.chunk_log2 != a.log2_p && (!a.ws || !a.tickets)) return hipErrorInvalidValue;
+        if ((8u << a.chunk_log2) / (8u * a.waves_per_group) < 8u) return hipErrorInvalidValue;   // a wave needs a whole group
+        switch (a.waves_per_group) {
+        case 4: return launch_bank_short<4>(a, s);
+        case 8: return launch_bank_short<8>(a, s);
+        case 16: return launch_bank_short<16>(a, s);
+        default: return hipErrorInvalidValue;
+        }
+    }
     if (a.small_call) {   // lanes over partials
         if (a.log2_p < 8 || a.log2_p > 24 || a.n_times > SMALL_MAX_FRAMES || a.chunk_log2 != 8) return hipErrorInvalidValue;
         if (a.log2_p != 8 && !a.ws) return hipErrorInvalidValue;

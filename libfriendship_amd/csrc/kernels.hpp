@@ -59,12 +59,16 @@ struct BankArgs {
     uint32_t chunk_log2;       // partials per workgroup = 1 << chunk_log2 (5..13, <= log2_p); from bank_shape
     uint32_t frames_per_lane;  // 1, 2 or 4; from bank_shape
     uint32_t waves_per_group;  // 4 or 8; from bank_shape
-    uint32_t small_call;       // 1: lanes-over-partials kernel for calls of <= 32 frames; from bank_shape
+    uint32_t small_call;       // from bank_shape.  1: lanes-over-partials kernel (calls of <= 2 frames).  2: the short-call
+                               // kernel: too few (voice, tile) pairs to fill the chip, so every voice is split into chunks over
+                               // several workgroups of 4..16 waves, parameters staged through LDS, chunk sums combined by the
+                               // last workgroup to arrive (`tickets`) -- one launch
     uint32_t voices_per_wave;  // > 0: many small voices (<= 256 partials): a wave sums WHOLE voices, this many in a row, for one
                                // tile of frames -- no LDS, no barriers, the time values stay in registers (bank_multi_kernel)
     uint32_t leaf_variant;     // 0 = product-form leaves; 1 = FMA-form leaves + zero-sign repair (same bits, faster)
     float *hist_dst;           // if non-null: the kernel also copies time[0..time_valid) here (input-history append)
     float *ws;                 // [P >> chunk_log2][n_voices][n_times] partial sums; unused when one chunk
+    uint32_t *tickets;         // small_call == 2 with chunks: [n_voices][tiles] arrival counters, all zero between launches
     // general voices (launch_gbank): groups[i] = log2(item leaves, <= 11) | merges_after << 4; params = the items'
     // {w, -4*amp} pairs in order, items of < 8 leaves padded to 8 pairs; voice v owns items
     // [group_off[2v], group_off[2v+2]) and its parameters start at pair 8 * group_off[2v+1]

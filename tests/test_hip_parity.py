@@ -430,6 +430,45 @@ def test_host_entry_point_two_interleaved_banks(hip_lib, oracle_lib):
     test_sim_engine.test_host_entry_point_two_interleaved_banks(hip_lib, oracle_lib)
 
 
+@pytest.mark.parametrize("V,P,T,block", [(64, 4096, 4800, 64), (64, 4096, 2048, 512), (3, 65536, 640, 64), (16, 512, 1280, 128),
+                                         (640, 512, 256, 64), (5, 2048, 700, 100), (1, 1 << 20, 192, 64)])
+def test_short_call_kernel_equals_block_render(hip_lib, V, P, T, block):
+    """The short-call kernel (voices cut into chunks over workgroups, parameters staged through LDS, chunk sums combined by
+    the last workgroup to arrive) against the time-major kernel: the same frames rendered as one long call and as many
+    short calls must be the same bits -- every frame of every voice, several passes (the in-launch combine is a
+    cross-workgroup hand-off: a stale read would show as a wrong sample somewhere)."""
+    tree = synth.additive_tree(V, P, seed=V + P, detune=True)
+    t = synth.time_ramp(0, T)
+    with Renderer(hip_lib) as a, Renderer(hip_lib) as b:
+        synth.install(a, tree)
+        synth.install(b, tree)
+        whole = a.fill_buffer(V, 0, T, [t])
+        for rep in range(6):
+            base = rep * T   # contiguous calls, the same time VALUES every pass
+            parts = np.concatenate([b.fill_buffer(V, base + s, base + min(s + block, T), [t[s:min(s + block, T)]])
+                                    for s in range(0, T, block)], axis=1)
+            assert same_bits(whole, parts), f"pass {rep}: " + first_diff(parts, whole)
+
+
+def test_short_call_kernel_against_oracle(hip_lib, oracle_lib):
+    """Short calls of a chunked voice against the oracle, t = 0 (an exact zero whose sign the chunks must settle), negative
+    and fractional times (the general fract path) included."""
+    V, P = 4, 2048
+    tree = synth.additive_tree(V, P, seed=8, detune=True)
+    rng = np.random.default_rng(3)
+    rows = [synth.time_ramp(0, 64), synth.time_ramp(64, 100), -synth.time_ramp(0, 50), (rng.normal(size=70) * 100).astype(np.float32),
+            np.zeros(33, np.float32)]
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        idx = 0
+        for row in rows:
+            got = hip.fill_buffer(V, idx, idx + len(row), [row])
+            exp = ref.fill_buffer(V, idx, idx + len(row), [row])
+            assert same_bits(got, exp), first_diff(got, exp)
+            idx += len(row)
+
+
 def test_rccl_is_loadable_and_hands_out_an_id(hip_lib):
     """fr_comm_unique_id = ncclGetUniqueId through the engine's lazily loaded RCCL (one rank cannot exercise more)."""
     a, b = hip_lib.comm_unique_id(), hip_lib.comm_unique_id()
