@@ -128,20 +128,27 @@ enum {
     FR_SEMANTICS_SPARKLE = 1
 };
 
+/* fr_config.flags.  Kernels specialised at run time (hipRTC, ~0.1 s per distinct shape) are compiled on a worker
+ * thread by default: fill_buffer never waits for a compiler, calls are served by the generic evaluators meanwhile and
+ * the plan switches over when the kernel is ready (same bits either way).  FR_CONFIG_SYNC_COMPILE compiles inside the
+ * call that first needs the kernel instead: deterministic plans for tests, benchmarks and offline rendering. */
+#define FR_CONFIG_SYNC_COMPILE 1u
+
 typedef struct fr_config {
     uint32_t abi_version;          /* FR_ABI_VERSION                                              */
     int32_t device;                /* HIP device ordinal; -1 = current device                     */
     int32_t mode;                  /* FR_MODE_*                                                   */
-    uint32_t flags;                /* reserved, 0                                                 */
+    uint32_t flags;                /* FR_CONFIG_*                                                 */
     int32_t semantics;             /* FR_SEMANTICS_*                                              */
     uint32_t reserved;             /* 0                                                           */
     uint64_t history_frames;       /* Input history kept per slot, in frames; 0 = everything since the last
                                       seek, which is the reference's behaviour (reference.rs:25,70-73).  With a
-                                      cap, samples older than `head - history_frames` read as 0.0 -- exactly what
-                                      the reference returns for times before a seek point -- so a Delay (or a
-                                      later-added longer Delay) reaching further back than the cap sees silence
-                                      there.  The engine never trims below what the current plan's constant
-                                      delays and proven bounds need; the cap is rounded up to that.            */
+                                      cap, a call rendering [idx, idx + n) sees input samples older than
+                                      idx - history_frames as 0.0 -- what the reference returns for times before
+                                      a seek point -- so a later-added Delay reaching further back than the cap
+                                      sees silence there.  The cap is raised to what the current plan's constant
+                                      delays and proven delay bounds need, so a graph never loses samples it can
+                                      be shown to read; memory per fed slot is then 2 * (cap + call length).     */
 } fr_config;
 
 /* cfg may be NULL (device -1, FR_MODE_AUTO). */

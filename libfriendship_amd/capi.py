@@ -37,6 +37,7 @@ FR_SHARD_NONE, FR_SHARD_VOICES, FR_SHARD_PARTIALS = 0, 1, 2
 SHARD_MODES = {"none": FR_SHARD_NONE, "voices": FR_SHARD_VOICES, "partials": FR_SHARD_PARTIALS}
 FR_SHARD_GATHER = 1
 FR_COMM_ID_BYTES = 128
+FR_CONFIG_SYNC_COMPILE = 1
 
 FR_ABI_VERSION = 2
 
@@ -213,10 +214,12 @@ class RendererLib:
 class Renderer:
     """Handle-owning wrapper: one method per entry point, arguments as in the reference's traits."""
 
-    def __init__(self, rlib, mode="auto", device=-1, semantics="reference", history_frames=0):
+    def __init__(self, rlib, mode="auto", device=-1, semantics="reference", history_frames=0, sync_compile=True):
+        """sync_compile: hipRTC specialisations are compiled inside the call that first needs them (deterministic plans:
+        what tests and benchmarks want); False = the ABI's default, compile on a worker thread and switch over when ready."""
         self.rlib = rlib
         self.L = rlib.lib
-        cfg = fr_config(FR_ABI_VERSION, device, MODES[mode] if isinstance(mode, str) else mode, 0,
+        cfg = fr_config(FR_ABI_VERSION, device, MODES[mode] if isinstance(mode, str) else mode, FR_CONFIG_SYNC_COMPILE if sync_compile else 0,
                         SEMANTICS[semantics] if isinstance(semantics, str) else semantics, 0, history_frames)
         h = C.c_void_p()
         st = self.L.fr_renderer_create(C.byref(cfg), C.byref(h))

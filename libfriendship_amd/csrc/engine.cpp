@@ -104,6 +104,8 @@ struct Plan {
     bool valid = false;
     uint64_t version = 0;
     uint64_t shard_epoch = 0;            // fr_set_shard generation the plan was made for
+    bool jit_pending = false;            // planned without a kernel that hipRTC is still compiling in the background:
+    uint64_t jit_epoch = 0;              // stale as soon as the cache's epoch moves on
     uint32_t n_slots = 0;
     uint32_t max_depth = 0;              // of the lowered graph (pull stack sizing)
     std::vector<BankStage> banks;
@@ -213,7 +215,8 @@ struct fr_renderer {
         if (sharded()) shard_row_range(shard.rank, shard.world, n_slots, lo, hi);
     }
     bool plan_current(uint32_t n_slots) const {
-        return plan.valid && plan.version == mirror.version && plan.n_slots == n_slots && plan.shard_epoch == shard_epoch;
+        return plan.valid && plan.version == mirror.version && plan.n_slots == n_slots && plan.shard_epoch == shard_epoch &&
+               !(plan.jit_pending && plan.jit_epoch != jit_cache.epoch());
     }
 
     // Pairwise exchange with `peer` on stream st (device pointers, counts in floats).
@@ -320,6 +323,7 @@ struct fr_renderer {
         for (TimerClass *tc : {&t_bank, &t_pull, &t_stage})
             for (auto &pr : tc->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
+        for (Retired &g : graveyard) (void)hipEventDestroy(g.ev);
         if (ev_last) (void)hipEventDestroy(ev_last);
         if (host_trace && trace_n)
             std::fprintf(stderr, "fr_fill_buffer phases over %llu calls (mapped out %d, mapped in %d): issue %.1f us, %s %.1f us, %s %.1f us\n",
@@ -363,16 +367,63 @@ struct fr_renderer {
     }
 
     // ---- input store (reference.rs:47-75) -------------------------------------------------------
-    void grow(InSlot &s, uint64_t need_floats, hipStream_t st) {
-        if (need_floats <= s.cap) return;
-        // growth stalls the stream (alloc + copy + sync): start at 4 MiB per fed slot and double from there
-        uint64_t cap = std::max<uint64_t>(need_floats, std::max<uint64_t>(s.cap * 2, 1u << 20));
+    // Frames of input history kept per slot (0 = everything since the last seek: the reference, reference.rs:25).  With
+    // fr_config.history_frames set, at least what the current plan's constant delays and proven bounds can reach.
+    uint64_t keep_frames() const {
+        if (!history_frames) return 0;
+        return std::max<uint64_t>(history_frames, plan.valid ? plan.sp.input_lookback : 0);
+    }
+    // Buffers replaced by bigger ones are freed once the stream has passed the copy out of them -- never by waiting.
+    uint64_t call_idx = 0;               // first frame of the call being served
+    uint64_t history_floor = 0;          // bounded history: input samples before this frame read as 0.0 (monotone)
+    struct Retired { DevBuf buf; hipEvent_t ev; };
+    std::vector<Retired> graveyard;
+    void bury(DevBuf &&b, hipStream_t st) {
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, st) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_CHECK(hipStreamSynchronize(st));   // (cannot track it: wait once)
+            if (ev) (void)hipEventDestroy(ev);
+            return;                                // `b` is freed here
+        }
+        graveyard.push_back(Retired{std::move(b), ev});
+    }
+    void reap() {
+        for (size_t i = 0; i < graveyard.size();) {
+            if (hipEventQuery(graveyard[i].ev) == hipSuccess) {
+                (void)hipEventDestroy(graveyard[i].ev);
+                graveyard[i] = std::move(graveyard.back());
+                graveyard.pop_back();
+            } else {
+                (void)hipGetLastError();
+                ++i;
+            }
+        }
+    }
+    // Room for n_times more frames in slot s.  Bounded history slides in place (the newest `keep` frames move to the
+    // front of a buffer sized 2 * (keep + call) -- one small device copy every `keep` frames, no allocation); unbounded
+    // history doubles into a new buffer with an asynchronous copy, the old buffer retired without a stream wait.
+    void make_room(InSlot &s, uint64_t n_times, hipStream_t st) {
+        uint64_t stored = s.len - s.base;
+        if (stored + n_times <= s.cap) return;
+        if (last_pending) HIP_CHECK(hipDeviceSynchronize());   // a call on another stream may still be appending to this buffer
+        const uint64_t keep = keep_frames();
+        if (keep && stored > keep) {
+            const uint64_t drop = stored - keep;
+            if (drop >= keep && keep + n_times <= s.cap) {         // source and destination do not overlap
+                HIP_CHECK(hipMemcpyAsync(s.buf.p, s.buf.as<float>() + drop, keep * sizeof(float), hipMemcpyDeviceToDevice, st));
+                s.base += drop;
+                return;
+            }
+        }
+        const uint64_t kept = keep ? std::min(stored, keep) : stored;
+        const uint64_t cap = keep ? std::max<uint64_t>(2 * (keep + n_times), 1u << 16)
+                                  : std::max<uint64_t>(stored + n_times, std::max<uint64_t>(s.cap * 2, 1u << 20));
         DevBuf nb;
         nb.ensure(cap * sizeof(float));
-        uint64_t stored = s.len - s.base;
-        if (last_pending) HIP_CHECK(hipDeviceSynchronize());   // a call on another stream may still be appending to the old buffer
-        if (stored) HIP_CHECK(hipMemcpyAsync(nb.p, s.buf.p, stored * sizeof(float), hipMemcpyDeviceToDevice, st));
-        HIP_CHECK(hipStreamSynchronize(st));   // old buffer is freed below
+        if (kept) HIP_CHECK(hipMemcpyAsync(nb.p, s.buf.as<float>() + (stored - kept), kept * sizeof(float), hipMemcpyDeviceToDevice, st));
+        s.base += stored - kept;
+        if (s.buf.p) bury(std::move(s.buf), st);
         s.buf = std::move(nb);
         s.cap = cap;
     }
@@ -446,7 +497,12 @@ struct fr_renderer {
             return;
         }
         for (size_t i = 0; i < slots.size(); ++i) {
-            if (i < sn.slots.size()) { slots[i].fed = sn.slots[i].fed; slots[i].base = sn.slots[i].base; slots[i].len = sn.slots[i].len; }
+            if (i < sn.slots.size()) {
+                // (a bounded history may have slid forward meanwhile: the buffer then starts at the later base)
+                slots[i].fed = sn.slots[i].fed;
+                slots[i].base = std::min(std::max(slots[i].base, sn.slots[i].base), sn.slots[i].len);
+                slots[i].len = sn.slots[i].len;
+            }
             else { slots[i].fed = false; slots[i].base = slots[i].len = 0; }
         }
         segs = sn.segs;
@@ -457,6 +513,8 @@ struct fr_renderer {
     void store_inputs(uint32_t n_slots, uint64_t n_times, uint64_t idx, const float *in_data,
                       const uint64_t *offs, uint32_t n_rows, bool device_rows, hipStream_t st) {
         deferred.clear();
+        reap();
+        call_idx = idx;
         const bool seek = idx != head;   // forget history, act as if inputs were 0 before idx (renderer.rs:12-15)
         // validate everything before mutating so a refused call leaves the history intact: the lengths the rows must
         // continue are those AFTER the seek (idx for every vec) and after the vec count grew (reference.rs:52-71)
@@ -478,6 +536,12 @@ struct fr_renderer {
             for (InSlot &s : slots) { s.base = idx; s.len = idx; }
             segs.clear();
             if (n_vecs) segs.push_back({0, n_vecs, idx});
+            history_floor = 0;   // (everything before idx is zero now anyway)
+        }
+        {   // bounded history: what this call may see, and no later call may see more (deterministic whatever slack the
+            // buffers happen to hold when a longer Delay arrives)
+            const uint64_t keep = keep_frames();
+            if (keep && idx > keep) history_floor = std::max(history_floor, idx - keep);
         }
         uint64_t want = (uint64_t)n_slots * n_times;   // `buff.len()`, reference.rs:60 (element count, a quirk)
         if (n_vecs < want) { segs.push_back({n_vecs, want, idx}); n_vecs = want; }
@@ -490,7 +554,8 @@ struct fr_renderer {
             if (!s.fed) { s.fed = true; s.base = implicit_len(r); s.len = s.base; }
             uint64_t rl = offs[r + 1] - offs[r];
             uint64_t stored = s.len - s.base;
-            grow(s, stored + n_times, st);
+            make_room(s, n_times, st);
+            stored = s.len - s.base;
             float *dst = s.buf.as<float>() + stored;
             if (device_rows && rl == n_times && rl > 0 && bank_time_slot(n_slots, n_times, r, idx)) {
                 deferred.push_back(Deferred{r, in_data + offs[r], dst});
@@ -532,6 +597,13 @@ struct fr_renderer {
             d.data = s.buf.as<float>();
             d.base = s.base;
             d.len = s.len;
+            // bounded history: exactly `keep` frames before the call's first frame are visible, whatever slack the
+            // buffer still holds (so that results do not depend on when the buffer last slid)
+            if (history_floor > d.base) {
+                const uint64_t floor = std::min(history_floor, d.len);
+                d.data += floor - d.base;
+                d.base = floor;
+            }
         }
         return d;
     }
@@ -554,12 +626,20 @@ struct fr_renderer {
         }
         p.sp = plan_stages(fg, mode == FR_MODE_AUTO, mode != FR_MODE_PULL, 20, use_jit, allow_template, matcher.get(), shard_spec);
         std::vector<std::shared_ptr<JitKernel>> jits(p.sp.banks.size());
+        p.jit_epoch = jit_cache.epoch();   // (read first: a compile finishing from here on makes this plan stale)
         if (use_jit) {
+            bool without = false;
             try {
                 for (size_t i = 0; i < p.sp.banks.size(); ++i)
-                    if (p.sp.banks[i].jit) jits[i] = jit_cache.get(p.sp.banks[i].shape, p.sp.banks[i].varying, p.sp.banks[i].literal_bits, p.sp.banks[i].alias);
+                    if (p.sp.banks[i].jit) {
+                        jits[i] = jit_cache.get(p.sp.banks[i].shape, p.sp.banks[i].varying, p.sp.banks[i].literal_bits, p.sp.banks[i].alias);
+                        if (!jits[i]) p.jit_pending = without = true;   // being compiled on the worker thread: do not wait
+                    }
             } catch (const Error &e) {   // hipRTC unavailable or the generated source did not compile: plan without it
                 jit_error = e.what();
+                without = true;
+            }
+            if (without) {
                 p.sp = plan_stages(fg, true, true, 20, false, true, nullptr, shard_spec);
                 jits.assign(p.sp.banks.size(), nullptr);
             }
@@ -598,6 +678,10 @@ struct fr_renderer {
             if (allow_jit && stage_jit_mode != 0 && plan_stage_jit(p.sp.progs, p.sp.instrs, 32, stage_jit_mode == 2, sj)) {
                 try {
                     p.stage_jit = jit_cache.get_source(sj.source, "jit_stage");
+                    if (!p.stage_jit) {   // still compiling: the interpreter serves the calls until the plan is rebuilt
+                        p.jit_pending = true;
+                        throw Error(FR_OK, "");
+                    }
                     p.stage_shapes = sj.n_shapes;
                     p.d_jprogs.ensure(sj.progs.size() * sizeof(JitStageProg));
                     p.d_ptab.ensure(std::max<size_t>(sj.ptab.size(), 1) * sizeof(uint32_t));
@@ -606,7 +690,7 @@ struct fr_renderer {
                         HIP_CHECK(hipMemcpyAsync(p.d_ptab.p, sj.ptab.data(), sj.ptab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
                     HIP_CHECK(hipStreamSynchronize(st));   // `sj` goes out of scope
                 } catch (const Error &e) {   // keep the interpreter
-                    jit_error = e.what();
+                    if (e.code != FR_OK) jit_error = e.what();
                     p.stage_jit = nullptr;
                 }
             }
@@ -653,7 +737,9 @@ struct fr_renderer {
            << ",\"stage_levels\":" << (p.sp.level_first.empty() ? 0 : p.sp.level_first.size() - 1)
            << ",\"stage_jit\":" << (p.stage_jit ? "true" : "false") << ",\"stage_shapes\":" << p.stage_shapes
            << ",\"rings\":" << p.sp.n_rings << ",\"max_lookback\":" << p.sp.lmax
-           << ",\"jit_kernels_compiled\":" << jit_cache.compiled() << ",\"jit_compile_ms\":" << jit_cache.compile_ms()
+           << ",\"input_lookback\":" << p.sp.input_lookback << ",\"input_lookback_unbounded\":" << (p.sp.input_lookback_unbounded ? "true" : "false")
+           << ",\"history_frames\":" << history_frames
+           << ",\"jit_pending\":" << (p.jit_pending ? "true" : "false") << ",\"jit_kernels_compiled\":" << jit_cache.compiled() << ",\"jit_compile_ms\":" << jit_cache.compile_ms()
            << ",\"pull_rows\":" << p.pull_rows.size()
            << ",\"shard\":{\"rank\":" << shard.rank << ",\"world\":" << shard.world << ",\"mode\":" << (sharded() ? shard.mode : 0)
            << ",\"split_voices\":" << p.sp.split.size() << ",\"transport\":\"" << (rccl ? "rccl" : has_host_comm ? "host-callback" : "none") << "\"}"
@@ -980,7 +1066,7 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     if (cfg && cfg->abi_version != FR_ABI_VERSION) return FR_ERR_INVALID_ARG;
     int mode = cfg ? cfg->mode : FR_MODE_AUTO;
     if (mode < FR_MODE_AUTO || mode > FR_MODE_STAGED) return FR_ERR_INVALID_ARG;
-    if (cfg && (cfg->flags != 0 || cfg->reserved != 0)) return FR_ERR_INVALID_ARG;
+    if (cfg && ((cfg->flags & ~FR_CONFIG_SYNC_COMPILE) != 0 || cfg->reserved != 0)) return FR_ERR_INVALID_ARG;
     if (cfg && cfg->semantics != FR_SEMANTICS_REFERENCE && cfg->semantics != FR_SEMANTICS_SPARKLE) return FR_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FR_ERR_NO_DEVICE;
@@ -997,6 +1083,7 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     if (!r) return FR_ERR_OUT_OF_MEMORY;
     r->device = dev;
     r->mode = mode;
+    r->jit_cache.set_async(!(cfg && (cfg->flags & FR_CONFIG_SYNC_COMPILE)));
     r->semantics = cfg ? cfg->semantics : FR_SEMANTICS_REFERENCE;
     r->history_frames = cfg ? cfg->history_frames : 0;
     if (const char *lv = std::getenv("FR_BANK_LEAF")) r->bank_leaf_variant = (lv[0] == '1') ? 1u : 0u;

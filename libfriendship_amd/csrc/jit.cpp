@@ -3,7 +3,10 @@
 
 #include <hip/hiprtc.h>
 
+#include <atomic>
 #include <chrono>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <functional>
 #include <map>
@@ -144,23 +147,44 @@ std::string JitCache::generate_source(const LeafShape &shape, const std::vector<
     return src.str();
 }
 
+// One cache entry: the source's code object once hipRTC is through with it (worker thread), then the loaded module
+// (made on the calling thread, which has the device current).
+struct JitCache::Impl {
+    struct Entry {
+        enum State { COMPILING, CODE_READY, LOADED, FAILED } state = COMPILING;
+        std::string fn_name, error;
+        std::vector<char> code;
+        std::shared_ptr<JitKernel> kernel;
+        std::thread worker;
+        double ms = 0;
+    };
+    std::mutex mu;
+    std::map<std::string, std::unique_ptr<Entry>> cache;
+    std::atomic<uint64_t> epoch{0};
+    size_t compiled = 0;
+    double compile_ms = 0;
+};
+
+JitCache::JitCache() : impl_(new Impl) {}
+JitCache::~JitCache() {
+    for (auto &kv : impl_->cache)
+        if (kv.second->worker.joinable()) kv.second->worker.join();
+    delete impl_;
+}
+uint64_t JitCache::epoch() const { return impl_->epoch.load(); }
+size_t JitCache::compiled() const { std::lock_guard<std::mutex> g(impl_->mu); return impl_->compiled; }
+double JitCache::compile_ms() const { std::lock_guard<std::mutex> g(impl_->mu); return impl_->compile_ms; }
+
 std::shared_ptr<JitKernel> JitCache::get(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
                                          const std::vector<uint32_t> &alias) {
     std::shared_ptr<JitKernel> jk = get_source(generate_source(shape, varying, literal_bits, alias), "jit_bank");
-    if (!jk->k)
+    if (jk && !jk->k)
         for (size_t c = 0; c < varying.size(); ++c) jk->k += (varying[c] && alias[c] == c) ? 1 : 0;
     return jk;
 }
 
-std::shared_ptr<JitKernel> JitCache::get_source(const std::string &src, const char *fn_name) {
-    auto it = cache_.find(src);
-    if (it != cache_.end()) return it->second;
-    auto t0 = std::chrono::steady_clock::now();
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-        throw Error(FR_ERR_DEVICE, "jit: cannot query the device");
-    std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
+// hipRTC only: source text -> code object.  No HIP runtime state is touched, so it may run on any thread.
+static void compile_source(const std::string &src, const std::string &arch, std::vector<char> &code) {
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "fr_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         throw Error(FR_ERR_DEVICE, "jit: hiprtcCreateProgram failed");
@@ -177,17 +201,70 @@ std::shared_ptr<JitKernel> JitCache::get_source(const std::string &src, const ch
     }
     size_t cs = 0;
     hiprtcGetCodeSize(prog, &cs);
-    std::vector<char> code(cs);
+    code.resize(cs);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
-    auto jk = std::make_shared<JitKernel>();
-    if (hipModuleLoadData(&jk->module, code.data()) != hipSuccess) throw Error(FR_ERR_DEVICE, "jit: hipModuleLoadData failed");
-    if (hipModuleGetFunction(&jk->fn, jk->module, fn_name) != hipSuccess) throw Error(FR_ERR_DEVICE, "jit: kernel symbol missing");
-    if (std::string(fn_name) == "jit_bank" && hipModuleGetFunction(&jk->fn_multi, jk->module, "jit_bank_multi") != hipSuccess) jk->fn_multi = nullptr;
-    compile_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    ++compiled_;
-    cache_.emplace(src, jk);
-    return jk;
+}
+
+std::shared_ptr<JitKernel> JitCache::get_source(const std::string &src, const char *fn_name) {
+    std::unique_lock<std::mutex> lock(impl_->mu);
+    auto it = impl_->cache.find(src);
+    if (it == impl_->cache.end()) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            throw Error(FR_ERR_DEVICE, "jit: cannot query the device");
+        const std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
+        it = impl_->cache.emplace(src, std::unique_ptr<Impl::Entry>(new Impl::Entry)).first;
+        Impl::Entry *e = it->second.get();
+        e->fn_name = fn_name;
+        Impl *impl = impl_;
+        auto job = [impl, e, src, arch] {   // (`src` by value: the map key may outlive nothing else here)
+            auto t0 = std::chrono::steady_clock::now();
+            std::vector<char> code;
+            std::string error;
+            try {
+                compile_source(src, arch, code);
+            } catch (const std::exception &ex) {
+                error = ex.what();
+            }
+            std::lock_guard<std::mutex> g(impl->mu);
+            e->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            e->code = std::move(code);
+            e->error = std::move(error);
+            e->state = e->error.empty() ? Impl::Entry::CODE_READY : Impl::Entry::FAILED;
+            impl->epoch.fetch_add(1);
+        };
+        if (async_) {
+            e->worker = std::thread(job);
+            return nullptr;
+        }
+        lock.unlock();
+        job();
+        lock.lock();
+    }
+    Impl::Entry *e = it->second.get();
+    if (e->state == Impl::Entry::COMPILING) return nullptr;
+    if (e->state == Impl::Entry::FAILED) throw Error(FR_ERR_DEVICE, e->error);
+    if (e->state == Impl::Entry::CODE_READY) {   // load on this thread: it has the device current
+        if (e->worker.joinable()) e->worker.join();
+        auto jk = std::make_shared<JitKernel>();
+        const bool ok = hipModuleLoadData(&jk->module, e->code.data()) == hipSuccess &&
+                        hipModuleGetFunction(&jk->fn, jk->module, e->fn_name.c_str()) == hipSuccess;
+        if (!ok) {
+            e->state = Impl::Entry::FAILED;
+            e->error = "jit: loading the compiled code object failed";
+            throw Error(FR_ERR_DEVICE, e->error);
+        }
+        if (e->fn_name == "jit_bank" && hipModuleGetFunction(&jk->fn_multi, jk->module, "jit_bank_multi") != hipSuccess) jk->fn_multi = nullptr;
+        e->code.clear();
+        e->code.shrink_to_fit();
+        e->kernel = jk;
+        e->state = Impl::Entry::LOADED;
+        impl_->compile_ms += e->ms;
+        ++impl_->compiled;
+    }
+    return e->kernel;
 }
 
 hipError_t launch_jit_bank(const JitKernel &k, const JitBankArgs &a, hipStream_t s) {

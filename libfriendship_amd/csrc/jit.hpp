@@ -104,24 +104,34 @@ struct JitKernel {
     ~JitKernel();
 };
 
+// hipRTC takes ~110 ms per distinct source.  By default that happens on a worker thread: get()/get_source() return
+// null ("not yet") at once, the caller plans without the kernel (interpreted programs, the pull interpreter) and plans
+// again when epoch() has moved -- fill_buffer never waits for a compiler.  set_async(false) compiles in the call
+// (fr_config.flags & FR_CONFIG_SYNC_COMPILE: tests, benchmarks, offline rendering).
 class JitCache {
 public:
+    JitCache();
+    ~JitCache();   // waits for compiles still running
+    JitCache(const JitCache &) = delete;
+    JitCache &operator=(const JitCache &) = delete;
     // `varying[c]` says whether constant column c is a per-leaf parameter; literals[c] is its value otherwise.
-    // Returns the compiled kernel (cached by generated source).  Throws fr::Error on compile/load failure.
-    // alias[c]: the column whose parameter column c shares (c itself if none).
+    // Returns the compiled kernel (cached by generated source), or null while it is being compiled in the background.
+    // Throws fr::Error on compile/load failure.  alias[c]: the column whose parameter column c shares (c itself if none).
     std::shared_ptr<JitKernel> get(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
                                    const std::vector<uint32_t> &alias);
     // any generated source with one extern "C" kernel `fn_name` (cached by source text)
     std::shared_ptr<JitKernel> get_source(const std::string &src, const char *fn_name);
     static std::string generate_source(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
                                        const std::vector<uint32_t> &alias);
-    size_t compiled() const { return compiled_; }
-    double compile_ms() const { return compile_ms_; }
+    void set_async(bool on) { async_ = on; }
+    uint64_t epoch() const;        // bumped whenever a background compile finishes (successfully or not)
+    size_t compiled() const;
+    double compile_ms() const;
 
 private:
-    std::map<std::string, std::shared_ptr<JitKernel>> cache_;
-    size_t compiled_ = 0;
-    double compile_ms_ = 0;
+    struct Impl;
+    Impl *impl_;
+    bool async_ = true;
 };
 
 hipError_t launch_jit_bank(const JitKernel &k, const JitBankArgs &a, hipStream_t s);

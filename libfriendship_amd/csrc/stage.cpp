@@ -457,6 +457,21 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         level[m] = lv;
     }
 
+    // input look-back (see StagedPlan::input_lookback)
+    for (uint32_t m : cuts) {
+        const uint64_t lm = L[m];
+        for (const StageInstr &in : built[m].instrs) {
+            if (in.op == S_INPUT) sp.input_lookback = std::max(sp.input_lookback, lm);
+            else if (in.op == S_READ_INPUT) sp.input_lookback = std::max(sp.input_lookback, lm + in.d_lo);
+            else if (in.op == S_READ_INPUT_DYN) {
+                if (in.d_lo == 0xFFFFFFFFu) sp.input_lookback_unbounded = true;
+                else sp.input_lookback = std::max(sp.input_lookback, lm + in.d_lo);
+            }
+        }
+    }
+    for (auto &kv : P.bank_of) sp.input_lookback = std::max(sp.input_lookback, L[kv.first]);
+    if (!sp.pull_rows.empty()) sp.input_lookback_unbounded = true;
+
     // rings
     std::unordered_map<uint32_t, uint32_t> ring_of;
     std::vector<uint32_t> ring_nodes(needs_ring.begin(), needs_ring.end());

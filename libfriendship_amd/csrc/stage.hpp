@@ -73,6 +73,11 @@ struct StagedPlan {
     uint64_t fused_max_frames = 0;
     uint32_t n_rings = 0;
     uint64_t lmax = 0;                     // deepest look-back any ring must serve
+    // How far back in the INPUT history the staged part can read when it computes frame t (ring look-backs + the delays
+    // of inputs on top of them: constant amounts and proven bounds); `input_lookback_unbounded`: some read has no bound
+    // (an input delayed by an unbounded signal, or rows left to the pull interpreter).  fr_config.history_frames.
+    uint64_t input_lookback = 0;
+    bool input_lookback_unbounded = false;
     std::vector<uint32_t> input_slots;     // dense input index used by programs -> external slot
     std::vector<uint32_t> pull_rows;       // output rows left to the pull interpreter
     bool uses_rings() const { return n_rings != 0; }

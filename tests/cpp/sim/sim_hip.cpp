@@ -15,7 +15,7 @@ struct ihipEvent_t { std::chrono::steady_clock::time_point t; };
 
 extern "C" {
 
-std::atomic<uint64_t> fr_sim_live_bytes{0};     // (device allocations are not tracked by size; kept for symmetry)
+static std::atomic<uint64_t> fr_sim_live_bytes_v{0};
 std::atomic<uint64_t> fr_sim_allocs{0}, fr_sim_frees{0};
 
 const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : (e == hipErrorOutOfMemory ? "out of memory" : "simulated HIP error"); }
@@ -28,14 +28,26 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     std::strcpy(p->gcnArchName, "gfx950:sim");
     return hipSuccess;
 }
+// every block is prefixed by its size so that live bytes can be tracked
 hipError_t hipMalloc(void **p, size_t n) {
-    *p = std::malloc(n ? n : 1);
-    if (!*p) return hipErrorOutOfMemory;
+    char *raw = (char *)std::malloc((n ? n : 1) + 16);
+    if (!raw) return hipErrorOutOfMemory;
+    *(size_t *)raw = n;
+    *p = raw + 16;
     std::memset(*p, 0xA5, n);   // uninitialised device memory is not zero: make a read of it show
     ++fr_sim_allocs;
+    fr_sim_live_bytes_v += n;
     return hipSuccess;
 }
-hipError_t hipFree(void *p) { if (p) ++fr_sim_frees; std::free(p); return hipSuccess; }
+hipError_t hipFree(void *p) {
+    if (!p) return hipSuccess;
+    char *raw = (char *)p - 16;
+    fr_sim_live_bytes_v -= *(size_t *)raw;
+    ++fr_sim_frees;
+    std::free(raw);
+    return hipSuccess;
+}
+uint64_t fr_sim_live_bytes(void) { return fr_sim_live_bytes_v.load(); }
 hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
 hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }

@@ -212,6 +212,12 @@ hipError_t launch_shard_combine(const ShardCombineArgs &a, hipStream_t) {
 
 // ---- no hipRTC in the simulator: plans fall back to the hand-written kernels' forms / interpreted programs --------------
 JitKernel::~JitKernel() {}
+struct JitCache::Impl {};
+JitCache::JitCache() : impl_(nullptr) {}
+JitCache::~JitCache() {}
+uint64_t JitCache::epoch() const { return 0; }
+size_t JitCache::compiled() const { return 0; }
+double JitCache::compile_ms() const { return 0; }
 std::shared_ptr<JitKernel> JitCache::get(const LeafShape &, const std::vector<bool> &, const std::vector<uint32_t> &, const std::vector<uint32_t> &) {
     throw Error(FR_ERR_DEVICE, "jit: not available in the host-logic simulator");
 }

@@ -469,6 +469,42 @@ def test_short_call_kernel_against_oracle(hip_lib, oracle_lib):
             idx += len(row)
 
 
+def test_bounded_input_history(hip_lib, oracle_lib):
+    """fr_config.history_frames on the device (the host-logic form is tests/test_sim_engine.py)."""
+    import test_sim_engine
+    test_sim_engine.test_bounded_input_history(hip_lib, oracle_lib)
+
+
+def test_ten_million_frames_in_bounded_memory(hip_lib):
+    """10^7 frames (3.5 minutes of audio) through the device entry point with history_frames set: device memory in use
+    stops growing after the first calls; with the reference's unbounded history it grows by 4 bytes per frame and slot."""
+    import torch
+    T = 50000
+
+    def run(history_frames):
+        with Renderer(hip_lib, history_frames=history_frames) as r:
+            r.on_add_node(1, "F32Constant")
+            r.on_add_node(2, "Delay")
+            r.on_add_edge(0, 2, 0, 0)
+            r.on_add_edge(1, 2, f32_bits(100.0), 1)
+            r.on_add_edge(2, 0, 0, 0)
+            d_row = torch.arange(T, dtype=torch.float32, device="cuda")
+            d_out = torch.empty((1, T), dtype=torch.float32, device="cuda")
+            stream = torch.cuda.current_stream().cuda_stream
+            free_at = {}
+            for k in range(200):
+                r.fill_buffer_device(d_out.data_ptr(), 1, T, k * T, d_row.data_ptr(), [0, T], stream)
+                if k in (10, 199):
+                    torch.cuda.synchronize()
+                    free_at[k] = torch.cuda.mem_get_info()[0]
+            out = d_out.cpu().numpy()
+            assert out[0, 100] == 0.0 and out[0, 99] == T - 1 and out[0, 150] == 50.0
+            return free_at[10] - free_at[199]
+
+    assert run(48000) < (4 << 20)          # bounded: nothing more after the first calls
+    assert run(0) > (30 << 20)             # the reference's behaviour: ~38 MB more for 9.5 M further frames
+
+
 def test_rccl_is_loadable_and_hands_out_an_id(hip_lib):
     """fr_comm_unique_id = ncclGetUniqueId through the engine's lazily loaded RCCL (one rank cannot exercise more)."""
     a, b = hip_lib.comm_unique_id(), hip_lib.comm_unique_id()
@@ -1111,6 +1147,41 @@ def test_jit_specialised_voices(hip_lib, oracle_lib, V, P, T, am, delayed):
         assert plan["pull_rows"] == 0 and plan["jit_kernels_compiled"] == 1, plan
         jb = [b for b in plan["banks"] if b["jit"]]   # (voices that feed a ring launch separately from direct ones)
         assert sum(b["voices"] for b in jb) == V and all(b["partials"] == P and b["leaf_params"] == 2 for b in jb), plan
+
+
+def test_jit_compiles_in_the_background(hip_lib, oracle_lib):
+    """The ABI's default: hipRTC runs on a worker thread.  The first calls are served without the specialised kernel
+    (plan says jit_pending), never waiting ~0.1 s for the compiler; once it is ready the plan switches over.  Same bits
+    all along, delay lines behind the voices included (the switch rebuilds their look-back)."""
+    import time
+    V, P, T = 3, 64, 96
+    tree = _triangle_tree(V, P, False, True)
+    n_out = tree["n_outputs"]
+    rng = np.random.default_rng(1)
+    with Renderer(hip_lib, sync_compile=False) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        seen_pending = seen_jit = False
+        t_first = None
+        for k in range(400):
+            rows = [synth.time_ramp(k * T, (k + 1) * T), (rng.normal(size=T) * 2).astype(np.float32)]
+            t0 = time.perf_counter()
+            got = hip.fill_buffer(n_out, k * T, (k + 1) * T, rows)
+            if k == 0:
+                t_first = time.perf_counter() - t0
+            exp = ref.fill_buffer(n_out, k * T, (k + 1) * T, rows)
+            assert same_bits(got, exp), f"call {k}: " + first_diff(got, exp)
+            plan = hip.plan()
+            if plan["jit_pending"]:
+                seen_pending = True
+                assert not any(b["jit"] for b in plan["banks"])
+            elif any(b["jit"] for b in plan["banks"]):
+                seen_jit = True
+                if k > 20:
+                    break
+            time.sleep(0.002)
+        assert seen_pending and seen_jit, plan
+        assert plan["jit_kernels_compiled"] >= 1
 
 
 def test_jit_voices_unusual_time_inputs(hip_lib, oracle_lib):

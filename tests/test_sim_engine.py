@@ -198,3 +198,82 @@ def test_host_entry_point_two_interleaved_banks(sim, oracle_lib):
                 tt = t[c:c + 1] if c < rl else t[-1:]
                 exp = ref.fill_buffer(16, k * T + c, k * T + c + 1, [tt])
                 assert same_bits(got[:, c:c + 1], exp), f"call {k} frame {c}"
+
+
+def test_bounded_input_history(sim, oracle_lib):
+    """fr_config.history_frames: the input history slides in a buffer of fixed size instead of growing for ever.  Within
+    the cap (rounded up to what the plan's delays need) results equal the reference's; a Delay added later that reaches
+    further back than the cap reads 0.0 there -- what the reference returns for times before a seek point."""
+    T = 500
+    with Renderer(sim, history_frames=1000) as r, Renderer(sim) as full, Renderer(oracle_lib) as ref:
+        for x in (r, full, ref):
+            x.on_add_node(1, "F32Constant")
+            x.on_add_node(2, "Delay")      # in0 delayed by 1800 frames: more than the cap, so the cap is raised to it
+            x.on_add_node(3, "Sum2")
+            x.on_add_edge(0, 2, 0, 0)
+            x.on_add_edge(1, 2, f32_bits(1800.0), 1)
+            x.on_add_edge(2, 3, 0, 0)
+            x.on_add_edge(0, 3, 1, 1)
+            x.on_add_edge(3, 0, 0, 0)
+        rng = np.random.default_rng(4)
+        hist = []
+        for k in range(40):
+            rows = [rng.normal(size=T).astype(np.float32), rng.normal(size=T).astype(np.float32)]
+            hist.append(rows[0])
+            exp = ref.fill_buffer(1, k * T, (k + 1) * T, rows)
+            assert same_bits(r.fill_buffer(1, k * T, (k + 1) * T, rows), exp), f"call {k}"
+            assert same_bits(full.fill_buffer(1, k * T, (k + 1) * T, rows), exp)
+        plan = r.plan()
+        assert plan["history_frames"] == 1000 and plan["input_lookback"] == 1800 and not plan["input_lookback_unbounded"], plan
+        # a longer Delay arrives: 6000 frames back.  The unbounded renderers still hold those samples; the capped one kept
+        # 1800 (+ slack up to its buffer), so its output is 0 wherever t - 6000 is older than what it holds
+        for x in (r, full, ref):
+            x.on_add_node(4, "Delay")
+            x.on_add_edge(0, 4, 0, 0)
+            x.on_add_edge(1, 4, f32_bits(6000.0), 1)
+            x.on_add_edge(4, 0, 0, 1)
+        k = 40
+        rows = [rng.normal(size=T).astype(np.float32), rng.normal(size=T).astype(np.float32)]
+        exp = ref.fill_buffer(2, k * T, (k + 1) * T, rows)
+        assert same_bits(full.fill_buffer(2, k * T, (k + 1) * T, rows), exp)
+        got = r.fill_buffer(2, k * T, (k + 1) * T, rows)
+        assert same_bits(got[0], exp[0])                       # the old delay is served as before
+        mism = got[1] != exp[1]
+        assert mism.any() and not got[1][mism].any()           # where it differs from the reference it is exactly 0.0
+        # from now on the cap follows the new plan (6000): after 6000 more frames everything matches again
+        for k in range(41, 41 + 14):
+            rows = [rng.normal(size=T).astype(np.float32), rng.normal(size=T).astype(np.float32)]
+            exp = ref.fill_buffer(2, k * T, (k + 1) * T, rows)
+            got = r.fill_buffer(2, k * T, (k + 1) * T, rows)
+        assert same_bits(got, exp)
+        # a seek backwards: the floor must not hide the new samples
+        rows = [rng.normal(size=T).astype(np.float32), rng.normal(size=T).astype(np.float32)]
+        assert same_bits(r.fill_buffer(2, 100, 100 + T, rows), ref.fill_buffer(2, 100, 100 + T, rows))
+        rows = [rng.normal(size=T).astype(np.float32), rng.normal(size=T).astype(np.float32)]
+        assert same_bits(r.fill_buffer(2, 100 + T, 100 + 2 * T, rows), ref.fill_buffer(2, 100 + T, 100 + 2 * T, rows))
+
+
+def test_ten_million_frames_in_bounded_memory(sim):
+    """10^7 frames through a renderer with history_frames set: device allocations stop after the first calls (the history
+    slides in place), where the unbounded default keeps 40 MB per fed slot by then."""
+    import ctypes
+    sim.lib.fr_sim_live_bytes.restype = ctypes.c_uint64
+    T = 50000
+    with Renderer(sim, history_frames=48000) as r:
+        r.on_add_node(1, "F32Constant")
+        r.on_add_node(2, "Delay")
+        r.on_add_edge(0, 2, 0, 0)
+        r.on_add_edge(1, 2, f32_bits(100.0), 1)
+        r.on_add_edge(2, 0, 0, 0)
+        row = np.arange(T, dtype=np.float32)
+        out = np.zeros((1, T), np.float32)
+        allocs = ctypes.c_uint64.in_dll(sim.lib, "fr_sim_allocs")
+        peak = 0
+        for k in range(200):   # 200 x 50 000 = 10^7 frames
+            r.fill_buffer(1, k * T, (k + 1) * T, [row], out=out)
+            if k == 5:
+                settled = allocs.value
+            peak = max(peak, sim.lib.fr_sim_live_bytes())
+            assert out[0, 100] == row[0] and out[0, 99] == (row[T - 1] if k else 0.0)
+        assert allocs.value == settled, "device allocations kept happening"
+        assert peak < 4 * (2 * (48000 + T) * 4) + (1 << 20), peak   # history buffer + output + slack; not 40 MB
