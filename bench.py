@@ -194,7 +194,9 @@ def run():
         f"installed in {time.perf_counter() - t_build:.1f}s")
 
     transport = "none"
-    if world > 1 and shard_mode in ("voices", "partials"):
+    if world > 1 and shard_mode == "voices":
+        hip.set_shard(rank, world, "voices")     # no exchange in this mode: no transport, no communicator
+    elif world > 1 and shard_mode == "partials":
         if args.backend == "nccl":
             # the engine's own communicator: rank 0 draws the id, torch.distributed carries the 128 bytes
             idt = torch.zeros(128, dtype=torch.uint8, device="cuda")

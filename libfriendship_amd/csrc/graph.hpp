@@ -14,7 +14,9 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <deque>
+#include <new>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -27,11 +29,16 @@ namespace fr {
 
 // Open-addressing hash map, u64 -> u64 (linear probing, power-of-two capacity).  Lowering a multi-million-node
 // graph is dominated by hash lookups; this is ~3x faster than the node-based std::unordered_map for that use.
+// Growth never stalls a caller: the table of twice the size comes from calloc (pages are touched lazily) and the old
+// one is emptied into it a few slots per insertion, lookups consulting both meanwhile -- a doubling at 1.3 M nodes used
+// to be a 0.1 s pause inside a fill_buffer call that followed a graph edit.
 class FlatMap64 {
-    static constexpr uint64_t EMPTY = ~0ull;   // keys must not be ~0
-    struct Slot { uint64_t key, val; };        // key and value share a cache line: one miss per probe
-    std::vector<Slot> slots_;
-    size_t n_ = 0, mask_ = 0;
+    struct Slot { uint64_t key1, val; };       // key1 = key + 1, 0 = empty (keys must not be ~0); one cache line per probe
+    Slot *slots_ = nullptr;
+    size_t cap_ = 0, mask_ = 0, n_ = 0;        // n_: distinct keys, wherever they currently live
+    Slot *old_ = nullptr;                      // previous table, being migrated from old_pos_ on
+    size_t old_cap_ = 0, old_pos_ = 0;
+    static constexpr size_t MIGRATE_PER_INSERT = 16;
     // Groups of 16 consecutive keys stay adjacent (a few cache lines) and the groups are scattered by a full
     // mix: handles and node ids are mostly consecutive, so this keeps lowering cache-friendly without the long runs
     // that make linear probing degenerate under an identity hash.
@@ -40,44 +47,118 @@ class FlatMap64 {
         g ^= g >> 33; g *= 0xff51afd7ed558ccdULL; g ^= g >> 33; g *= 0xc4ceb9fe1a85ec53ULL; g ^= g >> 33;
         return (g << 4) | (k & 15u);
     }
-    void grow() {
-        std::vector<Slot> old = std::move(slots_);
-        size_t cap = old.empty() ? 64 : old.size() * 2;
-        slots_.assign(cap, Slot{EMPTY, 0});
-        mask_ = cap - 1;
-        n_ = 0;
-        for (const Slot &s : old)
-            if (s.key != EMPTY) *slot(s.key) = s.val;
+    static Slot *alloc(size_t cap) {
+        Slot *p = (Slot *)std::calloc(cap, sizeof(Slot));
+        if (!p) throw std::bad_alloc();
+        return p;
     }
-    uint64_t *slot(uint64_t k) {   // existing or fresh slot for k (capacity must allow it)
-        size_t i = hash(k) & mask_;
-        while (slots_[i].key != EMPTY && slots_[i].key != k) i = (i + 1) & mask_;
-        if (slots_[i].key == EMPTY) { slots_[i].key = k; ++n_; }
-        return &slots_[i].val;
+    static Slot *probe(Slot *t, size_t mask, uint64_t k) {   // the slot holding k, or the empty slot where it would go
+        size_t i = hash(k) & mask;
+        while (t[i].key1 != 0 && t[i].key1 != k + 1) i = (i + 1) & mask;
+        return &t[i];
+    }
+    void migrate(size_t steps) {
+        while (old_ && steps) {
+            if (old_pos_ == old_cap_) {
+                std::free(old_);
+                old_ = nullptr;
+                old_cap_ = old_pos_ = 0;
+                return;
+            }
+            const Slot &o = old_[old_pos_++];
+            if (o.key1 == 0) continue;
+            --steps;
+            Slot *s = probe(slots_, mask_, o.key1 - 1);
+            if (s->key1 == 0) { s->key1 = o.key1; s->val = o.val; }   // (else: already moved by a lookup)
+        }
+    }
+    void grow() {
+        migrate(~(size_t)0);                   // at most one table in migration (it finished long ago unless reserve() hurried)
+        old_ = slots_;
+        old_cap_ = cap_;
+        old_pos_ = 0;
+        cap_ = cap_ ? cap_ * 2 : 64;
+        mask_ = cap_ - 1;
+        slots_ = alloc(cap_);
+        if (!old_cap_) { old_ = nullptr; }
+    }
+    void copy_from(const FlatMap64 &o) {
+        if (!o.cap_) return;
+        cap_ = o.cap_;
+        mask_ = cap_ - 1;
+        slots_ = alloc(cap_);
+        auto put = [&](const Slot &e) {
+            if (e.key1 == 0) return;
+            Slot *s = probe(slots_, mask_, e.key1 - 1);
+            if (s->key1 == 0) { *s = e; ++n_; }
+        };
+        for (size_t i = 0; i < o.cap_; ++i) put(o.slots_[i]);
+        for (size_t i = o.old_pos_; i < o.old_cap_; ++i) put(o.old_[i]);
+    }
+    void steal(FlatMap64 &o) {
+        slots_ = o.slots_; cap_ = o.cap_; mask_ = o.mask_; n_ = o.n_; old_ = o.old_; old_cap_ = o.old_cap_; old_pos_ = o.old_pos_;
+        o.slots_ = o.old_ = nullptr;
+        o.cap_ = o.mask_ = o.n_ = o.old_cap_ = o.old_pos_ = 0;
     }
 
 public:
+    FlatMap64() = default;
+    FlatMap64(const FlatMap64 &o) { copy_from(o); }
+    FlatMap64(FlatMap64 &&o) noexcept { steal(o); }
+    FlatMap64 &operator=(const FlatMap64 &o) {
+        if (this != &o) { clear(); copy_from(o); }
+        return *this;
+    }
+    FlatMap64 &operator=(FlatMap64 &&o) noexcept {
+        if (this != &o) { clear(); steal(o); }
+        return *this;
+    }
+    ~FlatMap64() { clear(); }
     size_t size() const { return n_; }
-    void reserve(size_t n) { while (slots_.size() * 3 < n * 4 + 4) grow(); }
+    void reserve(size_t n) {                   // bulk loads: size once, up front
+        while (cap_ * 3 < n * 4 + 4) grow();
+        migrate(~(size_t)0);
+    }
     const uint64_t *find(uint64_t k) const {
-        if (slots_.empty()) return nullptr;
-        size_t i = hash(k) & mask_;
-        while (slots_[i].key != EMPTY) {
-            if (slots_[i].key == k) return &slots_[i].val;
-            i = (i + 1) & mask_;
+        if (!cap_) return nullptr;
+        const Slot *s = probe(slots_, mask_, k);
+        if (s->key1) return &s->val;
+        if (old_) {
+            const Slot *o = probe(old_, old_cap_ - 1, k);
+            if (o->key1) return &o->val;
         }
         return nullptr;
     }
-    uint64_t *find(uint64_t k) { return const_cast<uint64_t *>(static_cast<const FlatMap64 *>(this)->find(k)); }
+    // mutable lookup: an entry still in the old table is moved first, so the pointer stays good until the next grow
+    uint64_t *find(uint64_t k) {
+        if (!cap_) return nullptr;
+        Slot *s = probe(slots_, mask_, k);
+        if (s->key1) return &s->val;
+        if (old_) {
+            const Slot *o = probe(old_, old_cap_ - 1, k);
+            if (o->key1) { s->key1 = o->key1; s->val = o->val; return &s->val; }
+        }
+        return nullptr;
+    }
     // value slot for k, inserted as 0 if absent; `inserted` tells which
     uint64_t &get(uint64_t k, bool *inserted = nullptr) {
-        if ((n_ + 1) * 4 > slots_.size() * 3) grow();
-        size_t before = n_;
-        uint64_t *v = slot(k);
-        if (inserted) *inserted = n_ != before;
-        return *v;
+        if ((n_ + 1) * 4 > cap_ * 3) grow();
+        migrate(MIGRATE_PER_INSERT);
+        if (inserted) *inserted = false;
+        if (uint64_t *v = find(k)) return *v;
+        Slot *s = probe(slots_, mask_, k);
+        s->key1 = k + 1;
+        s->val = 0;
+        ++n_;
+        if (inserted) *inserted = true;
+        return s->val;
     }
-    void clear() { slots_.clear(); n_ = 0; mask_ = 0; }
+    void clear() {
+        std::free(slots_);
+        std::free(old_);
+        slots_ = old_ = nullptr;
+        cap_ = mask_ = n_ = old_cap_ = old_pos_ = 0;
+    }
 };
 
 struct Error : std::runtime_error {

@@ -243,7 +243,11 @@ __device__ __forceinline__ void bank_group(const ParamGroup &pg, uint32_t g,
     for (int f = 0; f < F; ++f) s8[f] = v[f];
 }
 
-template <int F, bool FAST, bool EXACT>
+// DEEP: two parameter groups fetched ahead instead of one (a PAIR of groups loaded while the previous pair is summed).
+// Built for launches that leave a SIMD only a few waves to hide a scalar load behind -- and measured SLOWER everywhere
+// (64 x 4096: T = 64 7.5 -> 8.4 us, 256 10.6 -> 13.3, 512 17.8 -> 20.1, 1024 29.3 -> 33.0; profiles/r02_short_calls.txt):
+// the 32 extra SGPRs take the kernels to the register limit.  Kept as an option for A/B runs only.
+template <int F, bool FAST, bool EXACT, bool DEEP = false>
 __device__ __forceinline__ void bank_wave_sum(const float *params, uint32_t ngroups, uint32_t levels,
                                               const float (&t)[F], float (&res)[F]) {
     float s0[F], s1[F], s2[F], s3[F], s4[F], s5[F], s6[F], s7[F], s8[F];
@@ -252,6 +256,25 @@ __device__ __forceinline__ void bank_wave_sum(const float *params, uint32_t ngro
         s0[f] = s1[f] = s2[f] = s3[f] = s4[f] = s5[f] = s6[f] = s7[f] = s8[f] = 0.0f;
 
     const_f32_ptr p = (const_f32_ptr)params;
+    if (DEEP && ngroups >= 4u) {   // (ngroups is a power of two)
+        ParamGroup pa, pb, pc, pd;
+        load_group(pa, p, 0);
+        load_group(pb, p, 1);
+        for (uint32_t g = 0; g < ngroups; g += 4) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // pa, pb have landed
+            load_group(pc, p, g + 2);
+            load_group(pd, p, g + 3);
+            bank_group<F, FAST, EXACT>(pa, g, t, FR_LEVELS_PASS);
+            bank_group<F, FAST, EXACT>(pb, g + 1, t, FR_LEVELS_PASS);
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // pc, pd have landed
+            if (g + 4 < ngroups) {
+                load_group(pa, p, g + 4);
+                load_group(pb, p, g + 5);
+            }
+            bank_group<F, FAST, EXACT>(pc, g + 2, t, FR_LEVELS_PASS);
+            bank_group<F, FAST, EXACT>(pd, g + 3, t, FR_LEVELS_PASS);
+        }
+    } else {
     // two parameter groups in flight: the scalar load of group g+1 is issued before group g's math
     ParamGroup pa, pb;
     load_group(pa, p, 0);
@@ -267,6 +290,7 @@ __device__ __forceinline__ void bank_wave_sum(const float *params, uint32_t ngro
             if (g + 2 < ngroups) load_group(pa, p, g + 2);
             bank_group<F, FAST, EXACT>(pb, g + 1, t, FR_LEVELS_PASS);
         }
+    }
     }
     // after the last group (all ones) the carry chain stopped at level `levels`
 #pragma unroll
@@ -758,15 +782,24 @@ void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &
         // time-major one: T <= 64: 7.4 vs 11.2; 128: 8.3 vs 11.4; 256: 10.6 vs 11.6; 512: 19.5 vs 17.8 -- hence pairs <= 320.
         // 512 or 1024 workgroups (more, smaller chunks) cost 2-3 us more in ticket traffic; 8 waves +0.3 us, 4 waves +2.4.
         const uint64_t pairs = ((n_times + 63) / 64) * n_voices;
-        if (short_kernel_enabled() && pairs <= 320 && log2_p >= 9 && log2_p <= 20 && pairs > 0) {
-            static const uint64_t target = [] { const char *e = std::getenv("FR_SHORT_WGS"); return e ? (uint64_t)std::atoi(e) : 256ull; }();
-            static const uint32_t nw = [] { const char *e = std::getenv("FR_SHORT_NW"); return e ? (uint32_t)std::atoi(e) : 16u; }();
+        static const uint64_t max_pairs = [] { const char *e = std::getenv("FR_SHORT_PAIRS"); return e ? (uint64_t)std::atoi(e) : 1000ull; }();
+        if (short_kernel_enabled() && pairs <= max_pairs && log2_p >= 9 && log2_p <= 20 && pairs > 0) {
+            // up to 320 pairs: ~256 workgroups of 16 waves; up to 1000 (a GPU's share of a voice-sharded job: 8 voices x 75
+            // tiles): ~1200 workgroups of 8 waves -- 600 one-voice workgroups deal 2 or 3 to a CU (28 % idle), twice as
+            // many half as long deal 4 or 5 (24.2 -> 21.9 us at 8 x 4096 x 4800; profiles/r02_short_calls.txt)
+            const bool few = pairs <= 320;
+            // (only where whole workgroups deal unevenly over the 256 CUs: 512 pairs are 2 per CU, and splitting them costs
+            //  4 us of ticket traffic for nothing -- 17.7 -> 22.0 us at 64 x 4096 x 512)
+            const bool lumpy = ((pairs + 255) / 256) * 256 * 100 >= pairs * 115;
+            static const uint64_t target_env = [] { const char *e = std::getenv("FR_SHORT_WGS"); return e ? (uint64_t)std::atoi(e) : 0ull; }();
+            static const uint32_t nw_env = [] { const char *e = std::getenv("FR_SHORT_NW"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+            const uint64_t target = target_env ? target_env : (few ? 256ull : 1200ull);
             uint32_t c = log2_p;
             uint64_t wgs = pairs;
             while (c > 9 && (wgs < target || c > 13)) { --c; wgs *= 2; }
-            if (log2_p - c <= 8) {
+            if (log2_p - c <= 8 && (few || (lumpy && c != log2_p))) {
                 chunk_log2 = c;
-                waves_per_group = nw;
+                waves_per_group = nw_env ? nw_env : (few ? 16u : 8u);
                 while ((1u << c) / waves_per_group < 8u) waves_per_group /= 2;   // a wave needs a whole group of 8
                 small_call = 2;
                 return;
