@@ -675,7 +675,7 @@ struct fr_renderer {
             HIP_CHECK(hipMemcpyAsync(p.d_instrs.p, p.sp.instrs.data(), p.sp.instrs.size() * sizeof(StageInstr), hipMemcpyHostToDevice, st));
             HIP_CHECK(hipMemcpyAsync(p.d_progs.p, p.sp.progs.data(), p.sp.progs.size() * sizeof(StageProg), hipMemcpyHostToDevice, st));
             StageJitPlan sj;
-            if (allow_jit && stage_jit_mode != 0 && plan_stage_jit(p.sp.progs, p.sp.instrs, 32, stage_jit_mode == 2, sj)) {
+            if (allow_jit && stage_jit_mode != 0 && plan_stage_jit(p.sp.progs, p.sp.instrs, 32, stage_jit_mode == 2, sj, mirror.sparkle)) {
                 try {
                     p.stage_jit = jit_cache.get_source(sj.source, "jit_stage");
                     if (!p.stage_jit) {   // still compiling: the interpreter serves the calls until the plan is rebuilt
@@ -957,6 +957,7 @@ struct fr_renderer {
                     a.idx = idx;
                     a.w0 = s0;
                     a.w_len = slen;
+                    a.sparkle = mirror.sparkle ? 1u : 0u;
                     Scope sc(this, &t_stage, st);
                     HIP_CHECK(launch_stage(a, st));
                     sc.done();
@@ -1015,6 +1016,7 @@ struct fr_renderer {
                 a.idx = idx;
                 a.first = first + off;
                 a.count = cnt;
+                a.sparkle = mirror.sparkle ? 1u : 0u;
                 a.st_node = d_stack_node.as<uint32_t>();
                 a.st_time = d_stack_time.as<uint64_t>();
                 a.st_val = d_stack_val.as<float>();
@@ -1084,6 +1086,8 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     r->device = dev;
     r->mode = mode;
     r->jit_cache.set_async(!(cfg && (cfg->flags & FR_CONFIG_SYNC_COMPILE)));
+    r->jit_cache.set_sparkle(cfg && cfg->semantics == FR_SEMANTICS_SPARKLE);
+    r->mirror.sparkle = cfg && cfg->semantics == FR_SEMANTICS_SPARKLE;
     r->semantics = cfg ? cfg->semantics : FR_SEMANTICS_REFERENCE;
     r->history_frames = cfg ? cfg->history_frames : 0;
     if (const char *lv = std::getenv("FR_BANK_LEAF")) r->bank_leaf_variant = (lv[0] == '1') ? 1u : 0u;

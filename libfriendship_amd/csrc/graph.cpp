@@ -170,7 +170,7 @@ void Mirror::del_edge(const fr_edge &e) {  // reference.rs:127-136
 
 // Same arithmetic as the device code and as reference.rs:221-262; this file is compiled with
 // -ffp-contract=off so every operation rounds once.
-float host_binop(FlatOp op, float a, float b) {
+float host_binop(FlatOp op, float a, float b, bool sparkle) {
     switch (op) {
     case OP_SUM2: return a + b;
     case OP_MUL: return a * b;
@@ -179,7 +179,9 @@ float host_binop(FlatOp op, float a, float b) {
         float rem = std::fmod(a, b);
         return rem < 0.0f ? rem + b : rem;
     }
-    case OP_MIN: return (a < b || b != b) ? a : b;  // Rust >= 1.20 f32::min
+    case OP_MIN:
+        if (sparkle && a != a) return a;             // select(fcmp ult a, b, a, b), sparkle.rs:495-496: a NaN on the left wins
+        return (a < b || b != b) ? a : b;            // Rust >= 1.20 f32::min
     default: return 0.0f;
     }
 }
@@ -219,11 +221,12 @@ uint32_t FlatGraph::make(FlatOp op, uint32_t a, uint32_t b) {
         if (is_const(b)) {
             float d = const_val(b);
             if (d >= 18446744073709551616.0f) return konst(0);
+            if (sparkle && !(d >= 0.0f)) return konst(0);     // sparkle.rs:531-534: amount `ult 0` (negative, NaN) -> 0.0
             uint64_t di = (d < 0.0f || d != d) ? 0 : (uint64_t)d;
             if (di == 0) return a;
         }
     } else {
-        if (is_const(a) && is_const(b)) return konst(f32_to_bits(host_binop(op, const_val(a), const_val(b))));
+        if (is_const(a) && is_const(b)) return konst(f32_to_bits(host_binop(op, const_val(a), const_val(b), sparkle)));
         // a+b and a*b are bitwise commutative up to NaN payload, which is outside the contract.
         if ((op == OP_SUM2 || op == OP_MUL) && a > b) std::swap(a, b);
     }
@@ -302,6 +305,7 @@ struct Lowering::Impl {
     void reset(const Mirror &mm) {
         m = &mm;
         fg = FlatGraph();
+        fg.sparkle = mm.sparkle;
         ctxs.clear();
         ctxs.push_back(Ctx{-1, nullptr, nullptr});
         child_ctx.clear();

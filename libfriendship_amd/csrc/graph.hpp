@@ -275,6 +275,7 @@ public:
     NodeTable nodes;
     std::vector<EdgeRef> outputs;
     uint64_t version = 0;                        // bumped by every edit
+    bool sparkle = false;                        // FR_SEMANTICS_SPARKLE: Minimum and Delay as SparkleRenderer computes them
 
     // Edit journal for incremental lowering (class Lowering).  While `journal_on`, every edit appends the dense
     // position of the top-level node it touched (| JOURNAL_NODE when the node itself was added, replaced or deleted).
@@ -316,6 +317,7 @@ struct FlatGraph {
     std::vector<uint32_t> outputs;     // per rendered slot, a node id
     uint32_t max_depth = 0;
     uint32_t max_input_slot = 0;       // highest OP_INPUT slot referenced (valid if has_input)
+    bool sparkle = false;              // FR_SEMANTICS_SPARKLE (constant folding here, range analysis, kernels)
     bool has_input = false;
     uint64_t n_mirror_nodes_visited = 0;
 
@@ -369,7 +371,7 @@ FlatGraph lower(const Mirror &m, uint32_t n_slots);
 
 // Exactly-rounded host evaluation of one primitive (same semantics as the device code and as
 // reference.rs:197-262); used for constant folding.
-float host_binop(FlatOp op, float a, float b);
+float host_binop(FlatOp op, float a, float b, bool sparkle = false);
 float f32_from_bits(uint32_t b);
 uint32_t f32_to_bits(float f);
 

@@ -128,8 +128,8 @@ extern "C" __global__ void __launch_bounds__(256) jit_bank_multi(JitBankArgs a) 
 )JIT";
 
 std::string JitCache::generate_source(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
-                                      const std::vector<uint32_t> &alias) {
-    LeafSource ls = generate_leaf_source(shape, varying, literal_bits, alias);
+                                      const std::vector<uint32_t> &alias, bool sparkle) {
+    LeafSource ls = generate_leaf_source(shape, varying, literal_bits, alias, sparkle);
     std::ostringstream call;
     call << "leaf<FAST>(x";
     for (uint32_t i = 0; i < ls.k; ++i) call << ", c[(j) * K + " << i << "]";
@@ -177,7 +177,7 @@ double JitCache::compile_ms() const { std::lock_guard<std::mutex> g(impl_->mu); 
 
 std::shared_ptr<JitKernel> JitCache::get(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
                                          const std::vector<uint32_t> &alias) {
-    std::shared_ptr<JitKernel> jk = get_source(generate_source(shape, varying, literal_bits, alias), "jit_bank");
+    std::shared_ptr<JitKernel> jk = get_source(generate_source(shape, varying, literal_bits, alias, sparkle_), "jit_bank");
     if (jk && !jk->k)
         for (size_t c = 0; c < varying.size(); ++c) jk->k += (varying[c] && alias[c] == c) ? 1 : 0;
     return jk;

@@ -81,7 +81,7 @@ struct StageJitPlan {
 // Groups the programs by skeleton and writes the kernel source.  Returns false when specialisation is not worth a
 // compile: more than `max_shapes` skeletons, or (unless `force`) fewer than 4 programs per skeleton on average.
 bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<StageInstr> &instrs, uint32_t max_shapes, bool force,
-                    StageJitPlan &out);
+                    StageJitPlan &out, bool sparkle = false);
 
 // Text of `template <bool FAST> float leaf(const float *x, float p0, ...)` for one leaf shape, preceded by the helper
 // functions it calls.  FAST = the body in which Modulo(x, 1.0) is one v_fract_f32 (valid under the conditions of
@@ -93,7 +93,7 @@ struct LeafSource {
     uint32_t fract_inputs = 0;   // mask of the inputs its arguments depend on
 };
 LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
-                                const std::vector<uint32_t> &alias);
+                                const std::vector<uint32_t> &alias, bool sparkle = false);
 
 // One compiled specialisation.
 struct JitKernel {
@@ -122,8 +122,9 @@ public:
     // any generated source with one extern "C" kernel `fn_name` (cached by source text)
     std::shared_ptr<JitKernel> get_source(const std::string &src, const char *fn_name);
     static std::string generate_source(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
-                                       const std::vector<uint32_t> &alias);
+                                       const std::vector<uint32_t> &alias, bool sparkle = false);
     void set_async(bool on) { async_ = on; }
+    void set_sparkle(bool on) { sparkle_ = on; }   // FR_SEMANTICS_SPARKLE: baked into the generated leaves
     uint64_t epoch() const;        // bumped whenever a background compile finishes (successfully or not)
     size_t compiled() const;
     double compile_ms() const;
@@ -132,6 +133,7 @@ private:
     struct Impl;
     Impl *impl_;
     bool async_ = true;
+    bool sparkle_ = false;
 };
 
 hipError_t launch_jit_bank(const JitKernel &k, const JitBankArgs &a, hipStream_t s);

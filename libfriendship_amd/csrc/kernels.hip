@@ -23,25 +23,28 @@ __device__ __forceinline__ float prim_mod(float a, float b) {
     return rem < 0.0f ? rem + b : rem;
 }
 
-__device__ __forceinline__ float prim_min(float a, float b) {
-    // Rust >= 1.20 core f32::min: (a < b || b.is_nan()) ? a : b
+__device__ __forceinline__ float prim_min(float a, float b, bool sparkle = false) {
+    // RefRenderer: Rust >= 1.20 core f32::min: (a < b || b.is_nan()) ? a : b.
+    // SparkleRenderer (sparkle.rs:495-496): select(fcmp ult a, b, a, b) -- differs only for a NaN `a` beside a number.
+    if (sparkle && a != a) return a;
     return (a < b || b != b) ? a : b;
 }
 
-__device__ __forceinline__ float prim_binop(uint32_t op, float a, float b) {
+__device__ __forceinline__ float prim_binop(uint32_t op, float a, float b, bool sparkle = false) {
     switch (op) {
     case OP_SUM2: return a + b;
     case OP_MUL: return a * b;
     case OP_DIV: return a / b;   // hipcc default: correctly rounded f32 divide
     case OP_MOD: return prim_mod(a, b);
-    default: return prim_min(a, b);
+    default: return prim_min(a, b, sparkle);
     }
 }
 
-// Delay's amount -> frames (reference.rs:200-211).  Returns false when the output is 0 because the
-// amount is >= 2^64.
-__device__ __forceinline__ bool delay_frames(float d, uint64_t &frames) {
+// Delay's amount -> frames (reference.rs:200-211).  Returns false when the output is 0: the amount is >= 2^64, or --
+// SparkleRenderer only, sparkle.rs:531-534 -- it is negative or NaN (`ult 0`), where RefRenderer delays by 0 frames.
+__device__ __forceinline__ bool delay_frames(float d, uint64_t &frames, bool sparkle = false) {
     if (d >= 18446744073709551616.0f) return false;
+    if (sparkle && !(d >= 0.0f)) return false;
     frames = (d < 0.0f || d != d) ? 0ull : (uint64_t)d;   // clamp negatives, NaN -> 0, floor
     return true;
 }
@@ -99,7 +102,7 @@ __global__ void __launch_bounds__(256) pull_kernel(PullArgs a) {
                 if (n.op == OP_DELAY) {
                     uint64_t frames;
                     --sp;   // tail call: the source's value is the Delay's value
-                    if (!delay_frames(ret, frames) || frames > t) {
+                    if (!delay_frames(ret, frames, a.sparkle != 0u) || frames > t) {
                         ret = 0.0f;   // >= 2^64 or t - frames underflows (reference.rs:202-205,213)
                     } else {
                         cur = n.a;
@@ -114,7 +117,7 @@ __global__ void __launch_bounds__(256) pull_kernel(PullArgs a) {
                     calling = true;
                 }
             } else {
-                ret = prim_binop(n.op, a.st_val[o], ret);
+                ret = prim_binop(n.op, a.st_val[o], ret, a.sparkle != 0u);
                 --sp;
             }
         }
@@ -1255,12 +1258,12 @@ __global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
         case S_MUL: v = tmp[in.a][tid] * tmp[in.b][tid]; break;
         case S_DIV: v = tmp[in.a][tid] / tmp[in.b][tid]; break;
         case S_MOD: v = prim_mod(tmp[in.a][tid], tmp[in.b][tid]); break;
-        case S_MIN: v = prim_min(tmp[in.a][tid], tmp[in.b][tid]); break;
+        case S_MIN: v = prim_min(tmp[in.a][tid], tmp[in.b][tid], a.sparkle != 0u); break;
         case S_STORE: a.rings[(size_t)in.buf * (a.ring_mask + 1) + (t & a.ring_mask)] = tmp[in.a][tid]; continue;
         case S_READ_DYN: case S_READ_INPUT_DYN: case S_STEP_DYN: {   // Delay by a signal amount (reference.rs:200-215)
             uint64_t fr;
             v = 0.0f;
-            if (delay_frames(tmp[in.a][tid], fr) && t >= fr) {
+            if (delay_frames(tmp[in.a][tid], fr, a.sparkle != 0u) && t >= fr) {
                 if (in.op == S_READ_DYN) v = a.rings[(size_t)in.buf * (a.ring_mask + 1) + ((t - fr) & a.ring_mask)];
                 else if (in.op == S_READ_INPUT_DYN) v = stage_input(a, in.imm, t - fr);
                 else v = __uint_as_float(in.imm);

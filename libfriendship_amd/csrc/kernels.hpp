@@ -31,6 +31,7 @@ struct PullArgs {
     uint64_t idx;
     uint64_t first;            // first linear (slot*n_times + t) element of this launch
     uint64_t count;            // elements in this launch
+    uint32_t sparkle;          // FR_SEMANTICS_SPARKLE: Minimum / Delay as SparkleRenderer computes them (kernels.hip prim_min)
     uint32_t *st_node;         // pull stack, [depth][count]
     uint64_t *st_time;
     float *st_val;
@@ -130,6 +131,7 @@ struct StageArgs {
     uint64_t idx;              // first frame of the call
     uint64_t w0;               // first frame of the window computed now (<= idx)
     uint64_t w_len;            // window length
+    uint32_t sparkle;          // FR_SEMANTICS_SPARKLE
 };
 hipError_t launch_stage(const StageArgs &a, hipStream_t s);
 

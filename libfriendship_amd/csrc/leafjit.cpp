@@ -19,13 +19,16 @@ __device__ __forceinline__ float jit_mod1(float a) {           // Modulo(a, 1.0)
     float rem = a - truncf(a);                                  // (inf - inf = NaN, like fmodf); then the same fix-up
     return rem < 0.0f ? rem + 1.0f : rem;
 }
-__device__ __forceinline__ float jit_min(float a, float b) {   // Rust >= 1.20 f32::min
+__device__ __forceinline__ float jit_min(float a, float b) {   // Rust >= 1.20 f32::min; FR_SPARKLE: select(a ult b, a, b)
+#if FR_SPARKLE
+    if (a != a) return a;
+#endif
     return (a < b || b != b) ? a : b;
 }
 )JIT";
 
 LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
-                                const std::vector<uint32_t> &alias) {
+                                const std::vector<uint32_t> &alias, bool sparkle) {
     std::ostringstream leaf;
     uint32_t k = 0;
     std::vector<int> pidx(shape.n_consts, -1);
@@ -102,7 +105,7 @@ LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> 
     out.k = k ? k : 1;
     out.has_mod1 = has_mod1;
     out.fract_inputs = fract_inputs;
-    out.text = std::string(kLeafHelpers) + leaf.str();
+    out.text = std::string(sparkle ? "#define FR_SPARKLE 1\n" : "#define FR_SPARKLE 0\n") + kLeafHelpers + leaf.str();
     return out;
 }
 

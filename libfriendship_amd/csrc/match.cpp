@@ -377,7 +377,7 @@ struct BankMatcher::Impl : Matcher {
             case OP_DIV: nonneg = a.nonneg && b.nonneg && b.r.lo > 0.0; break;
             default: nonneg = a.nonneg && b.r.lo > 0.0 && !b.r.nan; break;   // OP_MOD: fmod keeps the dividend's sign
             }
-            val[i] = Val{Range::combine(o.op, a.r, b.r), nonneg};
+            val[i] = Val{Range::combine(o.op, a.r, b.r, g.sparkle), nonneg};
             const LeafShape::Op &d = vm.shape.ops[o.b];
             if (o.op == OP_MOD && d.op == OP_CONST && !vm.varying[d.a] && first[d.a] == 0x3F800000u) {
                 any = true;

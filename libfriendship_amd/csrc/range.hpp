@@ -29,7 +29,7 @@ struct Range {
         return Range{lo, hi, nan};
     }
     // value range of op(a, b) for the five arithmetic primitives (reference.rs:221-262)
-    static Range combine(uint32_t op, const Range &a, const Range &b) {
+    static Range combine(uint32_t op, const Range &a, const Range &b, bool sparkle = false) {
         const bool nan = a.nan || b.nan;
         switch (op) {
         case OP_SUM2:
@@ -52,7 +52,12 @@ struct Range {
             const double B = std::max(std::fabs(b.lo), std::fabs(b.hi));
             return widened(-2.0 * B, B, may_nan);                         // a non-positive divisor: (-2|b|, |b|)
         }
-        default: {        // Minimum = (a < b || isnan(b)) ? a : b: NaN only if both are; a NaN on one side selects the other side
+        default: {
+            if (sparkle) {   // select(a ult b, a, b): NaN iff a is; a NaN b selects a
+                const double hi = b.nan ? a.hi : std::min(a.hi, b.hi);
+                return Range{std::min(a.lo, b.lo), hi, a.nan};
+            }
+            // Minimum = (a < b || isnan(b)) ? a : b: NaN only if both are; a NaN on one side selects the other side
             double hi = (!a.nan && !b.nan) ? std::min(a.hi, b.hi) : !a.nan ? a.hi : !b.nan ? b.hi : std::max(a.hi, b.hi);
             return Range{std::min(a.lo, b.lo), hi, a.nan && b.nan};
         }

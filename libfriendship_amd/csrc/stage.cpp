@@ -78,7 +78,7 @@ struct Planner {
                 Range s = range_memo[x.a];
                 range_memo[n] = Range{std::min(s.lo, 0.0), std::max(s.hi, 0.0), s.nan};
             } else {
-                range_memo[n] = Range::combine(x.op, range_memo[x.a], range_memo[x.b]);
+                range_memo[n] = Range::combine(x.op, range_memo[x.a], range_memo[x.b], g.sparkle);
             }
             st.pop_back();
         }

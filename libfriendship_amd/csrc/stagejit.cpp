@@ -21,7 +21,10 @@ __device__ __forceinline__ float jit_mod1(float a) {           // Modulo(a, 1.0)
     float rem = a - truncf(a);
     return rem < 0.0f ? rem + 1.0f : rem;
 }
-__device__ __forceinline__ float jit_min(float a, float b) {   // Rust >= 1.20 f32::min
+__device__ __forceinline__ float jit_min(float a, float b) {   // Rust >= 1.20 f32::min; FR_SPARKLE: select(a ult b, a, b)
+#if FR_SPARKLE
+    if (a != a) return a;
+#endif
     return (a < b || b != b) ? a : b;
 }
 __device__ __forceinline__ float f32(unsigned int bits) { return __builtin_bit_cast(float, bits); }
@@ -44,6 +47,9 @@ __device__ __forceinline__ float step(unsigned int bits, unsigned int d, u64 t) 
 // Delay by a signal amount (reference.rs:200-215): >= 2^64 -> the output is 0; negative / NaN -> 0 frames; else floor
 __device__ __forceinline__ bool dyn_frames(float d, u64 t, u64 &at) {
     if (d >= 18446744073709551616.0f) return false;
+#if FR_SPARKLE
+    if (!(d >= 0.0f)) return false;   // sparkle.rs:531-534
+#endif
     u64 fr = (d < 0.0f || d != d) ? 0ull : (u64)d;
     at = t - fr;
     return t >= fr;
@@ -90,7 +96,7 @@ bool literal_worthy(uint32_t bits) {
 }  // namespace
 
 bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<StageInstr> &instrs, uint32_t max_shapes, bool force,
-                    StageJitPlan &out) {
+                    StageJitPlan &out, bool sparkle) {
     if (progs.empty()) return false;
     struct Shape { uint32_t first; std::vector<uint32_t> members; std::vector<bool> literal; };
     std::map<std::string, uint32_t> ids;
@@ -178,7 +184,7 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
         cases << "    case " << si << ": r = shape" << si << "(a, P, t); break;\n";
     }
     std::ostringstream src;
-    src << "#pragma clang fp contract(off)\n" << FR_STR(FR_JIT_STAGE_ARGS_TEXT) << "\n";
+    src << "#pragma clang fp contract(off)\n#define FR_SPARKLE " << (sparkle ? 1 : 0) << "\n" << FR_STR(FR_JIT_STAGE_ARGS_TEXT) << "\n";
     std::string body = kStageSkeleton;
     auto put = [&](const std::string &tag, const std::string &text) { body.replace(body.find(tag), tag.size(), text); };
     put("SHAPE_FUNCTIONS", fns.str());

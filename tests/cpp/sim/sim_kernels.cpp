@@ -28,18 +28,19 @@ float prim_mod(float a, float b) {
     float rem = std::fmod(a, b);
     return rem < 0.0f ? rem + b : rem;
 }
-float prim_min(float a, float b) { return (a < b || b != b) ? a : b; }
-float prim_binop(uint32_t op, float a, float b) {
+float prim_min(float a, float b, bool sparkle) { return (sparkle && a != a) ? a : ((a < b || b != b) ? a : b); }
+float prim_binop(uint32_t op, float a, float b, bool sparkle) {
     switch (op) {
     case OP_SUM2: return a + b;
     case OP_MUL: return a * b;
     case OP_DIV: return a / b;
     case OP_MOD: return prim_mod(a, b);
-    default: return prim_min(a, b);
+    default: return prim_min(a, b, sparkle);
     }
 }
-bool delay_frames(float d, uint64_t &frames) {
+bool delay_frames(float d, uint64_t &frames, bool sparkle) {
     if (d >= 18446744073709551616.0f) return false;
+    if (sparkle && !(d >= 0.0f)) return false;
     frames = (d < 0.0f || d != d) ? 0ull : (uint64_t)d;
     return true;
 }
@@ -73,10 +74,10 @@ float eval_node(const PullArgs &a, uint32_t id, uint64_t t) {
     case OP_INPUT: return n.a < a.n_inputs ? read_input(a.inputs[n.a], t) : 0.0f;
     case OP_DELAY: {
         uint64_t fr_;
-        if (!delay_frames(eval_node(a, n.b, t), fr_) || fr_ > t) return 0.0f;
+        if (!delay_frames(eval_node(a, n.b, t), fr_, a.sparkle != 0) || fr_ > t) return 0.0f;
         return eval_node(a, n.a, t - fr_);
     }
-    default: { float x = eval_node(a, n.a, t); return prim_binop(n.op, x, eval_node(a, n.b, t)); }
+    default: { float x = eval_node(a, n.a, t); return prim_binop(n.op, x, eval_node(a, n.b, t), a.sparkle != 0); }
     }
 }
 
@@ -166,7 +167,7 @@ hipError_t launch_stage(const StageArgs &a, hipStream_t) {
                 case S_STORE: ring(in.buf, t) = tmp[in.a]; continue;
                 case S_READ_DYN: case S_READ_INPUT_DYN: case S_STEP_DYN: {
                     uint64_t fr_;
-                    if (delay_frames(tmp[in.a], fr_) && t >= fr_) {
+                    if (delay_frames(tmp[in.a], fr_, a.sparkle != 0) && t >= fr_) {
                         if (in.op == S_READ_DYN) v = ring(in.buf, t - fr_);
                         else if (in.op == S_READ_INPUT_DYN) v = input(in.imm, t - fr_);
                         else std::memcpy(&v, &in.imm, 4);
@@ -177,7 +178,7 @@ hipError_t launch_stage(const StageArgs &a, hipStream_t) {
                 case S_MUL: v = tmp[in.a] * tmp[in.b]; break;
                 case S_DIV: v = tmp[in.a] / tmp[in.b]; break;
                 case S_MOD: v = prim_mod(tmp[in.a], tmp[in.b]); break;
-                default: v = prim_min(tmp[in.a], tmp[in.b]); break;
+                default: v = prim_min(tmp[in.a], tmp[in.b], a.sparkle != 0); break;
                 }
                 tmp[in.dst] = v;
             }

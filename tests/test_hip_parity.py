@@ -505,6 +505,21 @@ def test_ten_million_frames_in_bounded_memory(hip_lib):
     assert run(0) > (30 << 20)             # the reference's behaviour: ~38 MB more for 9.5 M further frames
 
 
+@pytest.mark.parametrize("mode", ["auto", "pull", "staged"])
+def test_sparkle_semantics(hip_lib, oracle_lib, mode):
+    """FR_SEMANTICS_SPARKLE (Minimum as select-ult, Delay amount < 0 / NaN -> 0.0) on the device, all three evaluators."""
+    import test_sim_engine
+    test_sim_engine._sparkle_cases(hip_lib, oracle_lib, mode)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_graphs_sparkle_semantics(hip_lib, oracle_lib, seed, monkeypatch):
+    import test_sim_engine
+    if seed % 2:
+        monkeypatch.setenv("FR_STAGE_JIT", "force")     # the compiled stage programs carry the semantics too
+    test_sim_engine.test_random_graphs_sparkle_semantics(hip_lib, oracle_lib, seed)
+
+
 def test_rccl_is_loadable_and_hands_out_an_id(hip_lib):
     """fr_comm_unique_id = ncclGetUniqueId through the engine's lazily loaded RCCL (one rank cannot exercise more)."""
     a, b = hip_lib.comm_unique_id(), hip_lib.comm_unique_id()

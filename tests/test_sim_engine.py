@@ -277,3 +277,73 @@ def test_ten_million_frames_in_bounded_memory(sim):
             assert out[0, 100] == row[0] and out[0, 99] == (row[T - 1] if k else 0.0)
         assert allocs.value == settled, "device allocations kept happening"
         assert peak < 4 * (2 * (48000 + T) * 4) + (1 << 20), peak   # history buffer + output + slack; not 40 MB
+
+
+def _sparkle_cases(lib, oracle_lib, mode):
+    """Minimum with a NaN on either side and Delay with negative / NaN / fractional / huge amounts -- constant and as
+    signals -- under FR_SEMANTICS_SPARKLE, against the oracle under the same flag; and the two semantics really differ."""
+    nan = float("nan")
+    rows = [np.array([1.0, nan, -2.0, nan, 5.0, -0.0, 0.0, 3.0], np.float32),          # a
+            np.array([nan, 2.0, -3.0, nan, 4.0, 0.0, -0.0, nan], np.float32),           # b
+            np.array([-1.0, nan, 0.5, 2.0, -0.0, 3.9, 1e30, 1.0], np.float32)]          # delay amounts
+    outs = {}
+    for sem in ("sparkle", "reference"):
+        with Renderer(lib, mode=mode, semantics=sem) as r, Renderer(oracle_lib, semantics=sem) as ref:
+            for x in (r, ref):
+                x.on_add_node(1, "F32Constant")
+                x.on_add_node(2, "Minimum")       # min(a, b)
+                x.on_add_node(3, "Minimum")       # min(b, a)
+                x.on_add_node(4, "Delay")         # a delayed by the signal in slot 2
+                x.on_add_node(5, "Delay")         # a delayed by the constant -3
+                x.on_add_node(6, "Delay")         # (a + 1) delayed by NaN: a computed source
+                x.on_add_node(7, "Sum2")
+                x.on_add_node(8, "Minimum")       # min(NaN constant, a): folds nothing, a NaN on the LEFT
+                x.on_add_edge(0, 2, 0, 0); x.on_add_edge(0, 2, 1, 1)
+                x.on_add_edge(0, 3, 1, 0); x.on_add_edge(0, 3, 0, 1)
+                x.on_add_edge(0, 4, 0, 0); x.on_add_edge(0, 4, 2, 1)
+                x.on_add_edge(0, 5, 0, 0); x.on_add_edge(1, 5, f32_bits(-3.0), 1)
+                x.on_add_edge(0, 7, 0, 0); x.on_add_edge(1, 7, f32_bits(1.0), 1)
+                x.on_add_edge(7, 6, 0, 0); x.on_add_edge(1, 6, f32_bits(nan), 1)
+                x.on_add_edge(1, 8, f32_bits(nan), 0); x.on_add_edge(0, 8, 0, 1)
+                for i, h in enumerate((2, 3, 4, 5, 6, 8)):
+                    x.on_add_edge(h, 0, 0, i)
+            got = r.fill_buffer(6, 0, 8, rows)
+            exp = ref.fill_buffer(6, 0, 8, rows)
+            assert same_bits(got, exp), f"{sem} / {mode}: " + G.first_diff(got, exp)
+            outs[sem] = got
+    s, f = outs["sparkle"], outs["reference"]
+    assert np.isnan(s[0, 1]) and f[0, 1] == 2.0                    # min(NaN, 2): Sparkle returns its left operand
+    assert s[0, 0] == 1.0 and f[0, 0] == 1.0                       # min(1, NaN): both return the left operand
+    assert not s[3].any() and same_bits(f[3], rows[0])             # Delay by -3: Sparkle 0.0, RefRenderer no delay
+    assert s[2, 0] == 0.0 and f[2, 0] == 1.0                       # Delay by the signal -1 at t = 0
+    assert not s[4].any() and same_bits(f[4], rows[0] + 1)         # Delay by NaN
+    assert np.isnan(s[5]).all() and same_bits(f[5], rows[0])       # min(NaN, a)
+
+
+@pytest.mark.parametrize("mode", ["auto", "pull", "staged"])
+def test_sparkle_semantics(sim, oracle_lib, mode):
+    _sparkle_cases(sim, oracle_lib, mode)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_graphs_sparkle_semantics(sim, oracle_lib, seed):
+    """Random graphs (NaN / negative constants and signal delays included) under FR_SEMANTICS_SPARKLE."""
+    import randgraph
+    rng = np.random.default_rng(2000 + seed)
+    steps, n_out = randgraph.random_graph(700 + seed, n_nodes=int(rng.integers(6, 40)), n_inputs=2, n_outputs=3)
+    T = 64
+    for mode in ("auto", "pull"):
+        with Renderer(sim, mode=mode, semantics="sparkle") as r, Renderer(oracle_lib, semantics="sparkle") as ref:
+            randgraph.install_steps(r, steps)
+            randgraph.install_steps(ref, steps)
+            for start in (0, T):
+                rows = [synth.time_ramp(start, start + T), (rng.normal(size=T) * 3).astype(np.float32)]
+                try:
+                    exp = ref.fill_buffer(n_out, start, start + T, rows)
+                except RenderError as e:
+                    with pytest.raises(RenderError) as ei:
+                        r.fill_buffer(n_out, start, start + T, rows)
+                    assert ei.value.status == e.status
+                    break
+                got = r.fill_buffer(n_out, start, start + T, rows)
+                assert same_bits(got, exp), f"seed {seed} {mode}: " + G.first_diff(got, exp)
