@@ -272,7 +272,7 @@ struct Lowering::Impl {
     // Context 0 (the top-level graph, where almost all nodes of a big patch live) is indexed directly by position;
     // the hash maps serve the contexts of composite instances.
     struct Table {
-        std::vector<uint64_t> top;
+        VArray<uint64_t> top;
         FlatMap64 rest;
         uint64_t *find(uint64_t k) {
             if (!(k >> 32)) return (uint32_t)k < top.size() ? &top[(uint32_t)k] : nullptr;
@@ -281,7 +281,7 @@ struct Lowering::Impl {
         uint64_t &get(uint64_t k) {
             if (!(k >> 32)) {
                 const size_t p = (uint32_t)k;
-                if (p >= top.size()) top.resize(std::max(p + 1, top.size() + top.size() / 2), 0);
+                if (p >= top.size()) top.resize(p + 1, 0);   // (no copy: VArray)
                 return top[p];
             }
             return rest.get(k);
@@ -293,7 +293,7 @@ struct Lowering::Impl {
     // readers: key -> list of keys whose lowering looked at `key` (as an operand, or -- for a top-level composite
     // instance -- by following one of its inbound edges or outputs)
     Table readers_head;   // -> cell index + 1
-    std::vector<UserCell> cells;
+    VArray<UserCell> cells;
     std::vector<uint32_t> free_cells;
     bool valid = false;
     uint64_t generation = 0, relowered = 0;

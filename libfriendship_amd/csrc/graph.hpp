@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <deque>
 #include <new>
 #include <memory>
@@ -159,6 +160,64 @@ public:
         slots_ = old_ = nullptr;
         cap_ = mask_ = n_ = old_cap_ = old_pos_ = 0;
     }
+};
+
+// Growable array for the engine's multi-million-element tables (lowered nodes, memo tables, reader lists) that never
+// moves its elements: the address range for the largest size it may ever reach is reserved once (mmap, no pages
+// committed) and the kernel backs pages as they are first touched.  A std::vector doubling one of these tables copies
+// tens of megabytes inside whichever fill_buffer call follows the edit that crossed the capacity -- measured 80-110 ms
+// for a note-on at config C size (profiles/r02_edit_latency.txt); here growth costs page faults only.
+// T must be trivially copyable and valid when all-zero.  Falls back to an ordinary doubling buffer when the
+// reservation is refused (strict overcommit).
+template <class T>
+class VArray {
+    T *p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;      // cap_: elements the current mapping / buffer can hold
+    bool mapped_ = false;
+    static constexpr size_t RESERVE_BYTES = (size_t)16 << 30;   // address space, not memory
+    void map_once();
+    void grow_to(size_t need);
+    void release();
+
+public:
+    VArray() = default;
+    VArray(const VArray &o) { *this = o; }
+    VArray(VArray &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_), mapped_(o.mapped_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; o.mapped_ = false; }
+    VArray &operator=(const VArray &o) {
+        if (this != &o) {
+            n_ = 0;
+            if (o.n_) { grow_to(o.n_); std::memcpy(p_, o.p_, o.n_ * sizeof(T)); n_ = o.n_; }
+        }
+        return *this;
+    }
+    VArray &operator=(VArray &&o) noexcept {
+        if (this != &o) { release(); p_ = o.p_; n_ = o.n_; cap_ = o.cap_; mapped_ = o.mapped_; o.p_ = nullptr; o.n_ = o.cap_ = 0; o.mapped_ = false; }
+        return *this;
+    }
+    ~VArray() { release(); }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    T *data() { return p_; }
+    const T *data() const { return p_; }
+    T &operator[](size_t i) { return p_[i]; }
+    const T &operator[](size_t i) const { return p_[i]; }
+    T &back() { return p_[n_ - 1]; }
+    const T &back() const { return p_[n_ - 1]; }
+    T *begin() { return p_; }
+    T *end() { return p_ + n_; }
+    const T *begin() const { return p_; }
+    const T *end() const { return p_ + n_; }
+    void reserve(size_t) {}                       // nothing to do: growth never copies
+    void push_back(const T &v) {
+        if (n_ == cap_) grow_to(n_ + 1);
+        p_[n_++] = v;
+    }
+    void resize(size_t n, const T &v = T()) {     // new elements take `v`
+        if (n > cap_) grow_to(n);
+        for (size_t i = n_; i < n; ++i) p_[i] = v;
+        n_ = n;
+    }
+    void clear();                                 // gives the pages back
 };
 
 struct Error : std::runtime_error {
@@ -313,7 +372,7 @@ struct FlatNode {
 };
 
 struct FlatGraph {
-    std::vector<FlatNode> nodes;       // topological: operands precede users
+    VArray<FlatNode> nodes;            // topological: operands precede users
     std::vector<uint32_t> outputs;     // per rendered slot, a node id
     uint32_t max_depth = 0;
     uint32_t max_input_slot = 0;       // highest OP_INPUT slot referenced (valid if has_input)
@@ -368,6 +427,46 @@ private:
 // Lowers the first n_slots output slots of the mirror.  Throws fr::Error (NO_SUCH_NODE, BAD_SLOT,
 // CYCLE) where the reference's evaluation of those slots would panic or never terminate.
 FlatGraph lower(const Mirror &m, uint32_t n_slots);
+
+}  // namespace fr
+#include <sys/mman.h>
+namespace fr {
+template <class T>
+void VArray<T>::map_once() {
+    void *m = mmap(nullptr, RESERVE_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) return;
+    p_ = (T *)m;
+    cap_ = RESERVE_BYTES / sizeof(T);
+    mapped_ = true;
+}
+template <class T>
+void VArray<T>::grow_to(size_t need) {
+    if (!p_ && !mapped_) map_once();
+    if (mapped_) {
+        if (need > cap_) throw std::bad_alloc();
+        return;
+    }
+    size_t cap = std::max<size_t>(need, std::max<size_t>(cap_ * 2, 1024));   // fallback: a doubling buffer
+    T *q = (T *)std::calloc(cap, sizeof(T));
+    if (!q) throw std::bad_alloc();
+    if (n_) std::memcpy(q, p_, n_ * sizeof(T));
+    std::free(p_);
+    p_ = q;
+    cap_ = cap;
+}
+template <class T>
+void VArray<T>::release() {
+    if (mapped_) munmap(p_, RESERVE_BYTES);
+    else std::free(p_);
+    p_ = nullptr;
+    n_ = cap_ = 0;
+    mapped_ = false;
+}
+template <class T>
+void VArray<T>::clear() {
+    if (mapped_ && n_) madvise(p_, ((n_ * sizeof(T) + 4095) / 4096) * 4096, MADV_DONTNEED);   // pages back, range kept
+    n_ = 0;
+}
 
 // Exactly-rounded host evaluation of one primitive (same semantics as the device code and as
 // reference.rs:197-262); used for constant folding.

@@ -20,13 +20,15 @@ def main():
     ap.add_argument("--partials", type=int, default=4096)
     ap.add_argument("--frames", type=int, default=4800)
     ap.add_argument("--tree", default="additive", choices=["additive", "effects"])
+    ap.add_argument("--async-compile", action="store_true", help="the ABI's default: hipRTC on a worker thread (Python's default is sync)")
+    ap.add_argument("--note-ons", type=int, default=3)
     a = ap.parse_args()
     V, P, T = a.voices, a.partials, a.frames
     tree = synth.additive_tree(V, P) if a.tree == "additive" else synth.effects_tree(V, P)
     e = tree["edges"]
     amp = tree["params"]["amp"]
     rows = np.nonzero((e[:, 0] == synth.CONST_HANDLE) & (e[:, 3] == 0) & (e[:, 2] == f32_bits(amp[0, 100 % P])))[0]
-    with Renderer(hip_lib()) as r:
+    with Renderer(hip_lib(), sync_compile=not a.async_compile) as r:
         t0 = time.perf_counter()
         synth.install(r, tree)
         t_install = time.perf_counter() - t0
@@ -56,7 +58,7 @@ def main():
             after.append((t_edit, call(), r.plan()))
         # note-on: a whole new voice (P partials, ~12 P nodes and ~22 P edges) arrives between two calls
         note_on = []
-        for i in range(3):
+        for i in range(a.note_ons):
             g = synth.GraphArrays()
             g.next = int(tree["handles"].max()) + 1 + i * 16 * P
             vp = synth.voice_params(1, P, 0x5EED0100 + i)
@@ -81,7 +83,8 @@ def main():
                   f"{p['relowered_nodes']} nodes re-lowered, build {p['build_ms']:.2f} ms")
         for t_msgs, ms, p in note_on:
             print(f"  call after a note-on          {ms:9.3f} ms   a {P}-partial voice added: batch messages {t_msgs:.1f} ms, {p['lowering']}, "
-                  f"{p['relowered_nodes']} nodes lowered, build {p['build_ms']:.2f} ms")
+                  f"{p['relowered_nodes']} nodes lowered, build {p['build_ms']:.2f} ms (lowering {p['lower_ms']:.1f}, hipRTC so far {p['jit_compile_ms']:.0f} ms / "
+                  f"{p['jit_kernels_compiled']} kernels, {len(p['banks'])} bank launches)")
 
 
 if __name__ == "__main__":

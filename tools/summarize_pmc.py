@@ -7,8 +7,9 @@ import glob
 import json
 import sys
 
-src, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r01")
+src, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r02")
 outdir = sys.argv[3] if len(sys.argv) > 3 else "profiles"
+commit = sys.argv[4] if len(sys.argv) > 4 else "unknown"
 V, P, T = 64, 4096, 4800
 out = {}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
@@ -27,7 +28,8 @@ for f in glob.glob(f"{src}/trace/*/*kernel_stats.csv"):
 pf = V * P * T
 avg_s = stats.get("average_ns", 0) * 1e-9
 summ = {
-    "command": "tools/collect_profiles.sh (rocprofv3 --pmc <counters> -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2; one pass per TCC counter)",
+    "commit": commit,
+    "command": "tools/collect_profiles.sh (rocprofv3 --pmc <counters> -- python3 bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2 --repeats 1; one pass per TCC counter)",
     "kernel": "fr::bank_kernel<1, 1, 4>", "per": "launch (one 4800-frame fill_buffer over 64 voices x 4096 partials)",
     "kernel_trace_stats": stats, "counters": out,
     "derived": {
