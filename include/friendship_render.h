@@ -180,7 +180,8 @@ fr_status fr_on_add_edges(fr_renderer *r, const fr_edge *edges, size_t n);
  *                      sends, each followed by the tree's own f32 add in the tree's own association --
  *                      leaves the owner with the bank's value, bit-identical to the unsharded render.
  *                      Effects behind the bank (envelopes, delay lines) then run on the owner.
- *                      world must be a power of two.
+ *                      world must be a power of two.  (Ranks must plan identically on the same call, so in this
+ *                      mode run-time kernels are compiled inside the call, as with FR_CONFIG_SYNC_COMPILE.)
  * FR_SHARD_GATHER (flag): after rendering, rank 0's `out` also receives every other rank's rows.
  * Transport of the exchange: the engine's own RCCL communicator over xGMI (pass the same
  * fr_comm_unique_id() bytes on every rank), or a host-staged callback (`comm`; MPI, gloo, a test

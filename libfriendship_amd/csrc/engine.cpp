@@ -893,7 +893,7 @@ struct fr_renderer {
                 d_bank_ws.ensure(((size_t)a.n_voices << (a.log2_p - a.chunk_log2)) * blen * sizeof(float));
                 a.ws = d_bank_ws.as<float>();
                 if (a.small_call == 2) {   // arrival counters of the in-launch combine: zero between launches (the kernel resets them)
-                    const size_t need = (size_t)a.n_voices * ((blen + 63) / 64) * sizeof(uint32_t);
+                    const size_t need = (size_t)a.n_voices * ((blen + 63) / 64) * BANK_TICKET_STRIDE * sizeof(uint32_t);
                     if (need > d_tickets.bytes) {
                         d_tickets.ensure(need * 2);
                         HIP_CHECK(hipMemsetAsync(d_tickets.p, 0, d_tickets.bytes, st));
@@ -1291,6 +1291,10 @@ fr_status fr_set_shard(fr_renderer *r, const fr_shard *sh) {
             }
             if (sh->rccl_id) transport = make_rccl_transport(sh->rccl_id, sh->rank, sh->world);   // collective
         }
+        // Partial-block sharding needs every rank to arrive at the SAME plan (the same list of split voices) on the same
+        // call; a kernel that finishes compiling at different moments on different ranks would break that, so compile in
+        // the call from here on.
+        if (spec.mode == FR_SHARD_PARTIALS) r->jit_cache.set_async(false);
         r->shard = spec;
         r->shard_flags = flags;
         r->rccl = std::move(transport);

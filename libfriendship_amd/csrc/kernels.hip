@@ -246,11 +246,11 @@ __device__ __forceinline__ void bank_group(const ParamGroup &pg, uint32_t g,
     for (int f = 0; f < F; ++f) s8[f] = v[f];
 }
 
-// DEEP: two parameter groups fetched ahead instead of one (a PAIR of groups loaded while the previous pair is summed).
-// Built for launches that leave a SIMD only a few waves to hide a scalar load behind -- and measured SLOWER everywhere
-// (64 x 4096: T = 64 7.5 -> 8.4 us, 256 10.6 -> 13.3, 512 17.8 -> 20.1, 1024 29.3 -> 33.0; profiles/r02_short_calls.txt):
-// the 32 extra SGPRs take the kernels to the register limit.  Kept as an option for A/B runs only.
-template <int F, bool FAST, bool EXACT, bool DEEP = false>
+// (Fetching a PAIR of parameter groups ahead instead of one -- for launches that leave a SIMD only a few waves to hide a
+//  scalar load behind -- was built and measured SLOWER everywhere: 64 x 4096, T = 64 7.5 -> 8.4 us, 256 10.6 -> 13.3,
+//  512 17.8 -> 20.1, 1024 29.3 -> 33.0; the 32 extra SGPRs take these kernels to the register limit.
+//  profiles/r02_short_calls.txt.)
+template <int F, bool FAST, bool EXACT>
 __device__ __forceinline__ void bank_wave_sum(const float *params, uint32_t ngroups, uint32_t levels,
                                               const float (&t)[F], float (&res)[F]) {
     float s0[F], s1[F], s2[F], s3[F], s4[F], s5[F], s6[F], s7[F], s8[F];
@@ -259,25 +259,6 @@ __device__ __forceinline__ void bank_wave_sum(const float *params, uint32_t ngro
         s0[f] = s1[f] = s2[f] = s3[f] = s4[f] = s5[f] = s6[f] = s7[f] = s8[f] = 0.0f;
 
     const_f32_ptr p = (const_f32_ptr)params;
-    if (DEEP && ngroups >= 4u) {   // (ngroups is a power of two)
-        ParamGroup pa, pb, pc, pd;
-        load_group(pa, p, 0);
-        load_group(pb, p, 1);
-        for (uint32_t g = 0; g < ngroups; g += 4) {
-            __builtin_amdgcn_s_waitcnt(0xC07F);   // pa, pb have landed
-            load_group(pc, p, g + 2);
-            load_group(pd, p, g + 3);
-            bank_group<F, FAST, EXACT>(pa, g, t, FR_LEVELS_PASS);
-            bank_group<F, FAST, EXACT>(pb, g + 1, t, FR_LEVELS_PASS);
-            __builtin_amdgcn_s_waitcnt(0xC07F);   // pc, pd have landed
-            if (g + 4 < ngroups) {
-                load_group(pa, p, g + 4);
-                load_group(pb, p, g + 5);
-            }
-            bank_group<F, FAST, EXACT>(pc, g + 2, t, FR_LEVELS_PASS);
-            bank_group<F, FAST, EXACT>(pd, g + 3, t, FR_LEVELS_PASS);
-        }
-    } else {
     // two parameter groups in flight: the scalar load of group g+1 is issued before group g's math
     ParamGroup pa, pb;
     load_group(pa, p, 0);
@@ -293,7 +274,6 @@ __device__ __forceinline__ void bank_wave_sum(const float *params, uint32_t ngro
             if (g + 2 < ngroups) load_group(pa, p, g + 2);
             bank_group<F, FAST, EXACT>(pb, g + 1, t, FR_LEVELS_PASS);
         }
-    }
     }
     // after the last group (all ones) the carry chain stopped at level `levels`
 #pragma unroll
@@ -629,6 +609,9 @@ __global__ void __launch_bounds__(256) bank_combine_kernel(BankArgs a) {
 //     (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores -> vmcnt(0) -> one lane's atomic add -> the last
 //     adder loads sc1).
 // ---------------------------------------------------------------------------------------------------
+// one ticket per 128-byte line: neighbouring (voice, tile) pairs would otherwise serialise their atomics on one L2 line
+constexpr uint32_t TICKET_STRIDE = BANK_TICKET_STRIDE;
+
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) bank_short_kernel(BankArgs a, uint32_t tiles) {
     __shared__ float sm[NW][64];
@@ -692,7 +675,7 @@ __global__ void __launch_bounds__(64 * NW) bank_short_kernel(BankArgs a, uint32_
     if (live) __hip_atomic_store(slot + (size_t)chunk * vstride + ti, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t old = 0u;
-    if (lane == 0u) old = __hip_atomic_fetch_add(a.tickets + vt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0u) old = __hip_atomic_fetch_add(a.tickets + (size_t)vt * TICKET_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     old = __builtin_amdgcn_readfirstlane(old);
     if (old != nchunks - 1u) return;
     if (live) {
@@ -719,7 +702,7 @@ __global__ void __launch_bounds__(64 * NW) bank_short_kernel(BankArgs a, uint32_
         result = clog == 1u ? c1 : result;
         orow[bank_out_index(a, ti)] = result;
     }
-    if (lane == 0u) __hip_atomic_store(a.tickets + vt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+    if (lane == 0u) __hip_atomic_store(a.tickets + (size_t)vt * TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
 }
 
 template <int NW>

@@ -69,13 +69,15 @@ struct BankArgs {
     uint32_t leaf_variant;     // 0 = product-form leaves; 1 = FMA-form leaves + zero-sign repair (same bits, faster)
     float *hist_dst;           // if non-null: the kernel also copies time[0..time_valid) here (input-history append)
     float *ws;                 // [P >> chunk_log2][n_voices][n_times] partial sums; unused when one chunk
-    uint32_t *tickets;         // small_call == 2 with chunks: [n_voices][tiles] arrival counters, all zero between launches
+    uint32_t *tickets;         // small_call == 2 with chunks: [n_voices][tiles] arrival counters, BANK_TICKET_STRIDE words
+                               // apart, all zero between launches
     // general voices (launch_gbank): groups[i] = log2(item leaves, <= 11) | merges_after << 4; params = the items'
     // {w, -4*amp} pairs in order, items of < 8 leaves padded to 8 pairs; voice v owns items
     // [group_off[2v], group_off[2v+2]) and its parameters start at pair 8 * group_off[2v+1]
     const uint32_t *groups;
     const uint32_t *group_off;
 };
+constexpr uint32_t BANK_TICKET_STRIDE = 32;
 void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane,
                 uint32_t &waves_per_group, uint32_t &small_call, uint32_t &voices_per_wave);
 uint64_t bank_blocks(const BankArgs &a);
