@@ -834,7 +834,13 @@ void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &
         return;
     }
     // (64 x 4096 at 512 / 1024 frames, 512 / 1024 workgroups: 8 waves 20.7 / 32.3 us, 4 waves 23.4 / 35.5 us, chunks of 2^11 35 / 47 us)
-    waves_per_group = (log2_p >= 14 || (blocks < 2048 && log2_p >= 6)) ? 8 : 4;
+    // (32 x 4096 x 4800, 2400 workgroups: 8 waves 65.2 us, 4 waves 66.9; 16 x 4096: 36.0 vs 38.5; 64 x 4096: equal)
+    waves_per_group = (log2_p >= 14 || (blocks < 4096 && log2_p >= 6)) ? 8 : 4;
+    {
+        static const uint32_t nw_env = [] { const char *e = std::getenv("FR_BANK_NW"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+        if (nw_env == 4 && log2_p < 14) waves_per_group = 4;   // A/B
+        if (nw_env == 8 && log2_p >= 6) waves_per_group = 8;
+    }
     const uint32_t cmax = waves_per_group == 8 ? 14 : 13;
     chunk_log2 = log2_p < cmax ? log2_p : cmax;
 }

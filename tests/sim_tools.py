@@ -16,6 +16,8 @@ SIM_SOURCES = ["sim_hip.cpp", "sim_kernels.cpp"]
 
 
 def build_sim():
+    if os.environ.get("FR_SIM_LIB"):          # a pre-built variant (e.g. an AddressSanitizer build), used as is
+        return os.environ["FR_SIM_LIB"]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(SIM, f) for f in SIM_SOURCES]
     deps.append(os.path.join(ROOT, "include", "friendship_render.h"))
     if os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in deps):
