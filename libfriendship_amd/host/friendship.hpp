@@ -638,6 +638,8 @@ protected:
         decltype(&fr_last_error) last_error;
         decltype(&fr_status_string) status_string;
         decltype(&fr_backend_name) backend_name;
+        decltype(&fr_set_shard) set_shard;
+        decltype(&fr_shard_rows) shard_rows;
     } api_{};
 
     template <class T>
@@ -679,7 +681,10 @@ protected:
     }
 
 public:
-    explicit PluginRenderer(const std::string &library_path, int mode = FR_MODE_AUTO, int device = -1) {
+    // `semantics`: FR_SEMANTICS_REFERENCE (RefRenderer, the default) or FR_SEMANTICS_SPARKLE; `history_frames`: 0 = keep
+    // every input sample since the last seek (the reference); `flags`: FR_CONFIG_SYNC_COMPILE for deterministic plans.
+    explicit PluginRenderer(const std::string &library_path, int mode = FR_MODE_AUTO, int device = -1,
+                            int semantics = FR_SEMANTICS_REFERENCE, uint64_t history_frames = 0, uint32_t flags = 0) {
         dl_ = dlopen(library_path.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!dl_) throw std::runtime_error(std::string("cannot load renderer library: ") + dlerror());
         sym(api_.create, "fr_renderer_create");
@@ -692,7 +697,9 @@ public:
         sym(api_.last_error, "fr_last_error");
         sym(api_.status_string, "fr_status_string");
         sym(api_.backend_name, "fr_backend_name");
-        fr_config cfg{FR_ABI_VERSION, device, mode, 0};
+        sym(api_.set_shard, "fr_set_shard");
+        sym(api_.shard_rows, "fr_shard_rows");
+        fr_config cfg{FR_ABI_VERSION, device, mode, flags, semantics, 0, history_frames};
         fr_status s = api_.create(&cfg, &h_);
         if (s != FR_OK) {
             std::string what = api_.status_string(s);
@@ -707,6 +714,21 @@ public:
         if (dl_) dlclose(dl_);
     }
     std::string backend() const { return api_.backend_name(); }
+
+    // One process (and one renderer) per GPU: this renderer becomes rank `rank` of `world` (friendship_render.h
+    // fr_set_shard).  Every rank is sent the same RouteGraph messages and the same RenderRange; it fills the rows
+    // shard_rows() names (rank 0 all of them with FR_SHARD_GATHER).  `rccl_id`: the bytes of fr_comm_unique_id from
+    // rank 0; `comm`: a host transport instead.  Neither is needed for FR_SHARD_VOICES without gathering.
+    void set_shard(uint32_t rank, uint32_t world, int mode = FR_SHARD_VOICES, uint32_t flags = 0, const uint8_t *rccl_id = nullptr,
+                   const fr_comm *comm = nullptr) {
+        fr_shard sh{rank, world, mode, flags, rccl_id, comm};
+        check(api_.set_shard(h_, &sh));
+    }
+    std::pair<uint32_t, uint32_t> shard_rows(uint32_t n_slots) const {
+        uint32_t lo = 0, hi = 0;
+        api_.shard_rows(h_, n_slots, &lo, &hi);
+        return {lo, hi};
+    }
 
     void on_add_node(const routing::NodeHandle &node, const routing::NodeData &data) override {
         auto ce = lower(*data);

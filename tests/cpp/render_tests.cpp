@@ -331,8 +331,38 @@ static void mpsc_client_and_queries() {
         throw std::runtime_error("osc_address");
 }
 
+// Two GPUs' worth of Dispatch: every rank's Dispatch<HipRenderer, _> is sent the SAME messages (dispatch.rs:111-161) and its
+// renderer is told which rank it is -- the reference's message stream needs no change.  Voices mode: rank r's buffer holds
+// its block of the rows, the other rows keep the zeros Dispatch allocated (dispatch.rs:149).
+static void sharded_dispatch_two_ranks() {
+    const char *lib = std::getenv("FRIENDSHIP_RENDERER_LIB");
+    std::vector<Array2> got;
+    for (uint32_t rank = 0; rank < 2; ++rank) {
+        Channel rx = std::make_shared<std::deque<Array2>>();
+        auto pr = std::make_unique<render::PluginRenderer>(lib);
+        pr->set_shard(rank, 2, FR_SHARD_VOICES);
+        auto rows = pr->shard_rows(3);
+        if (rows != (rank == 0 ? std::make_pair(0u, 2u) : std::make_pair(2u, 3u))) throw std::runtime_error("shard_rows");
+        std::unique_ptr<render::Renderer> r = std::move(pr);
+        TestDispatch dispatch(std::move(r), MyClient(rx));
+        auto c = NodeHandle::make(1), m = NodeHandle::make(2);
+        dispatch.dispatch(OscRouteGraph::AddNode{c, const_id()});
+        dispatch.dispatch(OscRouteGraph::AddNode{m, mult_id()});
+        dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(c, m, EdgeWeight::make(f32_to_bits(3.0f), 0))});
+        dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(c, m, EdgeWeight::make(f32_to_bits(0.5f), 1))});
+        dispatch.dispatch(OscRouteGraph::AddEdge{Edge::new_to_null(c, EdgeWeight::make(f32_to_bits(7.0f), 0))});    // row 0 = 7
+        dispatch.dispatch(OscRouteGraph::AddEdge{Edge::new_to_null(m, EdgeWeight::make(0, 1))});                      // row 1 = 1.5
+        dispatch.dispatch(OscRouteGraph::AddEdge{Edge::new_to_null(c, EdgeWeight::make(f32_to_bits(-2.0f), 2))});   // row 2 = -2
+        dispatch.dispatch(render_range(0, 2, 3));
+        got.push_back(recv(rx));
+    }
+    ASSERT_EQ_ARR(got[0], (Array2{3, 2, {7.0f, 7.0f, 1.5f, 1.5f, 0.0f, 0.0f}}));
+    ASSERT_EQ_ARR(got[1], (Array2{3, 2, {0.0f, 0.0f, 0.0f, 0.0f, -2.0f, -2.0f}}));
+}
+
 int main(int argc, char **argv) {
     std::vector<std::pair<const char *, std::function<void()>>> tests = {
+        {"sharded_dispatch_two_ranks", sharded_dispatch_two_ranks},
         {"render_zeros", render_zeros}, {"render_const", render_const}, {"render_delay", render_delay},
         {"render_mult", render_mult}, {"render_sum2", render_sum2}, {"render_div", render_div},
         {"render_mod", render_mod}, {"render_min", render_min},
