@@ -183,3 +183,57 @@ def test_partials_without_a_transport_fails_loudly(sim):
         with pytest.raises(RenderError) as ei:
             r.fill_buffer(2, 0, 16, [synth.time_ramp(0, 16)])
         assert ei.value.status == FR_ERR_COMM
+
+
+def _random_patch(rng, n_rows):
+    """A random 'patch': voices of assorted sizes and tree shapes (balanced, odd counts, some tiny), each optionally through a
+    gain / an envelope shared between voices / a delay tap or two, wired to the rows at random -- some voices to two rows,
+    some rows to a plain input or a constant, some left unconnected."""
+    g = synth.GraphArrays()
+    f = np.float32
+    shared_env = synth.adsr_envelope(g, attack=30.0, decay=80.0, sustain=0.5, release=200.0, t_end=900.0)
+    heads = []
+    for v in range(int(rng.integers(2, 6))):
+        P = int(rng.choice([16, 24, 32, 64, 100, 128, 256, 512]))
+        p = synth.voice_params(1, P, int(rng.integers(1, 1 << 30)), bool(rng.integers(2)))
+        x = synth.sum_tree(g, synth.partial_leaves(g, p["w"], p["amp"]).reshape(1, P))
+        kind = int(rng.integers(5))
+        if kind == 1:
+            x = g.binop(synth.K_MUL, x, synth.C(f(rng.normal())), 1)
+        elif kind == 2:
+            x = g.binop(synth.K_MUL, np.broadcast_to(shared_env, x.shape), x, 1)
+        elif kind >= 3:
+            x = synth.delay_chain(g, x, taps=kind - 2, base_delay=float(rng.integers(5, 60)))
+        heads.append(x)
+    for row in range(n_rows):
+        r = rng.random()
+        if r < 0.65:
+            g.edge(heads[int(rng.integers(len(heads)))][0], 0, 0, row)
+        elif r < 0.8:
+            g.edge(0, 0, int(rng.integers(2)), row)                                 # an input, passed through
+        elif r < 0.9:
+            g.edge(synth.CONST_HANDLE, 0, int(synth.bits(f(rng.normal()))), row)     # a constant
+    return g.finish(n_rows)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_patches_sharded_every_way(sim, oracle_lib, seed):
+    """Random patches (see _random_patch) under voices and partial-block sharding at world 2, 4 and 8: contiguous calls, a
+    seek, every rank's rows bit-equal to the unsharded oracle, nobody writing rows it does not own."""
+    rng = np.random.default_rng(9000 + seed)
+    n_rows = int(rng.integers(3, 9))
+    tree = _random_patch(rng, n_rows)
+    T = 48
+    calls = [(0, T), (T, 2 * T), (2 * T, 3 * T), (700, 700 + T), (700 + T, 700 + 2 * T)]
+    rows_for = {c: [synth.time_ramp(c[0], c[1]), (rng.normal(size=T) * 2).astype(np.float32)] for c in calls}
+    with Renderer(oracle_lib) as ref:
+        synth.install(ref, tree)
+        expect = {c: ref.fill_buffer(n_rows, c[0], c[1], rows_for[c]) for c in calls}
+    for mode, world in (("voices", 2), ("voices", 3), ("partials", 2), ("partials", 4), ("partials", 8)):
+        job = shard_harness.Job(sim, world, mode)
+        for ren in job.ranks:
+            synth.install(ren, tree)
+        for c in calls:
+            got = job.assemble(job.fill(n_rows, c[0], c[1], rows_for[c]), n_rows)
+            assert same_bits(got, expect[c]), f"seed {seed} {mode} x{world} call {c}: " + first_diff(got, expect[c])
+        job.close()
