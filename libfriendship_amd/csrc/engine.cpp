@@ -616,7 +616,11 @@ struct fr_renderer {
         p.n_slots = n_slots;
         const ShardSpec *shard_spec = sharded() ? &shard : nullptr;
         const auto t_begin = std::chrono::steady_clock::now();
-        const FlatGraph &fg = lowering.update(mirror, n_slots);
+        // a rank of a voice-sharded job lowers only the rows it owns (1/world of the first-call cost; graph errors on another
+        // rank's rows are that rank's to report); partial-block sharding analyses the whole graph on every rank
+        uint32_t lower_lo = 0, lower_hi = UINT32_MAX;
+        if (sharded() && shard.mode == FR_SHARD_VOICES) my_rows(n_slots, lower_lo, lower_hi);
+        const FlatGraph &fg = lowering.update(mirror, n_slots, lower_lo, lower_hi);
         const double lower_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
         p.max_depth = fg.max_depth;
         bool use_jit = allow_jit && mode == FR_MODE_AUTO;

@@ -296,6 +296,7 @@ struct Lowering::Impl {
     VArray<UserCell> cells;
     std::vector<uint32_t> free_cells;
     bool valid = false;
+    uint32_t row_lo = 0, row_hi = 0xFFFFFFFFu;   // output slots lowered (Lowering::update)
     uint64_t generation = 0, relowered = 0;
     bool was_full = true;
     size_t base_nodes = 0, base_ctxs = 0, base_cells = 0;
@@ -501,6 +502,7 @@ struct Lowering::Impl {
         valid = true;   // from here on the state matches the mirror even if an output fails to lower
         fg.outputs.assign(n_slots, 0);
         for (uint32_t s = 0; s < n_slots; ++s) {
+            if (s < row_lo || s >= row_hi) { fg.outputs[s] = fg.konst(0); continue; }   // another rank's row
             EdgeRef ref = s < mm.outputs.size() ? mm.outputs[s] : EdgeRef{};  // reference.rs:158-161
             fg.outputs[s] = eval(0, ref);
         }
@@ -511,12 +513,17 @@ struct Lowering::Impl {
 
 Lowering::Lowering() : impl_(new Impl) {}
 Lowering::~Lowering() = default;
-const FlatGraph &Lowering::update(Mirror &m, uint32_t n_slots) {
+const FlatGraph &Lowering::update(Mirror &m, uint32_t n_slots, uint32_t row_lo, uint32_t row_hi) {
     std::vector<uint32_t> journal;
     journal.swap(m.journal);
-    const bool usable = m.journal_on && !m.journal_overflow;
+    bool usable = m.journal_on && !m.journal_overflow;
     m.journal_on = true;        // the invalidations below are applied before anything can throw
     m.journal_overflow = false;
+    if (row_lo != impl_->row_lo || row_hi != impl_->row_hi) {
+        impl_->row_lo = row_lo;
+        impl_->row_hi = row_hi;
+        usable = false;         // other rows than last time: from scratch
+    }
     return impl_->update(m, n_slots, usable ? &journal : nullptr);
 }
 uint64_t Lowering::generation() const { return impl_->generation; }

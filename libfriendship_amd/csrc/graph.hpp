@@ -413,7 +413,9 @@ public:
     // Brings the lowered form of the first n_slots outputs up to date and consumes the mirror's journal.
     // Throws fr::Error like lower(); the state stays consistent and the next update() throws again until the
     // graph is fixed.  The returned reference is stable for the life of this object.
-    const FlatGraph &update(Mirror &m, uint32_t n_slots);
+    // [row_lo, row_hi): only these output slots are lowered (a rank of a voice-sharded job needs nothing else); the
+    // others read as the constant 0 and are never planned.  A different range than last time lowers from scratch.
+    const FlatGraph &update(Mirror &m, uint32_t n_slots, uint32_t row_lo = 0, uint32_t row_hi = 0xFFFFFFFFu);
     uint64_t generation() const;        // bumped by every from-scratch rebuild: ids of different generations are unrelated
     bool last_was_full() const;
     uint64_t last_relowered() const;    // nodes lowered by the last update()

@@ -29,6 +29,14 @@ __global__ void busy_store4(float *dst, size_t n, float v, int iters) {
     if (i < n) dst[i] = x;
 }
 
+// the bank kernel's pattern exactly: 4-wave blocks, only wave 0 stores its 64 results (256 B) when the block's work is done
+__global__ void busy_store_wave0(float *dst, size_t n, float v, int iters) {
+    float x = v + (float)threadIdx.x;
+    for (int k = 0; k < iters; ++k) x = __builtin_fmaf(x, 1.0000001f, 0.5f);
+    size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x < 64 && i < n) dst[i] = x;
+}
+
 int main(int argc, char **argv) {
     size_t n = argc > 1 ? (size_t)std::atoll(argv[1]) : 307200;
     float *dev, *hc, *hn;
@@ -68,6 +76,16 @@ int main(int argc, char **argv) {
         for (int i = 0; i < reps; ++i) { hipLaunchKernelGGL(busy_store4, dim3(blocks), dim3(256), 0, st, t.p, n, (float)i, 6000); CK(hipStreamSynchronize(st)); }
         double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
         std::printf("busy kernel (4800 blocks) storing 4 B/lane to %-18s: %7.1f us per launch + sync\n", t.name, us);
+    }
+    for (auto &t : targets) {
+        const unsigned blocks = 4800;
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(busy_store_wave0, dim3(blocks), dim3(256), 0, st, t.p, n, 1.0f, 6000);
+        CK(hipStreamSynchronize(st));
+        const int reps = 30;
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < reps; ++i) { hipLaunchKernelGGL(busy_store_wave0, dim3(blocks), dim3(256), 0, st, t.p, n, (float)i, 6000); CK(hipStreamSynchronize(st)); }
+        double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+        std::printf("busy kernel, wave 0 of each of 4800 blocks stores 256 B to %-18s: %7.1f us per launch + sync\n", t.name, us);
     }
     // D2H alternatives for the same bytes
     {
