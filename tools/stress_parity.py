@@ -20,7 +20,11 @@ from libfriendship_amd.capi import RenderError, Renderer, RendererLib  # noqa: E
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    hip = libfriendship_amd.hip_lib()
+    if os.environ.get("FR_STRESS_LIB") == "sim":     # the host-logic simulator (CPU): planner / input store / rings, no kernels
+        import sim_tools
+        hip = sim_tools.sim_lib()
+    else:
+        hip = libfriendship_amd.hip_lib()
     oracle = RendererLib(os.path.join(ROOT, "oracle", "_build", "libfr_oracle.so"))
     bad = 0
     for seed in range(n):
@@ -30,9 +34,13 @@ def main():
         T = int(rng.integers(1, 200))
         calls = [(0, T), (T, 2 * T), (2 * T, 3 * T), (int(rng.integers(4 * T, 10**6)), None)]
         edit_after = {0, 2} if seed % 2 else set()          # odd seeds: graph edits between calls (incremental re-lowering)
-        with Renderer(oracle) as ref:
+        with Renderer(oracle) as ref, Renderer(oracle, semantics="sparkle") as ref_s:
             randgraph.install_steps(ref, steps)
+            randgraph.install_steps(ref_s, steps)
             modes = {m: Renderer(hip, mode=m) for m in ("auto", "staged", "pull")}
+            sparkle = {m: Renderer(hip, mode=m, semantics="sparkle") for m in ("auto", "pull")}   # FR_SEMANTICS_SPARKLE vs its oracle
+            for r in sparkle.values():
+                randgraph.install_steps(r, steps)
             os.environ["FR_STAGE_JIT"] = "force"          # read at renderer creation: every stage program through hipRTC
             modes["staged+jit"] = Renderer(hip, mode="staged")
             del os.environ["FR_STAGE_JIT"]
@@ -61,15 +69,26 @@ def main():
                     if not same_bits(got, exp):
                         print(f"seed {seed} mode {m} call {k}: MISMATCH")
                         bad += 1
+                if sparkle:
+                    try:
+                        exp_s = ref_s.fill_buffer(n_out, s, e, rows)
+                        for m, r in sparkle.items():
+                            if not same_bits(r.fill_buffer(n_out, s, e, rows), exp_s):
+                                print(f"seed {seed} sparkle mode {m} call {k}: MISMATCH")
+                                bad += 1
+                    except RenderError:
+                        for r in sparkle.values():
+                            r.close()
+                        sparkle = {}
                 if k in edit_after:
                     edits = randgraph.random_edits(rng, steps, int(rng.integers(1, 5)), signal_delays=bool(seed % 3))
-                    for r in list(modes.values()) + [ref]:
+                    for r in list(modes.values()) + list(sparkle.values()) + [ref, ref_s]:
                         randgraph.install_steps(r, edits)
-            for r in modes.values():
+            for r in list(modes.values()) + list(sparkle.values()):
                 r.close()
         if seed % 50 == 49:
             print(f"{seed + 1} graphs, {bad} problems", flush=True)
-    print(f"done: {n} graphs x 4 modes, {bad} problems")
+    print(f"done: {n} graphs x (4 modes + 2 under FR_SEMANTICS_SPARKLE), {bad} problems")
     return 1 if bad else 0
 
 
