@@ -250,9 +250,10 @@ __device__ __forceinline__ void bank_group(const ParamGroup &pg, uint32_t g,
 //  scalar load behind -- was built and measured SLOWER everywhere: 64 x 4096, T = 64 7.5 -> 8.4 us, 256 10.6 -> 13.3,
 //  512 17.8 -> 20.1, 1024 29.3 -> 33.0; the 32 extra SGPRs take these kernels to the register limit.
 //  profiles/r02_short_calls.txt.)
+// `first`: group 0 already requested by the caller (short calls ask for it before they wait for their time row).
 template <int F, bool FAST, bool EXACT>
 __device__ __forceinline__ void bank_wave_sum(const float *params, uint32_t ngroups, uint32_t levels,
-                                              const float (&t)[F], float (&res)[F]) {
+                                              const float (&t)[F], float (&res)[F], const ParamGroup *first = nullptr) {
     float s0[F], s1[F], s2[F], s3[F], s4[F], s5[F], s6[F], s7[F], s8[F];
 #pragma unroll
     for (int f = 0; f < F; ++f)
@@ -261,7 +262,8 @@ __device__ __forceinline__ void bank_wave_sum(const float *params, uint32_t ngro
     const_f32_ptr p = (const_f32_ptr)params;
     // two parameter groups in flight: the scalar load of group g+1 is issued before group g's math
     ParamGroup pa, pb;
-    load_group(pa, p, 0);
+    if (first) pa = *first;
+    else load_group(pa, p, 0);
     // (scalar loads return out of order, so the only usable wait is lgkmcnt(0): wait for the group
     // about to be consumed FIRST, then issue the next load so it flies under this group's ~120 VALU ops)
     for (uint32_t g = 0; g < ngroups; g += 2) {
@@ -624,19 +626,20 @@ __global__ void __launch_bounds__(64 * NW) bank_short_kernel(BankArgs a, uint32_
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t ti = (uint64_t)tile * 64u + lane;
     const bool live = ti < a.n_times;
-    const float t = bank_time(a, ti);
-    if (a.hist_dst && voice == 0u && chunk == 0u && wave == 0u && ti < a.time_valid) a.hist_dst[ti] = t;   // (every tile of voice 0)
-    const bool fast = a.fast_ok && __all(t >= 0.0f && t <= 4294967296.0f);   // the same 64 frames in every wave
-
     const uint32_t Pc = 1u << a.chunk_log2;
     const uint32_t Pw = Pc / NW, ngroups = Pw >> 3;
     uint32_t levels = 0;
     while ((1u << levels) < ngroups) ++levels;
     const float *mine = (const float *)(a.params + ((size_t)voice << a.log2_p) + (size_t)chunk * Pc + (size_t)wave * Pw);
+    ParamGroup first;                                      // requested BEFORE the time row: the two trips to memory overlap
+    load_group(first, (const_f32_ptr)mine, 0);
+    const float t = bank_time(a, ti);
+    if (a.hist_dst && voice == 0u && chunk == 0u && wave == 0u && ti < a.time_valid) a.hist_dst[ti] = t;   // (every tile of voice 0)
+    const bool fast = a.fast_ok && __all(t >= 0.0f && t <= 4294967296.0f);   // the same 64 frames in every wave
     const float tt[1] = {t};
     float r_wave[1];
-    if (fast) bank_wave_sum<1, true, false>(mine, ngroups, levels, tt, r_wave);
-    else bank_wave_sum<1, false, false>(mine, ngroups, levels, tt, r_wave);
+    if (fast) bank_wave_sum<1, true, false>(mine, ngroups, levels, tt, r_wave, &first);
+    else bank_wave_sum<1, false, false>(mine, ngroups, levels, tt, r_wave, &first);
     sm[wave][lane] = r_wave[0];
     __syncthreads();
     float r = 0.0f;
