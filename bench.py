@@ -364,7 +364,7 @@ def run():
     if extras:
         short_blocks = {}
         pf_rate = VALU_LANE_RATE / OPS_EXECUTED_PER_PF
-        for tb in (64, 512):
+        for tb in (1, 64, 512):
             base = stripe0 + (next_k + 8) * T
             for k in range(520):
                 if k == 20:
@@ -376,6 +376,11 @@ def run():
             us = (time.perf_counter() - tb0) / 500 * 1e6
             short_blocks[str(tb)] = {"us_per_call": us, "msamples_per_s": tb / us,
                                      "valu_frac": (float(V) * P * tb / pf_rate) / (us * 1e-6)}
+            if tb == 1:   # SURVEY 8d's per-sample state-streaming accounting: 16 B per partial + 4 B per voice + 4 B, per frame
+                b1 = 16.0 * V * P + 4.0 * V + 4.0
+                short_blocks["1"]["hbm_frac_state_streaming_model"] = b1 / (us * 1e-6) / (HBM_PEAK_GBS * 1e9)
+                short_blocks["1"]["note"] = ("one frame per call: the closed-form kernel reads 8 B per partial (no phase state); against the "
+                                             "survey's 16 B-per-partial model this is the fraction of 8 TB/s; launch latency, not HBM, bounds it")
             next_k += 8 + (520 * tb) // T + 1
 
     if rank != 0:
