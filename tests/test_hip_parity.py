@@ -475,6 +475,12 @@ def test_bounded_input_history(hip_lib, oracle_lib):
     test_sim_engine.test_bounded_input_history(hip_lib, oracle_lib)
 
 
+def test_bounded_history_with_banks_and_device_rows(hip_lib, oracle_lib):
+    """Sliding history + the bank kernel's own history append + device-resident rows, on the device."""
+    import test_sim_engine
+    test_sim_engine.test_bounded_history_with_banks_and_device_rows(hip_lib, oracle_lib)
+
+
 def test_ten_million_frames_in_bounded_memory(hip_lib):
     """10^7 frames (3.5 minutes of audio) through the device entry point with history_frames set: device memory in use
     stops growing after the first calls; with the reference's unbounded history it grows by 4 bytes per frame and slot."""

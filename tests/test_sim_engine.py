@@ -347,3 +347,56 @@ def test_random_graphs_sparkle_semantics(sim, oracle_lib, seed):
                     break
                 got = r.fill_buffer(n_out, start, start + T, rows)
                 assert same_bits(got, exp), f"seed {seed} {mode}: " + G.first_diff(got, exp)
+
+
+def _device_buffers(lib, n_out, T):
+    """(out buffer, row buffer, their pointers, a reader, a writer) for the device entry point: numpy on the simulator (its
+    'device' memory is host memory), torch on the GPU."""
+    if lib.path.endswith("libfr_simengine.so") or "simasan" in lib.path:
+        out = np.zeros((n_out, T), np.float32)
+        row = np.zeros(T, np.float32)
+        return out.ctypes.data, row.ctypes.data, (lambda: out.copy()), (lambda x: row.__setitem__(slice(None), x)), 0
+    import torch
+    d_out = torch.zeros((n_out, T), dtype=torch.float32, device="cuda")
+    d_row = torch.zeros(T, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def read():
+        torch.cuda.synchronize()
+        return d_out.cpu().numpy()
+    return d_out.data_ptr(), d_row.data_ptr(), read, (lambda x: d_row.copy_(torch.from_numpy(x))), stream
+
+
+def test_bounded_history_with_banks_and_device_rows(sim, oracle_lib):
+    """Bounded history where the bank kernel appends the caller's device-resident row to the history itself, while the
+    buffer slides: a voice bank plus a row that reads the time input 1500 frames back, 45 calls of 3000 frames through the
+    device entry point with history_frames = 2000 (the buffer slides about every 20 calls).  The delayed row is compared
+    with the oracle (which keeps everything) in full, the voices with the numpy restatement of the bank."""
+    V, P, T = 2, 32, 3000
+    g = synth.GraphArrays()
+    p = synth.voice_params(V, P, 3, True)
+    roots = synth.sum_tree(g, synth.partial_leaves(g, p["w"], p["amp"]).reshape(V, P))
+    g.edge(roots, 0, 0, np.arange(V, dtype=np.uint32))
+    dl = g.binop(synth.K_DELAY, synth.IN(0), synth.C(np.float32(1500.0)), 1)
+    g.edge(dl, 0, 0, V)
+    tree = g.finish(V + 1)
+    # the oracle gets only the delayed row (its cost is per output sample of every row it renders)
+    g2 = synth.GraphArrays()
+    dl2 = g2.binop(synth.K_DELAY, synth.IN(0), synth.C(np.float32(1500.0)), 1)
+    g2.edge(dl2, 0, 0, 0)
+    delay_only = g2.finish(1)
+    with Renderer(sim, history_frames=2000) as r, Renderer(oracle_lib) as ref:
+        synth.install(r, tree)
+        synth.install(ref, delay_only)
+        out_ptr, row_ptr, read, write, stream = _device_buffers(sim, V + 1, T)
+        for k in range(45):
+            t = (np.arange(k * T, (k + 1) * T) % 7919).astype(np.float32)      # a sawtooth: every call's row differs
+            write(t)
+            r.fill_buffer_device(out_ptr, V + 1, T, k * T, row_ptr, [0, T], stream)
+            got = read()
+            exp_delay = ref.fill_buffer(1, k * T, (k + 1) * T, [t])[0]
+            assert same_bits(got[V], exp_delay), f"call {k}: " + G.first_diff(got[V], exp_delay)
+            for v in range(V):
+                assert same_bits(got[v, :64], synth.bank_reference_numpy(p["w"][v], p["amp"][v], t[:64])), f"call {k} voice {v}"
+        plan = r.plan()
+        assert plan["history_frames"] == 2000 and plan["input_lookback"] == 1500 and len(plan["banks"]) == 1, plan
