@@ -382,6 +382,21 @@ def run():
                 short_blocks["1"]["note"] = ("one frame per call: the closed-form kernel reads 8 B per partial (no phase state); against the "
                                              "survey's 16 B-per-partial model this is the fraction of 8 TB/s; launch latency, not HBM, bounds it")
             next_k += 8 + (520 * tb) // T + 1
+            # the same calls alternating between two streams (separate output buffers): calls of a plan without delay state
+            # are independent, and unless the launch needs the shared chunk workspace the engine lets them overlap
+            if tb == 512 and not plan.get("rings") and not plan.get("stage_programs") and not plan.get("pull_rows"):
+                s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+                o2 = [torch.empty_like(d_out), torch.empty_like(d_out)]
+                base = stripe0 + (next_k + 8) * T
+                for k in range(520):
+                    if k == 20:
+                        torch.cuda.synchronize()
+                        tb0 = time.perf_counter()
+                    row = d_time[(k * tb) % (T - tb + 1):][:tb]
+                    hip.fill_buffer_device(o2[k % 2].data_ptr(), V, tb, base + k * tb, row.data_ptr(), [0, tb], s2[k % 2].cuda_stream)
+                torch.cuda.synchronize()
+                short_blocks[str(tb)]["two_streams_us_per_call"] = (time.perf_counter() - tb0) / 500 * 1e6
+                next_k += 8 + (520 * tb) // T + 1
 
     if rank != 0:
         if use_dist:
