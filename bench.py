@@ -333,7 +333,8 @@ def run():
         dt = time.perf_counter() - th
         hip.host_unregister(hout)
         host_api["registered_buffer"] = {"value": n_host * T / dt / 1e6, "ms_per_step": dt / n_host * 1e3,
-                                         "what": "same, output buffer page-locked once with fr_host_register (a host that reuses it)"}
+                                         "what": "same calls into a buffer the host page-locked once (fr_host_register: a host that reuses its sample "
+                                                 "buffer): the kernels store straight into it, no D2H copy"}
         next_k += n_host + 10
 
     # independent calls overlapped on two streams (an extra, never `value`)

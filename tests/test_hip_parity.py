@@ -469,6 +469,12 @@ def test_short_call_kernel_against_oracle(hip_lib, oracle_lib):
             idx += len(row)
 
 
+def test_registered_destination_is_written_directly(hip_lib, oracle_lib):
+    """fr_host_register on the device: kernels store straight into the caller's page-locked buffer."""
+    import test_sim_engine
+    test_sim_engine.test_registered_destination_is_written_directly(hip_lib, oracle_lib)
+
+
 def test_bounded_input_history(hip_lib, oracle_lib):
     """fr_config.history_frames on the device (the host-logic form is tests/test_sim_engine.py)."""
     import test_sim_engine

@@ -400,3 +400,24 @@ def test_bounded_history_with_banks_and_device_rows(sim, oracle_lib):
                 assert same_bits(got[v, :64], synth.bank_reference_numpy(p["w"][v], p["amp"][v], t[:64])), f"call {k} voice {v}"
         plan = r.plan()
         assert plan["history_frames"] == 2000 and plan["input_lookback"] == 1500 and len(plan["banks"]) == 1, plan
+
+
+def test_registered_destination_is_written_directly(sim, oracle_lib):
+    """fr_host_register: a page-locked destination is filled by the kernels themselves (no D2H copy); same bits, and a
+    buffer that merely overlaps a registered range, or an unregistered one, takes the ordinary path."""
+    V, P, T = 4, 64, 300
+    tree = synth.effects_tree(V, P, taps=2, base_delay=50.0)     # banks -> rings -> programs: every kind of writer
+    big = np.zeros((2 * V, T), np.float32)
+    with Renderer(sim) as r, Renderer(oracle_lib) as ref:
+        synth.install(r, tree)
+        synth.install(ref, tree)
+        r.host_register(big)
+        for k in range(3):
+            t = synth.time_ramp(k * T, (k + 1) * T)
+            out = big[:V] if k != 1 else np.zeros((V, T), np.float32)   # call 1 through an unregistered buffer
+            got = r.fill_buffer(V, k * T, (k + 1) * T, [t], out=out)
+            assert same_bits(got, ref.fill_buffer(V, k * T, (k + 1) * T, [t])), f"call {k}"
+        assert not big[V:].any()                                        # nothing beyond the rows asked for
+        r.host_unregister(big)
+        t = synth.time_ramp(3 * T, 4 * T)
+        assert same_bits(r.fill_buffer(V, 3 * T, 4 * T, [t], out=big[:V]), ref.fill_buffer(V, 3 * T, 4 * T, [t]))
