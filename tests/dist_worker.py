@@ -60,6 +60,17 @@ def main():
         last = [int(x) for x in e[(e[:, 1] == 0) & (e[:, 3] == V - 1)][0]]
         prev = [int(x) for x in e[(e[:, 1] == 0) & (e[:, 3] == V - 2)][0]]
         edits = [(5, [("del", last), ("add", [prev[0], 0, 0, V - 1])])]      # before call 5
+    elif case == "triangle":     # voices of a NON-template leaf (hipRTC-specialised on the device): cut by matching the sub-roots
+        V, T = 4, 64
+        g = synth.GraphArrays()
+        p = synth.voice_params(3, 128 * world, seed=5, detune=True)
+        roots = synth.sum_tree(g, synth.triangle_leaves(g, p["w"], p["amp"], am_slot=1).reshape(3, 128 * world))
+        g.edge(roots, 0, 0, np.arange(3, dtype=np.uint32))
+        d = g.binop(synth.K_SUM2, roots[0:1], g.binop(synth.K_DELAY, roots[0:1], synth.C(np.float32(37.0)), 1), 1)
+        g.edge(d, 0, 0, 3)          # voice 0 also feeds row 3 through a delay: needed by two ranks at world 2+ -> stays whole
+        tree = g.finish(V)
+        install = lambda r: synth.install(r, tree)
+        calls = [(0, T), (T, 2 * T), (500, 500 + T)]
     elif case == "random":       # arbitrary graphs (composites, signal delays, pull rows)
         import randgraph
         V, T = 5, 40
@@ -103,6 +114,10 @@ def main():
     # the edit leaves the last voice unreachable and makes voice V-2 feed rows V-2 and V-1: needed by two ranks (and then
     # rendered whole by both) when those rows have different owners
     want = V if not edits else (V - 1 if owner(V - 2) == owner(V - 1) else V - 2)
+    if case == "triangle":
+        want = plan["shard"]["split_voices"]      # (2 on the device, where the leaves get a kernel; 0 where they do not)
+        if libname == "hip" and mode == "partials" and want != 2:
+            ok, why = False, f"expected the two single-owner triangle voices to be split: {plan['shard']}"
     if ok and mode == "partials" and case != "random" and plan["shard"]["split_voices"] != want:
         ok, why = False, f"expected {want} split voices: {plan['shard']}"
     with open(os.path.join(outdir, f"rank{rank}.txt"), "w") as f:

@@ -48,13 +48,13 @@ def test_world2_gloo(oracle_lib, tmp_path, mode, case):
     launch(2, mode, "sim", case, tmp_path)
 
 
-@pytest.mark.parametrize("mode,case", [("partials", "effects"), ("voices", "random")])
+@pytest.mark.parametrize("mode,case", [("partials", "effects"), ("voices", "random"), ("partials", "triangle")])
 def test_world4_gloo(oracle_lib, tmp_path, mode, case):
     launch(4, mode, "sim", case, tmp_path)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,case", [("partials", "additive"), ("partials", "effects"), ("voices", "random")])
+@pytest.mark.parametrize("mode,case", [("partials", "additive"), ("partials", "effects"), ("voices", "random"), ("partials", "triangle")])
 def test_world2_hip_engine(hip_lib, oracle_lib, tmp_path, mode, case):
     """Two ranks sharing the one GPU of the test box; the exchange goes through pinned host memory and gloo."""
     launch(2, mode, "hip", case, tmp_path)
