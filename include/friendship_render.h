@@ -243,7 +243,7 @@ fr_status fr_fill_buffer_device(fr_renderer *r, float *d_out, uint32_t n_slots, 
 
 /* Optional: page-locks [p, p + bytes) and maps it for the device (hipHostRegister).  An `out` buffer of fr_fill_buffer
  * that lies inside a registered range is then written by the kernels themselves -- no device-to-host copy of the
- * samples at all (config C: 166 -> 153 us per call) -- for a host that REUSES its sample buffer between calls (the
+ * samples at all (config C: 166 -> 142 us per call) -- for a host that REUSES its sample buffer between calls (the
  * reference allocates a fresh Array2 per call, src/dispatch.rs:149; such a host has nothing to register).  The range
  * must stay allocated until fr_host_unregister; results are the same bits either way. */
 fr_status fr_host_register(fr_renderer *r, void *p, size_t bytes);

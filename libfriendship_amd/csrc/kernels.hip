@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tile
             float r = (sm[0][f][lane] + sm[1][f][lane]) + (sm[2][f][lane] + sm[3][f][lane]);
             if (NW == 8) r = r + ((sm[4][f][lane] + sm[5][f][lane]) + (sm[6][f][lane] + sm[7][f][lane]));
             bool live = ti < a.n_times;
-            if (live) orow[direct ? bank_out_index(a, ti) : ti] = r;
+            if (live) __builtin_nontemporal_store(r, &orow[direct ? bank_out_index(a, ti) : ti]);   // streaming store: nothing re-reads it here, and when the row lives in page-locked HOST memory (fr_host_register) the wave is released ~9 us/launch sooner
             if (MODE == 1) {
                 unsigned long long m = __ballot(live && r == 0.0f);
                 if (lane == 0) zmask[f] = m;
