@@ -156,6 +156,34 @@ struct fr_renderer {
     // input row through the mapping; 0 = the staged copies of round 1 (H2D row, D2H of the whole buffer)
     bool host_out_mapped = false, host_rows_mapped = true;
     bool host_direct = true;             // FR_HOST_DIRECT=0: registered destinations are filled by a D2H copy like any other
+    // Streamed output of the host entry point (plans whose rows all come straight from the time-major bank kernel): the
+    // kernels store into mapped pinned memory and publish a flag per finished row; the host copies rows into the
+    // caller's pageable buffer WHILE the launch is still computing the others.  FR_HOST_STREAM=0 turns it off.
+    bool host_stream = true;
+    PinnedBuf h_row_flags;               // [n_slots] u32: the call's sequence number once the row is complete
+    DevBuf d_row_done;                   // per-voice tile counters of the launch (zero between launches)
+    uint32_t host_seq = 0;
+    std::vector<uint32_t> stream_pending;
+    struct FlagOut { uint32_t *host_flags = nullptr; uint32_t *row_done = nullptr; uint32_t value = 0; } flag_out;
+    // every output row is a voice of a bank launch that can publish its completion (kernels.hpp bank_publishes_rows)?
+    bool can_stream_rows(uint32_t n_slots, uint64_t n_times) const {
+        if (!host_stream || sharded() || !plan_current(n_slots) || plan.banks.empty() || bank_leaf_variant != 1) return false;
+        if (!plan.sp.progs.empty() || plan.sp.uses_rings() || !plan.pull_rows.empty() || !plan.sp.split.empty()) return false;
+        size_t voices = 0;
+        for (const BankStage &bs : plan.banks) {
+            if (bs.grp.jit || bs.grp.general || bs.grp.to_ring || bs.grp.to_ws) return false;
+            BankArgs a{};
+            a.log2_p = bs.grp.log2_p;
+            a.n_voices = (uint32_t)bs.grp.rows.size();
+            bank_shape(a.log2_p, a.n_voices, n_times, a.chunk_log2, a.frames_per_lane, a.waves_per_group, a.small_call, a.voices_per_wave);
+            if (a.voices_per_wave && !allow_multi) { a.voices_per_wave = 0; a.frames_per_lane = 1; }
+            a.leaf_variant = 1;
+            a.host_flags = (uint32_t *)1;   // (asking "would it")
+            if (!bank_publishes_rows(a)) return false;
+            voices += bs.grp.rows.size();
+        }
+        return voices == n_slots;   // (each row is written by exactly one voice: a row fed by nothing would be a program)
+    }
     std::vector<std::pair<char *, size_t>> registered;   // fr_host_register: page-locked, device-visible host ranges
     bool host_trace = false;             // FR_HOST_TRACE=1: phase times of fr_fill_buffer on stderr at destroy
     double trace_us[3] = {0, 0, 0};
@@ -894,6 +922,12 @@ struct fr_renderer {
             }
             if (a.small_call == 1 && a.hist_dst) throw Error(FR_ERR_DEVICE, "internal: deferred history append on a short call");
             a.leaf_variant = bank_leaf_variant;
+            if (flag_out.host_flags) {
+                a.host_flags = flag_out.host_flags;
+                a.row_done = flag_out.row_done;
+                a.flag_value = flag_out.value;
+                if (!bank_publishes_rows(a)) throw Error(FR_ERR_DEVICE, "internal: a bank launch cannot publish row flags");
+            }
             if (a.chunk_log2 != a.log2_p) {
                 used_scratch = true;
                 d_bank_ws.ensure(((size_t)a.n_voices << (a.log2_p - a.chunk_log2)) * blen * sizeof(float));
@@ -1102,6 +1136,7 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     if (const char *mv = std::getenv("FR_BANK_MULTI")) r->allow_multi = mv[0] != '0';
     if (const char *tv2 = std::getenv("FR_HOST_TRACE")) r->host_trace = tv2[0] == '1';
     if (const char *dv = std::getenv("FR_HOST_DIRECT")) r->host_direct = dv[0] != '0';
+    if (const char *sv2 = std::getenv("FR_HOST_STREAM")) r->host_stream = sv2[0] != '0';
     if (const char *hv = std::getenv("FR_HOST_MAPPED")) {
         const int m = std::atoi(hv);
         r->host_out_mapped = (m & 1) != 0;
@@ -1188,6 +1223,55 @@ fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t 
         if (direct) {
             r->execute(direct, n_slots, n_times, idx, st);
             HIP_CHECK(hipStreamSynchronize(st));   // synchronous contract: dispatch.rs:150-151
+        } else if (bytes >= (64u << 10) && r->can_stream_rows(n_slots, n_times)) {
+            // Streamed: rows are copied to the caller's buffer as their flags arrive, under the rest of the launch.
+            r->h_out_stage.ensure(bytes);
+            if ((size_t)n_slots * sizeof(uint32_t) > r->h_row_flags.bytes) {
+                r->h_row_flags.ensure((size_t)n_slots * 2 * sizeof(uint32_t));
+                std::memset(r->h_row_flags.p, 0, r->h_row_flags.bytes);
+                r->host_seq = 0;
+            }
+            if ((size_t)n_slots * sizeof(uint32_t) > r->d_row_done.bytes) {
+                r->d_row_done.ensure((size_t)n_slots * 2 * sizeof(uint32_t));
+                HIP_CHECK(hipMemsetAsync(r->d_row_done.p, 0, r->d_row_done.bytes, st));
+            }
+            if (++r->host_seq == 0) {   // (wrapped: flags restart from a clean slate)
+                std::memset(r->h_row_flags.p, 0, r->h_row_flags.bytes);
+                r->host_seq = 1;
+            }
+            const uint32_t seq = r->host_seq;
+            r->flag_out.host_flags = r->h_row_flags.as_dev<uint32_t>();
+            r->flag_out.row_done = r->d_row_done.as<uint32_t>();
+            r->flag_out.value = seq;
+            struct Clear { fr_renderer *r; ~Clear() { r->flag_out = fr_renderer::FlagOut{}; } } clear{r};
+            r->execute(r->h_out_stage.as_dev<float>(), n_slots, n_times, idx, st);
+            const uint32_t *flags = r->h_row_flags.as<uint32_t>();
+            const float *stage = r->h_out_stage.as<float>();
+            r->stream_pending.resize(n_slots);
+            for (uint32_t i = 0; i < n_slots; ++i) r->stream_pending[i] = i;
+            size_t left = n_slots;
+            uint64_t idle = 0;
+            while (left) {
+                bool progress = false;
+                for (size_t i = 0; i < left;) {
+                    const uint32_t row = r->stream_pending[i];
+                    if (__atomic_load_n(flags + row, __ATOMIC_ACQUIRE) == seq) {
+                        std::memcpy(out + (size_t)row * n_times, stage + (size_t)row * n_times, n_times * sizeof(float));
+                        r->stream_pending[i] = r->stream_pending[--left];
+                        progress = true;
+                    } else {
+                        ++i;
+                    }
+                }
+                if (!progress && (++idle & 0xFFFFu) == 0 && hipStreamQuery(st) != hipErrorNotReady) {
+                    // the launch is over (or failed) and a flag never came: report rather than spin for ever
+                    HIP_CHECK(hipStreamSynchronize(st));
+                    for (size_t i = 0; i < left; ++i)
+                        if (__atomic_load_n(flags + r->stream_pending[i], __ATOMIC_ACQUIRE) != seq)
+                            throw Error(FR_ERR_DEVICE, "internal: a rendered row was never published to the host");
+                }
+            }
+            HIP_CHECK(hipStreamSynchronize(st));   // (everything is done; this only retires the launch)
         } else if (r->host_out_mapped && !gather) {
             // kernels store finished frames straight into mapped pinned memory; one wait, one copy to the caller's buffer
             r->h_out_stage.ensure(bytes);

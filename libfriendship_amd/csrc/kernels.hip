@@ -365,7 +365,9 @@ __device__ __forceinline__ uint64_t bank_out_index(const BankArgs &a, uint64_t t
 //  profiles/r01_bank_variants.txt.)
 // NW = waves per workgroup (4 or 8): a wave is the unit of work that cannot be split further, so more, smaller
 // waves shorten the kernel's tail at a given call size (measured: profiles/r01_bank_variants.txt).
-template <int F, int MODE, int NW>
+// FLAGS: publish row-completion flags to the host (BankArgs::host_flags) -- a separate instantiation, so that the few
+// scalar registers it needs never touch the occupancy of the ordinary launches.
+template <int F, int MODE, int NW, bool FLAGS = false>
 __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tiles, uint32_t nblocks) {
     // XCD-aware order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
     // contiguous range of (voice, chunk, tile) work: its L2 then sees 1/8 of the parameter streams.
@@ -421,7 +423,15 @@ __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tile
             float r = (sm[0][f][lane] + sm[1][f][lane]) + (sm[2][f][lane] + sm[3][f][lane]);
             if (NW == 8) r = r + ((sm[4][f][lane] + sm[5][f][lane]) + (sm[6][f][lane] + sm[7][f][lane]));
             bool live = ti < a.n_times;
-            if (live) __builtin_nontemporal_store(r, &orow[direct ? bank_out_index(a, ti) : ti]);   // streaming store: nothing re-reads it here, and when the row lives in page-locked HOST memory (fr_host_register) the wave is released ~9 us/launch sooner
+            // Streaming store: nothing re-reads it here, and when the row lives in page-locked HOST memory (fr_host_register)
+            // the wave is released ~9 us/launch sooner.  FLAGS: the row is read by the host BEFORE the launch ends, as soon as
+            // its flag arrives, so the store must be a system-scope one whose acknowledgement means "visible to the host"
+            // (a streaming store is acknowledged earlier: the flag overtook the data, tools/host_stream_soak.py).
+            if (live) {
+                float *dst = &orow[direct ? bank_out_index(a, ti) : ti];
+                if (FLAGS) __hip_atomic_store(dst, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else __builtin_nontemporal_store(r, dst);
+            }
             if (MODE == 1) {
                 unsigned long long m = __ballot(live && r == 0.0f);
                 if (lane == 0) zmask[f] = m;
@@ -442,7 +452,9 @@ __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tile
                     bool all = sm[0][f][lane] != 0.0f && sm[1][f][lane] != 0.0f && sm[2][f][lane] != 0.0f && sm[3][f][lane] != 0.0f;
                     if (NW == 8) all = all && sm[4][f][lane] != 0.0f && sm[5][f][lane] != 0.0f && sm[6][f][lane] != 0.0f && sm[7][f][lane] != 0.0f;
                     uint64_t ti = t0 + (uint32_t)f * 64u + lane;
-                    orow[direct ? bank_out_index(a, ti) : ti] = all ? -0.0f : 0.0f;
+                    float *dst = &orow[direct ? bank_out_index(a, ti) : ti];
+                    if (FLAGS) __hip_atomic_store(dst, all ? -0.0f : 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    else *dst = all ? -0.0f : 0.0f;
                 }
                 __syncthreads();
                 continue;
@@ -453,7 +465,24 @@ __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tile
                 uint64_t ti = t0 + (uint32_t)f * 64u + l;
                 float tz = bank_time(a, ti);
                 int all = __syncthreads_and(leaves_all_negzero(cparams, Pc, tz, threadIdx.x, 64u * NW) ? 1 : 0);
-                if (threadIdx.x == 0) orow[direct ? bank_out_index(a, ti) : ti] = all ? -0.0f : 0.0f;
+                if (threadIdx.x == 0) {
+                    float *dst = &orow[direct ? bank_out_index(a, ti) : ti];
+                    if (FLAGS) __hip_atomic_store(dst, all ? -0.0f : 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    else *dst = all ? -0.0f : 0.0f;
+                }
+            }
+        }
+    }
+    // Row-completion flag (the host entry point copies finished rows while the launch is still running).  Every output
+    // store of this workgroup was issued by wave 0; once they are acknowledged one lane counts the tile in, and the
+    // workgroup that brings a voice's count to `tiles` publishes the row's flag to the host (system-scope release).
+    if (FLAGS && a.host_flags && direct && wave == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0u) {
+            const uint32_t old = __hip_atomic_fetch_add(a.row_done + voice, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == tiles - 1u) {
+                __hip_atomic_store(a.row_done + voice, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+                __hip_atomic_store(a.host_flags + a.rows[voice], a.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -718,6 +747,13 @@ static hipError_t launch_bank_short(const BankArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Will launch_bank publish row-completion flags for these arguments (host_flags set)?  Only the time-major kernel with
+// one chunk per voice and the FMA-form leaves does.
+bool bank_publishes_rows(const BankArgs &a) {
+    return a.host_flags && !a.small_call && !a.voices_per_wave && a.leaf_variant == 1 && a.chunk_log2 == a.log2_p &&
+           (a.frames_per_lane == 1 || a.frames_per_lane == 2 || a.frames_per_lane == 4);
+}
+
 // Workgroups launch_bank uses for this shape.
 uint64_t bank_blocks(const BankArgs &a) {
     uint64_t f = a.frames_per_lane;
@@ -734,6 +770,9 @@ static hipError_t launch_bank_f(const BankArgs &a, hipStream_t s) {
     if (a.leaf_variant == 0) {
         if (w8) hipLaunchKernelGGL((bank_kernel<F, 0, 8>), dim3(nblocks), dim3(512), 0, s, a, tiles, nblocks);
         else hipLaunchKernelGGL((bank_kernel<F, 0, 4>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
+    } else if (a.leaf_variant == 1 && a.host_flags && a.chunk_log2 == a.log2_p) {   // (bank_publishes_rows)
+        if (w8) hipLaunchKernelGGL((bank_kernel<F, 1, 8, true>), dim3(nblocks), dim3(512), 0, s, a, tiles, nblocks);
+        else hipLaunchKernelGGL((bank_kernel<F, 1, 4, true>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
     } else if (a.leaf_variant == 1) {
         if (w8) hipLaunchKernelGGL((bank_kernel<F, 1, 8>), dim3(nblocks), dim3(512), 0, s, a, tiles, nblocks);
         else hipLaunchKernelGGL((bank_kernel<F, 1, 4>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);

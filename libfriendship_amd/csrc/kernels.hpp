@@ -69,6 +69,13 @@ struct BankArgs {
     uint32_t leaf_variant;     // 0 = product-form leaves; 1 = FMA-form leaves + zero-sign repair (same bits, faster)
     float *hist_dst;           // if non-null: the kernel also copies time[0..time_valid) here (input-history append)
     float *ws;                 // [P >> chunk_log2][n_voices][n_times] partial sums; unused when one chunk
+    // Row-completion flags for the host entry point (fr_fill_buffer streaming its output, engine.cpp): when host_flags is
+    // set (time-major kernel, one chunk per voice only), the workgroup that finishes the LAST tile of voice v -- counted
+    // in row_done[v], zero between launches -- stores flag_value to host_flags[rows[v]] (mapped host memory) after every
+    // output store of the voice has been acknowledged: the host may then read that row while other voices still compute.
+    uint32_t *row_done;
+    uint32_t *host_flags;
+    uint32_t flag_value;
     uint32_t *tickets;         // small_call == 2 with chunks: [n_voices][tiles] arrival counters, BANK_TICKET_STRIDE words
                                // apart, all zero between launches
     // general voices (launch_gbank): groups[i] = log2(item leaves, <= 11) | merges_after << 4; params = the items'
@@ -81,6 +88,7 @@ constexpr uint32_t BANK_TICKET_STRIDE = 32;
 void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane,
                 uint32_t &waves_per_group, uint32_t &small_call, uint32_t &voices_per_wave);
 uint64_t bank_blocks(const BankArgs &a);
+bool bank_publishes_rows(const BankArgs &a);
 hipError_t launch_bank(const BankArgs &a, hipStream_t s);
 hipError_t launch_gbank(const BankArgs &a, hipStream_t s);   // voices that are arbitrary Sum2 trees (schedule form)
 

@@ -102,6 +102,7 @@ void bank_shape(uint32_t log2_p, uint32_t, uint64_t, uint32_t &chunk_log2, uint3
     voices_per_wave = 0;
 }
 uint64_t bank_blocks(const BankArgs &a) { return ((a.n_times + 63) / 64) * a.n_voices; }
+bool bank_publishes_rows(const BankArgs &a) { return a.host_flags && !a.small_call && !a.voices_per_wave && a.leaf_variant == 1 && a.chunk_log2 == a.log2_p; }
 
 hipError_t launch_bank(const BankArgs &a, hipStream_t) {
     ++fr_sim_launches[C_BANK];
@@ -117,6 +118,8 @@ hipError_t launch_bank(const BankArgs &a, hipStream_t) {
             for (size_t k = 0; k < P; ++k) cur[k] = leaf(t, a.params[v * P + k].x, a.params[v * P + k].y);
             a.out[(size_t)a.rows[v] * a.out_stride + out_index(a, ti)] = tree(cur);
         }
+    if (a.host_flags)   // row-completion flags of the host entry point's streamed output
+        for (uint32_t v = 0; v < a.n_voices; ++v) __atomic_store_n(a.host_flags + a.rows[v], a.flag_value, __ATOMIC_RELEASE);
     return hipSuccess;
 }
 

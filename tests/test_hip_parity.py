@@ -469,6 +469,13 @@ def test_short_call_kernel_against_oracle(hip_lib, oracle_lib):
             idx += len(row)
 
 
+def test_streamed_host_output(hip_lib, oracle_lib, monkeypatch):
+    """fr_fill_buffer streaming rows out under the running launch (row-completion flags in mapped memory), on the device;
+    tools/host_stream_soak.py is the long form."""
+    import test_sim_engine
+    test_sim_engine.test_streamed_host_output(hip_lib, oracle_lib, monkeypatch)
+
+
 def test_registered_destination_is_written_directly(hip_lib, oracle_lib):
     """fr_host_register on the device: kernels store straight into the caller's page-locked buffer."""
     import test_sim_engine

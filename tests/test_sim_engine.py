@@ -421,3 +421,31 @@ def test_registered_destination_is_written_directly(sim, oracle_lib):
         r.host_unregister(big)
         t = synth.time_ramp(3 * T, 4 * T)
         assert same_bits(r.fill_buffer(V, 3 * T, 4 * T, [t], out=big[:V]), ref.fill_buffer(V, 3 * T, 4 * T, [t]))
+
+
+def test_streamed_host_output(sim, oracle_lib, monkeypatch):
+    """The host entry point's streamed output (rows copied to the caller's buffer as their completion flags arrive, while
+    the launch still computes the others) against the staged-copy path (FR_HOST_STREAM=0) and sampled oracle frames; fresh
+    destination buffers, varying call lengths, a short (padded) row, a seek."""
+    V, P = 12, 512
+    tree = synth.additive_tree(V, P, seed=4, detune=True)
+    streamed = Renderer(sim)
+    monkeypatch.setenv("FR_HOST_STREAM", "0")
+    staged = Renderer(sim)
+    monkeypatch.delenv("FR_HOST_STREAM")
+    with streamed, staged, Renderer(oracle_lib) as ref:
+        for x in (streamed, staged, ref):
+            synth.install(x, tree)
+        idx = 0
+        for k, (T, rl) in enumerate([(4800, 4800), (4800, 4700), (1500, 1500), (4800, 4800)]):
+            if k == 3:
+                idx = 10**6      # a seek
+            t = synth.time_ramp(idx, idx + rl)
+            a = streamed.fill_buffer(V, idx, idx + T, [t], out=np.full((V, T), np.float32(-3.0)))
+            b = staged.fill_buffer(V, idx, idx + T, [t], out=np.full((V, T), np.float32(-5.0)))
+            assert same_bits(a, b), f"call {k}: " + G.first_diff(a, b)
+            for c in (0, 63, 64, rl - 1, T - 1):
+                tt = t[c:c + 1] if c < rl else t[-1:]
+                exp = ref.fill_buffer(V, idx + c, idx + c + 1, [tt])
+                assert same_bits(a[:, c:c + 1], exp), f"call {k} frame {c}"
+            idx += T
