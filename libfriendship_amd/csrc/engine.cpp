@@ -155,6 +155,7 @@ struct fr_renderer {
     // FR_HOST_MAPPED (A/B): bit 0 = kernels write the output through the mapping, bit 1 = the bank kernel reads the
     // input row through the mapping; 0 = the staged copies of round 1 (H2D row, D2H of the whole buffer)
     bool host_out_mapped = false, host_rows_mapped = true;
+    size_t host_small_bytes = 96u << 10; // FR_HOST_SMALL_KB: results up to this size leave through mapped pinned memory
     bool host_direct = true;             // FR_HOST_DIRECT=0: registered destinations are filled by a D2H copy like any other
     // Streamed output of the host entry point (plans whose rows all come straight from the time-major bank kernel): the
     // kernels store into mapped pinned memory and publish a flag per finished row; the host copies rows into the
@@ -1136,6 +1137,7 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     if (const char *mv = std::getenv("FR_BANK_MULTI")) r->allow_multi = mv[0] != '0';
     if (const char *tv2 = std::getenv("FR_HOST_TRACE")) r->host_trace = tv2[0] == '1';
     if (const char *dv = std::getenv("FR_HOST_DIRECT")) r->host_direct = dv[0] != '0';
+    if (const char *kv = std::getenv("FR_HOST_SMALL_KB")) r->host_small_bytes = (size_t)std::max(0, std::atoi(kv)) << 10;
     if (const char *sv2 = std::getenv("FR_HOST_STREAM")) r->host_stream = sv2[0] != '0';
     if (const char *hv = std::getenv("FR_HOST_MAPPED")) {
         const int m = std::atoi(hv);
@@ -1223,7 +1225,7 @@ fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t 
         if (direct) {
             r->execute(direct, n_slots, n_times, idx, st);
             HIP_CHECK(hipStreamSynchronize(st));   // synchronous contract: dispatch.rs:150-151
-        } else if (bytes >= (64u << 10) && r->can_stream_rows(n_slots, n_times)) {
+        } else if (bytes >= (256u << 10) && r->can_stream_rows(n_slots, n_times)) {   // (below that one D2H is as quick)
             // Streamed: rows are copied to the caller's buffer as their flags arrive, under the rest of the launch.
             r->h_out_stage.ensure(bytes);
             if ((size_t)n_slots * sizeof(uint32_t) > r->h_row_flags.bytes) {
@@ -1272,7 +1274,10 @@ fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t 
                 }
             }
             HIP_CHECK(hipStreamSynchronize(st));   // (everything is done; this only retires the launch)
-        } else if (r->host_out_mapped && !gather) {
+        } else if ((r->host_out_mapped || bytes <= r->host_small_bytes) && !gather) {
+            // small results (a real-time block: 64 frames x 64 voices = 16 KB): the kernels store straight into mapped pinned
+            // memory and the host copies the few KB itself -- a D2H copy costs ~12 us of launch latency more than it moves
+            // (64-frame call at config C: 35 -> 23 us, tools/host_short_probe.py); large results pay for it in cold CPU reads
             // kernels store finished frames straight into mapped pinned memory; one wait, one copy to the caller's buffer
             r->h_out_stage.ensure(bytes);
             r->execute(r->h_out_stage.as_dev<float>(), n_slots, n_times, idx, st);

@@ -437,7 +437,7 @@ def test_streamed_host_output(sim, oracle_lib, monkeypatch):
         for x in (streamed, staged, ref):
             synth.install(x, tree)
         idx = 0
-        for k, (T, rl) in enumerate([(4800, 4800), (4800, 4700), (1500, 1500), (4800, 4800)]):
+        for k, (T, rl) in enumerate([(4800, 4800), (4800, 4700), (1500, 1500), (6000, 6000)]):
             if k == 3:
                 idx = 10**6      # a seek
             t = synth.time_ramp(idx, idx + rl)
