@@ -18,10 +18,11 @@ def same_bits(a, b):
     return bool(np.all((au == bu) | (np.isnan(a) & np.isnan(b))))
 
 
-def replay(rlib, test, mode="auto"):
-    """Returns [(step, rendered)] for every render step; raises RenderError on engine errors."""
+def replay(rlib, test, mode="auto", make=None):
+    """Returns [(step, rendered)] for every render step; raises RenderError on engine errors.
+    `make` = a factory of some other object with the renderer's methods (oracle/ref_numpy.py) instead of a C-ABI library."""
     out = []
-    with Renderer(rlib, mode=mode) as r:
+    with (make() if make else Renderer(rlib, mode=mode)) as r:
         for st in test["steps"]:
             op = st["op"]
             if op == "add_node":
@@ -47,8 +48,8 @@ def replay(rlib, test, mode="auto"):
     return out
 
 
-def check(rlib, test, mode="auto"):
-    for st, got in replay(rlib, test, mode):
+def check(rlib, test, mode="auto", make=None):
+    for st, got in replay(rlib, test, mode, make):
         if "expect_cols" in st:   # long renders keep only some column ranges of the expected output
             got = np.concatenate([got[:, a:b] for a, b in st["expect_cols"]], axis=1)
         exp = np.array(st["expect_bits"], dtype=np.uint32).view(np.float32).reshape(got.shape)

@@ -77,9 +77,10 @@ int main(int argc, char **argv) {
     Lowering low;
     std::unique_ptr<BankMatcher> matcher;
     uint64_t gen = 0;
-    for (int rep = 0; rep < 6; ++rep) {
+    const int reps = std::getenv("REPLAN_REPS") ? atoi(std::getenv("REPLAN_REPS")) : 6;
+    for (int rep = 0; rep < reps; ++rep) {
         if (rep > 0) {   // the edit: one partial's amplitude changes (rep 0 = the initial build)
-            size_t which = (size_t)rep * 1000 + 7;
+            size_t which = ((size_t)rep * 1000 + 7) % amp_mul.size();
             uint32_t leaf = amp_mul[which];
             m.del_edge(fr_edge{C, leaf, f32_to_bits(1.0f / (which % P + 1)), 0});
             m.add_edge(fr_edge{C, leaf, f32_to_bits(0.123f + rep), 0});

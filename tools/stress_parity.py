@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off parity stress on an MI355X: many seeded random graphs (all 7 primitives, nested composites, constant and
 signal-driven delays) through every engine mode against the CPU oracle, with contiguous calls, short rows, seeks.
-Not part of the default test suite (minutes, not seconds).   usage: python tools/stress_parity.py [n_seeds]"""
+Not part of the default test suite (minutes, not seconds).   usage: python tools/stress_parity.py [n_seeds [first_seed]]"""
 import os
 import sys
 
@@ -20,6 +20,7 @@ from libfriendship_amd.capi import RenderError, Renderer, RendererLib  # noqa: E
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     if os.environ.get("FR_STRESS_LIB") == "sim":     # the host-logic simulator (CPU): planner / input store / rings, no kernels
         import sim_tools
         hip = sim_tools.sim_lib()
@@ -27,7 +28,7 @@ def main():
         hip = libfriendship_amd.hip_lib()
     oracle = RendererLib(os.path.join(ROOT, "oracle", "_build", "libfr_oracle.so"))
     bad = 0
-    for seed in range(n):
+    for seed in range(first, first + n):
         rng = np.random.default_rng(seed)
         steps, n_out = randgraph.random_graph(10_000 + seed, n_nodes=int(rng.integers(3, 70)), n_inputs=2, n_outputs=3,
                                               signal_delays=bool(seed % 3))
