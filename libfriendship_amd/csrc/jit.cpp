@@ -5,6 +5,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <thread>
 #include <cstdio>
@@ -67,7 +69,7 @@ extern "C" __global__ void __launch_bounds__(256) jit_bank(JitBankArgs a) {
     float x[NIN > 0 ? NIN : 1];
 #pragma unroll
     for (int i = 0; i < NIN; ++i)
-        x[i] = (ti >= a.in_skip[i] && ti - a.in_skip[i] < a.in_valid[i]) ? a.in[i][ti - a.in_skip[i]] : 0.0f;
+        x[i] = (ti >= a.in_skip[i] && ti - a.in_skip[i] < a.in_valid[i]) ? a.in[i][ti - a.in_skip[i]] : jit_opaque(0.0f);
 
     const unsigned P = 1u << a.log2_p, Pw = P >> 2, ngroups = Pw >> 3, levels = a.log2_p - 5u;
     cptr p = (cptr)(a.params + ((size_t)voice * P + (size_t)wave * Pw) * K);
@@ -105,7 +107,7 @@ extern "C" __global__ void __launch_bounds__(256) jit_bank_multi(JitBankArgs a) 
     float x[NIN > 0 ? NIN : 1];
 #pragma unroll
     for (int i = 0; i < NIN; ++i)
-        x[i] = (ti >= a.in_skip[i] && ti - a.in_skip[i] < a.in_valid[i]) ? a.in[i][ti - a.in_skip[i]] : 0.0f;
+        x[i] = (ti >= a.in_skip[i] && ti - a.in_skip[i] < a.in_valid[i]) ? a.in[i][ti - a.in_skip[i]] : jit_opaque(0.0f);
     bool fast = false;
 #if HAS_MOD1
     bool in_range = a.fract_ok != 0u;
@@ -218,6 +220,10 @@ std::shared_ptr<JitKernel> JitCache::get_source(const std::string &src, const ch
         it = impl_->cache.emplace(src, std::unique_ptr<Impl::Entry>(new Impl::Entry)).first;
         Impl::Entry *e = it->second.get();
         e->fn_name = fn_name;
+        if (const char *dir = std::getenv("FR_JIT_DUMP")) {   // debugging aid: keep every generated source
+            const std::string path = std::string(dir) + "/" + fn_name + "_" + std::to_string(std::hash<std::string>{}(src)) + ".hip";
+            if (FILE *f = std::fopen(path.c_str(), "w")) { std::fwrite(src.data(), 1, src.size(), f); std::fclose(f); }
+        }
         Impl *impl = impl_;
         auto job = [impl, e, src, arch] {   // (`src` by value: the map key may outlive nothing else here)
             auto t0 = std::chrono::steady_clock::now();

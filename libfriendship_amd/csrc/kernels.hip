@@ -26,8 +26,15 @@ __device__ __forceinline__ float prim_mod(float a, float b) {
 __device__ __forceinline__ float prim_min(float a, float b, bool sparkle = false) {
     // RefRenderer: Rust >= 1.20 core f32::min: (a < b || b.is_nan()) ? a : b.
     // SparkleRenderer (sparkle.rs:495-496): select(fcmp ult a, b, a, b) -- differs only for a NaN `a` beside a number.
+    // The value selected for `b` passes through an empty asm: where the compiler can prove an operand is not NaN (a literal,
+    // or a 0.0 it has threaded in from an out-of-range read) the AMDGPU backend rewrites `x < c ? x : c` as v_min_f32, which
+    // answers -0 for the tie (-0, +0) where this rule answers `b` (found by tools/stress_parity.py in generated code with a
+    // literal zero operand; profiles/r02_stress_parity.txt).  Arms that are not the compare's operands cannot be matched.
     if (sparkle && a != a) return a;
-    return (a < b || b != b) ? a : b;
+    const bool take_a = a < b || b != b;
+    float other = b;
+    asm("" : "+v"(other));
+    return take_a ? a : other;
 }
 
 __device__ __forceinline__ float prim_binop(uint32_t op, float a, float b, bool sparkle = false) {

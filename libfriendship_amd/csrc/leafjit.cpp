@@ -11,6 +11,16 @@ namespace fr {
 
 // helpers every generated leaf may call (device functions; plain C++ otherwise)
 static const char *kLeafHelpers = R"JIT(
+// A zero the optimiser cannot see through.  With a LITERAL zero in reach this toolchain's AMDGPU backend applies folds that
+// are only valid without signed zeros -- `0.0 - y` becomes a negate modifier (-0 where IEEE gives +0 for y = +0), and
+// `x < 0.0 ? x : 0.0` becomes v_min_f32 (-0 on the tie) -- found by tools/stress_parity.py, profiles/r02_stress_parity.txt.
+// So generated code never shows the compiler a zero: constants +-0 and the zeros of out-of-range reads pass through here.
+__device__ __forceinline__ float jit_opaque(float v) {
+#if defined(__AMDGCN__)
+    asm("" : "+v"(v));
+#endif
+    return v;
+}
 __device__ __forceinline__ float jit_mod(float a, float b) {   // reference.rs:254-261
     float rem = fmodf(a, b);
     return rem < 0.0f ? rem + b : rem;
@@ -23,7 +33,12 @@ __device__ __forceinline__ float jit_min(float a, float b) {   // Rust >= 1.20 f
 #if FR_SPARKLE
     if (a != a) return a;
 #endif
-    return (a < b || b != b) ? a : b;
+    const bool take_a = a < b || b != b;
+    float other = b;   // not the compare's operand any more: `x < c ? x : c` with a non-NaN c would become v_min_f32 (-0 on ties)
+#if defined(__AMDGCN__)
+    asm("" : "+v"(other));
+#endif
+    return take_a ? a : other;
 }
 )JIT";
 
@@ -64,7 +79,11 @@ LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> 
         switch (o.op) {
         case OP_CONST:
             if (varying[o.a]) leaf << "p" << pidx[o.a];
-            else { std::snprintf(buf, sizeof buf, "__builtin_bit_cast(float, 0x%08xu)", literal_bits[o.a]); leaf << buf; }
+            else {   // (a literal zero of either sign: opaque, see jit_opaque)
+                const bool zero = (literal_bits[o.a] & 0x7FFFFFFFu) == 0;
+                std::snprintf(buf, sizeof buf, zero ? "jit_opaque(__builtin_bit_cast(float, 0x%08xu))" : "__builtin_bit_cast(float, 0x%08xu)", literal_bits[o.a]);
+                leaf << buf;
+            }
             break;
         case OP_INPUT: leaf << "x[" << o.a << "]"; dep[i] = 1u << o.a; break;
         case OP_SUM2: leaf << "v" << o.a << " + v" << o.b; break;

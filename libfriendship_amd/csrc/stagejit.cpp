@@ -13,6 +13,16 @@ static const char *kStageSkeleton = R"JIT(
 typedef unsigned int __attribute__((address_space(4))) const *cu32;
 typedef unsigned long long u64;
 
+// A zero the optimiser cannot see through.  With a LITERAL zero in reach this toolchain's AMDGPU backend applies folds that
+// are only valid without signed zeros -- `0.0 - y` becomes a negate modifier (-0 where IEEE gives +0 for y = +0), and
+// `x < 0.0 ? x : 0.0` becomes v_min_f32 (-0 on the tie) -- found by tools/stress_parity.py, profiles/r02_stress_parity.txt.
+// So generated code never shows the compiler a zero: constants +-0 and the zeros of out-of-range reads pass through here.
+__device__ __forceinline__ float jit_opaque(float v) {
+#if defined(__AMDGCN__)
+    asm("" : "+v"(v));
+#endif
+    return v;
+}
 __device__ __forceinline__ float jit_mod(float a, float b) {   // reference.rs:254-261
     float rem = fmodf(a, b);
     return rem < 0.0f ? rem + b : rem;
@@ -25,25 +35,30 @@ __device__ __forceinline__ float jit_min(float a, float b) {   // Rust >= 1.20 f
 #if FR_SPARKLE
     if (a != a) return a;
 #endif
-    return (a < b || b != b) ? a : b;
+    const bool take_a = a < b || b != b;
+    float other = b;   // not the compare's operand any more: `x < c ? x : c` with a non-NaN c would become v_min_f32 (-0 on ties)
+#if defined(__AMDGCN__)
+    asm("" : "+v"(other));
+#endif
+    return take_a ? a : other;
 }
 __device__ __forceinline__ float f32(unsigned int bits) { return __builtin_bit_cast(float, bits); }
 __device__ __forceinline__ float in_at(const JitStageArgs &a, unsigned int slot, u64 t) {
-    if (slot >= a.n_inputs) return 0.0f;
+    if (slot >= a.n_inputs) return jit_opaque(0.0f);
     JitInput s = a.n_inputs <= 8u ? a.inline_inputs[slot] : a.inputs[slot];
-    if (t < s.base || t >= s.len) return 0.0f;
+    if (t < s.base || t >= s.len) return jit_opaque(0.0f);
     return s.data[t - s.base];
 }
 __device__ __forceinline__ float in_delayed(const JitStageArgs &a, unsigned int slot, unsigned int d, u64 t) {
-    return t >= d ? in_at(a, slot, t - d) : 0.0f;
+    return t >= d ? in_at(a, slot, t - d) : jit_opaque(0.0f);
 }
 __device__ __forceinline__ float ring_read(const JitStageArgs &a, unsigned int buf, unsigned int d, u64 t) {
-    return t >= d ? a.rings[(size_t)buf * (a.ring_mask + 1) + ((t - d) & a.ring_mask)] : 0.0f;
+    return t >= d ? a.rings[(size_t)buf * (a.ring_mask + 1) + ((t - d) & a.ring_mask)] : jit_opaque(0.0f);
 }
 __device__ __forceinline__ void ring_store(const JitStageArgs &a, unsigned int buf, u64 t, float v) {
     a.rings[(size_t)buf * (a.ring_mask + 1) + (t & a.ring_mask)] = v;
 }
-__device__ __forceinline__ float step(unsigned int bits, unsigned int d, u64 t) { return t >= d ? f32(bits) : 0.0f; }
+__device__ __forceinline__ float step(unsigned int bits, unsigned int d, u64 t) { return t >= d ? f32(bits) : jit_opaque(0.0f); }
 // Delay by a signal amount (reference.rs:200-215): >= 2^64 -> the output is 0; negative / NaN -> 0 frames; else floor
 __device__ __forceinline__ bool dyn_frames(float d, u64 t, u64 &at) {
     if (d >= 18446744073709551616.0f) return false;
@@ -56,15 +71,15 @@ __device__ __forceinline__ bool dyn_frames(float d, u64 t, u64 &at) {
 }
 __device__ __forceinline__ float ring_read_dyn(const JitStageArgs &a, unsigned int buf, float d, u64 t) {
     u64 at;
-    return dyn_frames(d, t, at) ? a.rings[(size_t)buf * (a.ring_mask + 1) + (at & a.ring_mask)] : 0.0f;
+    return dyn_frames(d, t, at) ? a.rings[(size_t)buf * (a.ring_mask + 1) + (at & a.ring_mask)] : jit_opaque(0.0f);
 }
 __device__ __forceinline__ float in_delayed_dyn(const JitStageArgs &a, unsigned int slot, float d, u64 t) {
     u64 at;
-    return dyn_frames(d, t, at) ? in_at(a, slot, at) : 0.0f;
+    return dyn_frames(d, t, at) ? in_at(a, slot, at) : jit_opaque(0.0f);
 }
 __device__ __forceinline__ float step_dyn(unsigned int bits, float d, u64 t) {
     u64 at;
-    return dyn_frames(d, t, at) ? f32(bits) : 0.0f;
+    return dyn_frames(d, t, at) ? f32(bits) : jit_opaque(0.0f);
 }
 
 SHAPE_FUNCTIONS
@@ -156,7 +171,7 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
             switch (in.op) {
             case S_CONST:
                 if (s.literal[i]) {
-                    std::snprintf(buf, sizeof buf, "f32(0x%08xu)", in.imm);
+                    std::snprintf(buf, sizeof buf, (in.imm & 0x7FFFFFFFu) == 0 ? "jit_opaque(f32(0x%08xu))" : "f32(0x%08xu)", in.imm);
                     fns << buf;
                     is_one[i] = in.imm == 0x3F800000u;
                 } else { fns << "f32(P[" << k << "])"; k += 1; }

@@ -8,7 +8,7 @@ import oracle_tools
 import randgraph
 from kat_replay import same_bits
 from libfriendship_amd import synth
-from libfriendship_amd.capi import (FR_ERR_CYCLE, FR_ERR_INPUT_HISTORY, FR_ERR_INPUT_TOO_LONG, FR_ERR_NO_SUCH_NODE,
+from libfriendship_amd.capi import (FR_ERR_CYCLE, FR_ERR_INPUT_HISTORY, FR_ERR_INPUT_TOO_LONG, FR_ERR_NO_SUCH_NODE, Effect,
                                     RenderError, Renderer, f32_bits)
 
 pytestmark = pytest.mark.gpu
@@ -1318,3 +1318,71 @@ def test_jit_disabled_gives_the_same_bits(hip_lib, monkeypatch):
         y = b.fill_buffer(2, 0, T, rows)
         assert not any(bk["jit"] for bk in b.plan()["banks"])
     assert same_bits(x, y)
+
+
+# ---- Minimum beside a literal zero: the sign of the tie ---------------------------------------------------------------
+def _min_zero_steps():
+    """Six output rows: Minimum of input 0 with +0 / -0 constants on either side, and of two expressions that are zeros
+    of either sign (0 * x).  A tie between -0 and +0 goes to the RIGHT operand (`(a < b || b != b) ? a : b`), which
+    v_min_f32 does not do: found by tools/stress_parity.py in hipRTC-compiled programs, where the backend had turned the
+    select into v_min_f32 because the literal operand cannot be NaN."""
+    z, nz = f32_bits(0.0), f32_bits(-0.0)
+    steps = [("node", 1, Effect.primitive("F32Constant"))]
+    for i, (lhs, rhs) in enumerate([("x", z), ("x", nz), (z, "x"), (nz, "x")]):
+        h = 10 + i
+        steps.append(("node", h, Effect.primitive("Minimum")))
+        for slot, operand in enumerate((lhs, rhs)):
+            steps.append(("edge", 0, h, 0, slot) if operand == "x" else ("edge", 1, h, operand, slot))
+        steps.append(("edge", h, 0, 0, i))
+    # rows 4, 5: Minimum(0 * x, 0) and Minimum(0, 0 * x)
+    steps += [("node", 20, Effect.primitive("Multiply")), ("edge", 1, 20, z, 0), ("edge", 0, 20, 0, 1),
+              ("node", 21, Effect.primitive("Minimum")), ("edge", 20, 21, 0, 0), ("edge", 1, 21, z, 1), ("edge", 21, 0, 0, 4),
+              ("node", 22, Effect.primitive("Minimum")), ("edge", 1, 22, z, 0), ("edge", 20, 22, 0, 1), ("edge", 22, 0, 0, 5)]
+    return steps, 6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("semantics", ["reference", "sparkle"])
+@pytest.mark.parametrize("mode", ["auto", "staged", "staged+jit", "pull"])
+def test_minimum_beside_a_literal_zero_keeps_the_sign_of_the_tie(hip_lib, oracle_lib, monkeypatch, mode, semantics):
+    steps, n_out = _min_zero_steps()
+    x = np.array([0.0, -0.0, np.nan, 1.0, -1.0, np.inf, -np.inf, 1e-40, -1e-40, 3.5, -0.0, 0.0], np.float32)
+    if mode == "staged+jit":
+        monkeypatch.setenv("FR_STAGE_JIT", "force")
+    with Renderer(hip_lib, mode=mode.split("+")[0], semantics=semantics) as hip, Renderer(oracle_lib, semantics=semantics) as ref:
+        randgraph.install_steps(hip, steps)
+        randgraph.install_steps(ref, steps)
+        got, exp = hip.fill_buffer(n_out, 0, len(x), [x]), ref.fill_buffer(n_out, 0, len(x), [x])
+        assert same_bits(got, exp), first_diff(got, exp)
+        if mode == "staged+jit":
+            assert hip.plan()["stage_jit"], hip.plan()
+    # the rule itself, spelled out for the ties: the right operand wins
+    assert exp.view(np.uint32)[0, 1] == 0x00000000 and exp.view(np.uint32)[1, 0] == 0x80000000
+
+
+@pytest.mark.gpu
+def test_minimum_beside_a_literal_zero_in_a_compiled_voice(hip_lib, oracle_lib):
+    """The same tie inside a hipRTC-specialised bank leaf: a partial  amp * Minimum(phase - 0.5, 0)  (a half-wave: zeros
+    of both signs for half of every period), summed per voice."""
+    V, P, T = 2, 64, 400
+    g = synth.GraphArrays()
+    p = synth.voice_params(V, P, seed=77, detune=True)
+    w, amp = p["w"].ravel(), p["amp"].ravel()
+    n = len(w)
+    f = np.float32
+    ph = g.binop(synth.K_MOD, g.binop(synth.K_MUL, synth.IN(0), synth.C(w), n), synth.C(f(1.0)), n)
+    u = g.binop(synth.K_SUM2, ph, synth.C(f(-0.5)), n)
+    half = g.binop(synth.K_MIN, g.binop(synth.K_MUL, synth.C(f(0.0)), u, n), g.binop(synth.K_MIN, u, synth.C(f(0.0)), n), n)
+    leaf = g.binop(synth.K_MUL, synth.C(amp), half, n)
+    roots = synth.sum_tree(g, leaf.reshape(V, P))
+    g.edge(roots, 0, 0, np.arange(V, dtype=np.uint32))
+    tree = g.finish(V)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        for idx in (0, T, 40 * T):
+            rows = [synth.time_ramp(idx, idx + T)]
+            got, exp = hip.fill_buffer(V, idx, idx + T, rows), ref.fill_buffer(V, idx, idx + T, rows)
+            assert same_bits(got, exp), first_diff(got, exp)
+        plan = hip.plan()
+        assert plan["pull_rows"] == 0 and any(b["jit"] for b in plan["banks"]), plan

@@ -28,7 +28,8 @@ def main():
         hip = libfriendship_amd.hip_lib()
     oracle = RendererLib(os.path.join(ROOT, "oracle", "_build", "libfr_oracle.so"))
     bad = 0
-    for seed in range(first, first + n):
+    only = [int(x) for x in os.environ["FR_STRESS_SEEDS"].split(",")] if os.environ.get("FR_STRESS_SEEDS") else None
+    for seed in (only or range(first, first + n)):
         rng = np.random.default_rng(seed)
         steps, n_out = randgraph.random_graph(10_000 + seed, n_nodes=int(rng.integers(3, 70)), n_inputs=2, n_outputs=3,
                                               signal_delays=bool(seed % 3))
@@ -70,6 +71,11 @@ def main():
                     if not same_bits(got, exp):
                         print(f"seed {seed} mode {m} call {k}: MISMATCH")
                         bad += 1
+                        if only:   # details for a named seed
+                            w = np.argwhere((got.view(np.uint32) != exp.view(np.uint32)) & ~(np.isnan(got) & np.isnan(exp)))
+                            for r_, c_ in w[:6]:
+                                print(f"    row {r_} frame {s + c_}: got {got[r_, c_]!r} ({got.view(np.uint32)[r_, c_]:#x}) expected {exp[r_, c_]!r} ({exp.view(np.uint32)[r_, c_]:#x})")
+                            print(f"    {len(w)} samples differ; T={T}; plan {r.plan()}")
                 if sparkle:
                     try:
                         exp_s = ref_s.fill_buffer(n_out, s, e, rows)
