@@ -25,10 +25,10 @@ __device__ __forceinline__ float jit_mod(float a, float b) {   // reference.rs:2
     float rem = fmodf(a, b);
     return rem < 0.0f ? rem + b : rem;
 }
-__device__ __forceinline__ float jit_mod1(float a) {           // Modulo(a, 1.0): fmodf(a, 1) == a - trunc(a) exactly for finite a
-    float rem = a - truncf(a);                                  // (inf - inf = NaN, like fmodf); then the same fix-up
-    return rem < 0.0f ? rem + 1.0f : rem;
-}
+__device__ __forceinline__ float jit_mod1(float a) {           // Modulo(a, 1.0) without the generic fmodf routine:
+    float rem = __builtin_copysignf(a - truncf(a), a);          // a - trunc(a) == fmodf(a, 1) for finite a (inf - inf = NaN, like
+    return rem < 0.0f ? rem + 1.0f : rem;                        // fmodf) except that a zero comes out +0: fmodf keeps a's sign
+}                                                                // (-0 and the negative integers give -0); then the same fix-up
 __device__ __forceinline__ float jit_min(float a, float b) {   // Rust >= 1.20 f32::min; FR_SPARKLE: select(a ult b, a, b)
 #if FR_SPARKLE
     if (a != a) return a;

@@ -1008,6 +1008,10 @@ static void generated_leaves_equal_the_graph() {
         uint32_t m = b.op(FR_PRIM_MINIMUM, N(x), N(b.op(FR_PRIM_MULTIPLY, N(x), Cf(-1.0f))));       // -|x| only if x is never -0: it can be
         uint32_t r = b.op(FR_PRIM_MODULO, N(m), Cf(0.75f));
         return b.op(FR_PRIM_DIVIDE, N(r), Cf(amp + 0.5f)); }, false, false});
+    cases.push_back({"sawtooth whose phase hits -0 and the negative integers", [](Build &b, float, float amp) {
+        const float wq = 0.25f * std::round(1.0f / amp);   // quarter-integer rates: t * wq is often integral; fmodf(-3, 1) is -0
+        uint32_t ph = b.op(FR_PRIM_MODULO, N(b.op(FR_PRIM_MULTIPLY, In(0), Cf(wq))), Cf(1.0f));
+        return b.op(FR_PRIM_MULTIPLY, N(ph), Cf(amp)); }, true, false});
     for (const Case &cs : cases) {
         std::mt19937 rng(77);
         Build b;

@@ -1386,3 +1386,50 @@ def test_minimum_beside_a_literal_zero_in_a_compiled_voice(hip_lib, oracle_lib):
             assert same_bits(got, exp), first_diff(got, exp)
         plan = hip.plan()
         assert plan["pull_rows"] == 0 and any(b["jit"] for b in plan["banks"]), plan
+
+
+# ---- Modulo(x, 1.0) of -0 and of negative integers: fmodf keeps the dividend's sign -----------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["auto", "staged", "staged+jit", "pull"])
+def test_modulo_by_one_keeps_the_sign_of_a_zero_result(hip_lib, oracle_lib, monkeypatch, mode):
+    """`-3 % 1` is -0 and stays -0 (`rem < 0` is false, reference.rs:254-261).  The generated code's shortcut for a literal
+    divisor of 1.0, a - trunc(a), gave +0 (found by tools/stress_parity.py, seed 5587)."""
+    x = np.array([-0.0, 0.0, -3.0, 3.0, -1.0, -2.5, 2.5, -1e-30, 1e-30, -16777216.0, np.inf, -np.inf, np.nan, -7.0], np.float32)
+    steps = [("node", 1, Effect.primitive("F32Constant")),
+             ("node", 2, Effect.primitive("Modulo")), ("edge", 0, 2, 0, 0), ("edge", 1, 2, f32_bits(1.0), 1), ("edge", 2, 0, 0, 0),
+             # the same through a product, so that the zero's sign reaches a non-zero-free consumer: 1 / (x mod 1)
+             ("node", 3, Effect.primitive("Divide")), ("edge", 1, 3, f32_bits(1.0), 0), ("edge", 2, 3, 0, 1), ("edge", 3, 0, 0, 1)]
+    if mode == "staged+jit":
+        monkeypatch.setenv("FR_STAGE_JIT", "force")
+    with Renderer(hip_lib, mode=mode.split("+")[0]) as hip, Renderer(oracle_lib) as ref:
+        randgraph.install_steps(hip, steps)
+        randgraph.install_steps(ref, steps)
+        got, exp = hip.fill_buffer(2, 0, len(x), [x]), ref.fill_buffer(2, 0, len(x), [x])
+        assert same_bits(got, exp), first_diff(got, exp)
+    assert exp.view(np.uint32)[0, 2] == 0x80000000 and exp[1, 2] == -np.inf    # -3 mod 1 = -0; 1 / -0 = -inf
+
+
+@pytest.mark.gpu
+def test_modulo_by_one_in_a_compiled_voice_with_negative_phases(hip_lib, oracle_lib):
+    """A sawtooth partial amp * Modulo(x * w, 1) with quarter-integer rates, driven by an input that runs through negative
+    integers and zeros of both signs (the general body of the generated kernel; the v_fract body needs inputs >= +0)."""
+    V, P, T = 2, 64, 256
+    g = synth.GraphArrays()
+    n = V * P
+    w = (0.25 * (1 + np.arange(n) % P)).astype(np.float32)
+    amp = (1.0 / (1 + np.arange(n) % P)).astype(np.float32)
+    ph = g.binop(synth.K_MOD, g.binop(synth.K_MUL, synth.IN(0), synth.C(w), n), synth.C(np.float32(1.0)), n)
+    leaf = g.binop(synth.K_MUL, synth.C(amp), ph, n)
+    roots = synth.sum_tree(g, leaf.reshape(V, P))
+    g.edge(roots, 0, 0, np.arange(V, dtype=np.uint32))
+    tree = g.finish(V)
+    rng = np.random.default_rng(5)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        for k, idx in enumerate((0, T, 2 * T)):
+            x = np.round(rng.normal(size=T) * 6).astype(np.float32) * np.float32([1.0, -1.0, 0.25][k])   # integers, incl. -0 (0 * -1)
+            got, exp = hip.fill_buffer(V, idx, idx + T, [x]), ref.fill_buffer(V, idx, idx + T, [x])
+            assert same_bits(got, exp), first_diff(got, exp)
+        plan = hip.plan()
+        assert plan["pull_rows"] == 0 and any(b["jit"] for b in plan["banks"]), plan
