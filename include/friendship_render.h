@@ -224,7 +224,11 @@ fr_status fr_shard_rows(const fr_renderer *r, uint32_t n_slots, uint32_t *lo, ui
  * by the caller, src/dispatch.rs:149); every element is overwritten.  `idx` is the absolute sample
  * index of column 0; idx != previous idx+n_times is a seek (renderer.rs:12-15).  Inputs are the
  * Jagged2<f32> in CSR form: row r (feeds input slot r) = in_data[in_row_offsets[r] ..
- * in_row_offsets[r+1]); in_row_offsets has n_in_rows+1 entries.  n_in_rows == 0 allows NULLs. */
+ * in_row_offsets[r+1]); in_row_offsets has n_in_rows+1 entries.  n_in_rows == 0 allows NULLs.
+ * A call that returns an error -- where the reference panics (reference.rs:69,71) -- leaves the renderer as it was before
+ * the call: no row of it is stored, `out` is unspecified, the next call may follow as if this one had not been made.  (The
+ * reference has no "afterwards" there; it stores row by row, so a caught panic would find the rows before the offending one
+ * stored.  The CPU oracle library reproduces that half-done state; make the call after a refused one a seek when comparing.) */
 fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t n_times,
                          uint64_t idx, const float *in_data, const uint64_t *in_row_offsets,
                          uint32_t n_in_rows);
@@ -245,7 +249,8 @@ fr_status fr_fill_buffer_device(fr_renderer *r, float *d_out, uint32_t n_slots, 
  * that lies inside a registered range is then written by the kernels themselves -- no device-to-host copy of the
  * samples at all (config C: 166 -> 142 us per call) -- for a host that REUSES its sample buffer between calls (the
  * reference allocates a fresh Array2 per call, src/dispatch.rs:149; such a host has nothing to register).  The range
- * must stay allocated until fr_host_unregister; results are the same bits either way. */
+ * must stay allocated until fr_host_unregister (fr_renderer_destroy unregisters what is left); results are the same bits
+ * either way. */
 fr_status fr_host_register(fr_renderer *r, void *p, size_t bytes);
 fr_status fr_host_unregister(fr_renderer *r, void *p);
 

@@ -356,6 +356,11 @@ struct fr_renderer {
         for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
         for (Retired &g : graveyard) (void)hipEventDestroy(g.ev);
         if (ev_last) (void)hipEventDestroy(ev_last);
+        // ranges the host registered and never unregistered: the page-lock and the device mapping must not outlive the
+        // renderer that made them (the host may free that memory next; a later registration of the same addresses by
+        // another renderer would otherwise meet a stale one)
+        if (!registered.empty()) (void)hipStreamSynchronize(stream);
+        for (auto &rg : registered) { if (hipHostUnregister(rg.first) != hipSuccess) (void)hipGetLastError(); }
         if (host_trace && trace_n)
             std::fprintf(stderr, "fr_fill_buffer phases over %llu calls (mapped out %d, mapped in %d): issue %.1f us, %s %.1f us, %s %.1f us\n",
                          (unsigned long long)trace_n, (int)host_out_mapped, (int)host_rows_mapped, trace_us[0] / trace_n,

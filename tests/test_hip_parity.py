@@ -1433,3 +1433,27 @@ def test_modulo_by_one_in_a_compiled_voice_with_negative_phases(hip_lib, oracle_
             assert same_bits(got, exp), first_diff(got, exp)
         plan = hip.plan()
         assert plan["pull_rows"] == 0 and any(b["jit"] for b in plan["banks"]), plan
+
+
+@pytest.mark.gpu
+def test_registered_destination_lifecycle(hip_lib, oracle_lib):
+    """Renderers that register a small, unaligned destination and are destroyed WITHOUT unregistering it, the memory freed
+    and handed out again by the allocator to the next one (what tools/stress_calls.py did when a GPU memory fault was
+    reported): destroy drops the registration, every render lands in the buffer it was given."""
+    steps = [("node", 1, Effect.primitive("F32Constant")), ("node", 2, Effect.primitive("Sum2")),
+             ("edge", 0, 2, 0, 0), ("edge", 1, 2, f32_bits(0.5), 1), ("edge", 2, 0, 0, 0), ("edge", 0, 0, 0, 1), ("edge", 2, 0, 0, 2)]
+    with Renderer(oracle_lib) as ref:
+        randgraph.install_steps(ref, steps)
+        x = np.arange(300, dtype=np.float32)
+        exp = ref.fill_buffer(3, 0, 300, [x])
+    for i in range(40):
+        out = np.zeros((3, 300), np.float32)          # 3600 bytes from malloc: not page-aligned, reused from round to round
+        r = Renderer(hip_lib)
+        randgraph.install_steps(r, steps)
+        r.host_register(out)
+        got = r.fill_buffer(3, 0, 300, [x], out=out)
+        assert got is out and same_bits(out, exp), i
+        if i % 2:
+            r.host_unregister(out)
+        r.close()
+        del out, got

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Latency of the reference-shaped call fr_fill_buffer (host rows in, host buffer out, synchronous) for SHORT blocks --
-what a real-time host pays per audio block.  usage: python tools/host_short_probe.py [voices partials]"""
+what a real-time host pays per audio block.  usage: python tools/host_short_probe.py [voices partials [T,T,...]]
+(FR_HOST_TRACE=1 with ONE block length prints where the time goes: issue / wait / copy)"""
 import os
 import sys
 import time
@@ -16,7 +17,7 @@ r = libfriendship_amd.HipRenderer()
 synth.install(r, synth.additive_tree(V, P))
 idx = 0
 print(f"{V} x {P}, FR_HOST_MAPPED={os.environ.get('FR_HOST_MAPPED', 'default')}")
-for T in (1, 16, 64, 128, 256, 512, 1024):
+for T in ([int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else (1, 16, 64, 128, 256, 512, 1024)):
     out = np.zeros((V, T), np.float32)
     rows = [synth.time_ramp(k * T, (k + 1) * T) for k in range(8)]
     ts = []

@@ -36,10 +36,15 @@ def main():
         n_in, n_out = 3, 3
         steps, _ = randgraph.random_graph(30_000 + seed, n_nodes=int(rng.integers(3, 30)), n_inputs=n_in, n_outputs=n_out,
                                           signal_delays=bool(seed % 2))
-        engines = {"auto": Renderer(hip, mode="auto"), "staged": Renderer(hip, mode="staged"), "pull": Renderer(hip, mode="pull"),
-                   "auto, bounded history": Renderer(hip, mode="auto", history_frames=1 << 14)}
+        engines = {"auto": Renderer(hip, mode="auto"), "staged": Renderer(hip, mode="staged"), "pull": Renderer(hip, mode="pull")}
+        if not os.environ.get("FR_CALLS_NO_BOUNDED"):
+            engines["auto, bounded history"] = Renderer(hip, mode="auto", history_frames=1 << 14)
         reg_out = np.zeros((n_out, 300), np.float32)
-        engines["auto"].host_register(reg_out)
+        registered = not os.environ.get("FR_CALLS_NO_REG")
+        if registered:
+            engines["auto"].host_register(reg_out)
+        if os.environ.get("FR_CALLS_VERBOSE"):
+            print(f"seed {seed}", flush=True)
         with Renderer(oracle) as ref:
             for r in [ref] + list(engines.values()):
                 randgraph.install_steps(r, steps)
@@ -99,6 +104,8 @@ def main():
                     edits = randgraph.random_edits(rng, steps, int(rng.integers(1, 4)), n_inputs=n_in, n_outputs=n_out, signal_delays=bool(seed % 2))
                     for r in [ref] + list(engines.values()):
                         randgraph.install_steps(r, edits)
+        if registered:
+            engines["auto"].host_unregister(reg_out)
         for e in engines.values():
             e.close()
         if i % 25 == 24:
