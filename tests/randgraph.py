@@ -54,7 +54,7 @@ def random_effect(rng, depth=0, max_nodes=6):
     return Effect.graph(nodes, edges), n_in, n_out
 
 
-def random_graph(seed, n_nodes=24, n_inputs=2, n_outputs=3, signal_delays=True, composites=True):
+def random_graph(seed, n_nodes=24, n_inputs=2, n_outputs=3, signal_delays=True, composites=True, max_delay=9):
     """Returns a list of steps [('node', h, effect) | ('edge', f, t, fs, ts)] and n_outputs."""
     rng = np.random.default_rng(seed)
     steps = [("node", 1, Effect.primitive("F32Constant"))]
@@ -74,7 +74,7 @@ def random_graph(seed, n_nodes=24, n_inputs=2, n_outputs=3, signal_delays=True, 
                 continue
             force_const = kind == "Delay" and slot == 1 and not (signal_delays and rng.random() < 0.4)
             if force_const:
-                d = float(rng.integers(0, 9)) if rng.random() < 0.8 else _const(rng)
+                d = float(rng.integers(0, max_delay)) if rng.random() < 0.8 else _const(rng)   # (max_delay 9: the seeds' original stream)
                 steps.append(("edge", 1, h, f32_bits(d), slot))
             elif r < 0.3 or not avail:
                 if rng.random() < 0.6:

@@ -31,9 +31,10 @@ def main():
     only = [int(x) for x in os.environ["FR_STRESS_SEEDS"].split(",")] if os.environ.get("FR_STRESS_SEEDS") else None
     for seed in (only or range(first, first + n)):
         rng = np.random.default_rng(seed)
-        steps, n_out = randgraph.random_graph(10_000 + seed, n_nodes=int(rng.integers(3, 70)), n_inputs=2, n_outputs=3,
-                                              signal_delays=bool(seed % 3))
-        T = int(rng.integers(1, 200))
+        long_form = bool(os.environ.get("FR_STRESS_LONG"))   # calls of up to 3000 frames over delays of up to 2500: ring
+        steps, n_out = randgraph.random_graph(10_000 + seed, n_nodes=int(rng.integers(3, 40 if long_form else 70)), n_inputs=2, n_outputs=3,
+                                              signal_delays=bool(seed % 3), max_delay=2500 if long_form else 9)   # wrap, windows
+        T = int(rng.integers(1, 3000 if long_form else 200))
         calls = [(0, T), (T, 2 * T), (2 * T, 3 * T), (int(rng.integers(4 * T, 10**6)), None)]
         edit_after = {0, 2} if seed % 2 else set()          # odd seeds: graph edits between calls (incremental re-lowering)
         with Renderer(oracle) as ref, Renderer(oracle, semantics="sparkle") as ref_s:
