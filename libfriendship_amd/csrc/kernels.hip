@@ -869,6 +869,10 @@ void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &
     // 2 or 4 frames per lane amortise it (measured with tools/bank_bench: 32 partials 2.1 -> 3.2 T partial-frames/s,
     // 128 partials 5.3 -> 6.2, 512 partials 8.5 -> 8.8; at 4096 one frame per lane is best)
     if (n_times >= 1024 && blocks >= 4096) frames_per_lane = log2_p <= 7 ? 4 : (log2_p <= 9 ? 2 : 1);
+    {   // A/B switch for measurements
+        static const uint32_t f_env = [] { const char *e = std::getenv("FR_BANK_F"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+        if (f_env == 1 || f_env == 2 || f_env == 4) frames_per_lane = f_env;
+    }
     if (n_times >= 512 && blocks < 320 && log2_p >= 10) {
         // a few big voices on a long call: too few workgroups to hide the scalar-load latency of the parameter stream
         // (one 8-wave workgroup per tile leaves a SIMD with 1-2 waves).  Split the voices into chunks of >= 512 partials,
