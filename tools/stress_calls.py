@@ -48,13 +48,14 @@ def main():
         with Renderer(oracle) as ref:
             for r in [ref] + list(engines.values()):
                 randgraph.install_steps(r, steps)
-            head = 0
+            base = int(os.environ.get("FR_CALLS_BASE", "0"))   # e.g. 2**40: sample indices far beyond 32 bits (and beyond f32's integers)
+            head = base
             ok = True
             after_refusal = False
             for k in range(40):
                 T = int(rng.choice([1, 2, 7, 64, 65, 100, 300]))
                 if after_refusal or rng.random() < 0.15:      # a seek, either direction
-                    head = int(rng.choice([h for h in (int(rng.integers(0, head + 3000)), head + 1 + T) if h != head]))
+                    head = int(rng.choice([h for h in (base + int(rng.integers(0, head - base + 3000)), head + 1 + T) if h != head]))
                     after_refusal = False
                 kind = rng.random()
                 rows = []
