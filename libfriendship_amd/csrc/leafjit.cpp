@@ -1,6 +1,8 @@
 // leafjit.cpp -- source text of one shape-matched voice's leaf function (see jit.hpp).  No HIP runtime calls in this
 // file: tests/cpp/plan_tests.cpp builds the generated leaf with g++ and compares it with the graph's own evaluation.
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <sstream>
 
@@ -65,6 +67,15 @@ LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> 
         }
         return same_expr(a.a, b.a) && same_expr(a.b, b.b);
     };
+    // bound[i]: |value of op i| <= bound[i] for ANY inputs and parameters, or infinity.  (NaN is always possible and passes
+    // through either form of a fold alike.)  Used by the one arithmetic fold below.
+    std::vector<double> bound(shape.ops.size(), HUGE_VAL);
+    auto pow2_literal = [&](uint32_t i) {   // a literal +-2^k, k >= 1: multiplying by it is exact unless it overflows (+-1 is a free sign flip)
+        const LeafShape::Op &c = shape.ops[i];
+        if (c.op != OP_CONST || varying[c.a]) return false;
+        const uint32_t bits = literal_bits[c.a], e = (bits >> 23) & 0xFFu;
+        return (bits & 0x007FFFFFu) == 0 && e >= 128 && e != 255;
+    };
     auto is_literal = [&](uint32_t i, uint32_t bits) {
         const LeafShape::Op &c = shape.ops[i];
         return c.op == OP_CONST && !varying[c.a] && literal_bits[c.a] == bits;
@@ -86,7 +97,30 @@ LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> 
             }
             break;
         case OP_INPUT: leaf << "x[" << o.a << "]"; dep[i] = 1u << o.a; break;
-        case OP_SUM2: leaf << "v" << o.a << " + v" << o.b; break;
+        case OP_SUM2: {
+            // y + (+-2^k * v), k >= 1, |2^k * v| provably finite: the product is exact, so one fused multiply-add rounds the
+            // same real number the graph's two operations round -- bit for bit, zero signs included (a product that is
+            // exact keeps its sign into the sum either way).  E.g. a triangle's 1 + (-4 * |u|).
+            int prod = -1, other = -1;
+            static const bool fold = [] { const char *e = std::getenv("FR_JIT_FMA"); return !(e && e[0] == '0'); }();   // A/B switch
+            for (int side = 0; fold && side < 2 && prod < 0; ++side) {
+                const uint32_t m = side ? o.b : o.a;
+                const LeafShape::Op &mo = shape.ops[m];
+                if (mo.op != OP_MUL) continue;
+                for (int ms = 0; ms < 2; ++ms) {
+                    const uint32_t c = ms ? mo.b : mo.a, v = ms ? mo.a : mo.b;
+                    if (pow2_literal(c) && bound[v] * std::fabs((double)f32_from_bits(literal_bits[shape.ops[c].a])) <= 1e38) {
+                        prod = (int)m; other = (int)(side ? o.a : o.b);
+                        char cb[64];
+                        std::snprintf(cb, sizeof cb, "__builtin_bit_cast(float, 0x%08xu)", literal_bits[shape.ops[c].a]);
+                        leaf << "__builtin_fmaf(" << cb << ", v" << v << ", v" << other << ")";
+                        break;
+                    }
+                }
+            }
+            if (prod < 0) leaf << "v" << o.a << " + v" << o.b;
+            break;
+        }
         case OP_MUL: leaf << "v" << o.a << " * v" << o.b; break;
         case OP_DIV: leaf << "v" << o.a << " / v" << o.b; break;
         case OP_MOD: {   // a literal divisor of exactly 1.0 (every oscillator's phase wrap) avoids the generic fmodf routine
@@ -112,6 +146,19 @@ LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> 
         }
         leaf << ";\n";
         if (o.op != OP_CONST && o.op != OP_INPUT) dep[i] = dep[o.a] | dep[o.b];
+        switch (o.op) {
+        case OP_CONST: {
+            const float c = f32_from_bits(literal_bits[o.a]);
+            bound[i] = (!varying[o.a] && c == c && std::fabs(c) <= 3e38f) ? std::fabs((double)c) : HUGE_VAL;
+            break;
+        }
+        case OP_INPUT: case OP_DIV: bound[i] = HUGE_VAL; break;
+        case OP_SUM2: bound[i] = bound[o.a] + bound[o.b]; break;
+        case OP_MUL: bound[i] = (std::isinf(bound[o.a]) || std::isinf(bound[o.b])) ? HUGE_VAL : bound[o.a] * bound[o.b]; break;
+        case OP_MOD: bound[i] = 2.0 * bound[o.b]; break;   // |fmod(a, b)| < |b|, and the fix-up adds b once (a finite literal b here)
+        default: bound[i] = std::max(bound[o.a], bound[o.b]); break;   // OP_MIN
+        }
+        if (!(bound[i] <= 1e38)) bound[i] = HUGE_VAL;
         switch (o.op) {
         case OP_CONST: maybe_negzero[i] = varying[o.a] || literal_bits[o.a] == 0x80000000u; break;
         case OP_SUM2: maybe_negzero[i] = maybe_negzero[o.a] && maybe_negzero[o.b]; break;

@@ -1027,6 +1027,9 @@ static void generated_leaves_equal_the_graph() {
         LeafSource ls = generate_leaf_source(vm.shape, vm.varying, vm.literal_bits, vm.alias);
         CHECK(vm.fast_ok == cs.expect_fast);
         CHECK((ls.text.find("__builtin_fabsf") != std::string::npos) == cs.expect_abs);
+        // 1 + (-4 * |u|) of the triangle: the product by a power of two is exact, one fused multiply-add replaces both operations
+        if (std::string(cs.name).find("triangle") == 0) CHECK(ls.text.find("__builtin_fmaf(__builtin_bit_cast(float, 0xc0800000u)") != std::string::npos);
+        if (std::string(cs.name).find("N1") == 0) CHECK(ls.text.find("__builtin_fmaf") == std::string::npos);   // (nothing to fold there)
         // lowered ids of the leaves, in parameter order (left to right)
         std::vector<uint32_t> leaf_ids;
         std::function<void(uint32_t, int)> walk = [&](uint32_t id, int h) {

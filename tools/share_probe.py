@@ -2,7 +2,7 @@
 """One GPU's share of a voice-sharded job: wall time per back-to-back 4800-frame call of V voices x P partials through the
 device entry point.  The FR_* shape switches are read once per process, so a sweep starts one process per setting:
     python tools/share_probe.py sweep            # 8 / 16 / 32 voices x 4096, the settings in SWEEP
-    python tools/share_probe.py V P [T]          # one measurement with the current environment"""
+    python tools/share_probe.py V P [T [triangle]]   # one measurement with the current environment"""
 import os
 import subprocess
 import sys
@@ -24,7 +24,14 @@ def one(V, P, T):
     import libfriendship_amd
     from libfriendship_amd import synth
     hip = libfriendship_amd.HipRenderer()
-    synth.install(hip, synth.additive_tree(V, P))
+    if len(sys.argv) > 4 and sys.argv[4] == "triangle":   # a leaf the hand-written kernel does not know: hipRTC-specialised
+        g = synth.GraphArrays()
+        p = synth.voice_params(V, P, seed=P + 1, detune=True)
+        import numpy as np
+        g.edge(synth.sum_tree(g, synth.triangle_leaves(g, p["w"], p["amp"]).reshape(V, P)), 0, 0, np.arange(V, dtype=np.uint32))
+        synth.install(hip, g.finish(V))
+    else:
+        synth.install(hip, synth.additive_tree(V, P))
     d_time = torch.arange(0, 1 << 16, dtype=torch.float32, device="cuda")
     d_out = torch.empty((V, T), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
