@@ -1457,3 +1457,37 @@ def test_registered_destination_lifecycle(hip_lib, oracle_lib):
             r.host_unregister(out)
         r.close()
         del out, got
+
+
+# ---- generated leaves: y + (2^k * v) as one fused multiply-add ---------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("c_pow2,c_add,divisor,swap", [(4.0, -2.0, 1.0, False), (-4.0, 1.0, 1.0, True), (2.0, -0.0, 1.0, False),
+                                                       (-16.0, 0.0, 0.5, True), (8.0, -4.0, 0.75, False), (2.0, 1e-30, 3.0, True)])
+def test_power_of_two_fma_fold_in_compiled_voices(hip_lib, oracle_lib, c_pow2, c_add, divisor, swap):
+    """leaf = amp * (c_add + c_pow2 * Modulo(x * w, divisor)), either operand order, on an input that makes the sum cancel
+    to zero, the remainder -0 / +0 / tiny, and the phase NaN or infinite: the fused form rounds the same real number as the
+    graph's two operations, zero signs included (leafjit.cpp)."""
+    V, P, T = 2, 32, 192
+    g = synth.GraphArrays()
+    n = V * P
+    f = np.float32
+    w = (0.25 * (1 + np.arange(n) % P)).astype(f)
+    amp = (1.0 / (1 + np.arange(n) % 7)).astype(f)
+    ph = g.binop(synth.K_MOD, g.binop(synth.K_MUL, synth.IN(0), synth.C(w), n), synth.C(f(divisor)), n)
+    prod = g.binop(synth.K_MUL, ph, synth.C(f(c_pow2)), n) if swap else g.binop(synth.K_MUL, synth.C(f(c_pow2)), ph, n)
+    s = g.binop(synth.K_SUM2, prod, synth.C(f(c_add)), n) if swap else g.binop(synth.K_SUM2, synth.C(f(c_add)), prod, n)
+    leaf = g.binop(synth.K_MUL, synth.C(amp), s, n)
+    g.edge(synth.sum_tree(g, leaf.reshape(V, P)), 0, 0, np.arange(V, dtype=np.uint32))
+    tree = g.finish(V)
+    rng = np.random.default_rng(11)
+    special = np.array([0.0, -0.0, 2.0, -2.0, 0.5, -0.5, 1e-30, -1e-30, 1e30, np.inf, -np.inf, np.nan, 3.0, -7.0, 0.125, 1e-42], f)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        for k, idx in enumerate((0, T, 2 * T)):
+            x = (np.round(rng.normal(size=T) * 8) / 4).astype(f) if k < 2 else synth.time_ramp(idx, idx + T)   # quarter-integers
+            x[rng.integers(T, size=24)] = special[rng.integers(len(special), size=24)]
+            got, exp = hip.fill_buffer(V, idx, idx + T, [x]), ref.fill_buffer(V, idx, idx + T, [x])
+            assert same_bits(got, exp), first_diff(got, exp)
+        plan = hip.plan()
+        assert plan["pull_rows"] == 0 and any(b["jit"] for b in plan["banks"]), plan
