@@ -779,7 +779,7 @@ struct fr_renderer {
            << ",\"rings\":" << p.sp.n_rings << ",\"max_lookback\":" << p.sp.lmax
            << ",\"input_lookback\":" << p.sp.input_lookback << ",\"input_lookback_unbounded\":" << (p.sp.input_lookback_unbounded ? "true" : "false")
            << ",\"history_frames\":" << history_frames
-           << ",\"jit_pending\":" << (p.jit_pending ? "true" : "false") << ",\"jit_kernels_compiled\":" << jit_cache.compiled() << ",\"jit_compile_ms\":" << jit_cache.compile_ms()
+           << ",\"jit_pending\":" << (p.jit_pending ? "true" : "false") << ",\"jit_kernels_compiled\":" << jit_cache.compiled() << ",\"jit_compile_ms\":" << jit_cache.compile_ms() << ",\"jit_disk_hits\":" << jit_cache.disk_hits()
            << ",\"pull_rows\":" << p.pull_rows.size()
            << ",\"shard\":{\"rank\":" << shard.rank << ",\"world\":" << shard.world << ",\"mode\":" << (sharded() ? shard.mode : 0)
            << ",\"split_voices\":" << p.sp.split.size() << ",\"transport\":\"" << (rccl ? "rccl" : has_host_comm ? "host-callback" : "none") << "\"}"

@@ -164,6 +164,7 @@ struct JitCache::Impl {
     std::map<std::string, std::unique_ptr<Entry>> cache;
     std::atomic<uint64_t> epoch{0};
     size_t compiled = 0;
+    size_t disk_hits = 0;   // of them, code objects that came from FR_JIT_CACHE instead of the compiler
     double compile_ms = 0;
 };
 
@@ -176,6 +177,7 @@ JitCache::~JitCache() {
 uint64_t JitCache::epoch() const { return impl_->epoch.load(); }
 size_t JitCache::compiled() const { std::lock_guard<std::mutex> g(impl_->mu); return impl_->compiled; }
 double JitCache::compile_ms() const { std::lock_guard<std::mutex> g(impl_->mu); return impl_->compile_ms; }
+size_t JitCache::disk_hits() const { std::lock_guard<std::mutex> g(impl_->mu); return impl_->disk_hits; }
 
 std::shared_ptr<JitKernel> JitCache::get(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
                                          const std::vector<uint32_t> &alias) {
@@ -185,14 +187,64 @@ std::shared_ptr<JitKernel> JitCache::get(const LeafShape &shape, const std::vect
     return jk;
 }
 
+// ---- code objects kept on disk (FR_JIT_CACHE=<directory>; off when unset) --------------------------------------------
+// A host that renders the same patches day after day compiles each distinct kernel once per toolchain, not once per
+// process (~0.1 s each).  One file per kernel, named by a hash of everything the code object depends on -- architecture,
+// hipRTC version, options, source text -- and carrying that text itself: a file is used only if its text equals the
+// request's (a hash collision or a stale file is a miss, never a wrong kernel).  Written to a temporary name and
+// renamed, so a reader never sees half a file; any I/O failure just means compiling as if there were no cache.
+static const char *kJitOptions[] = {"-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+                                    "-fno-slp-vectorize", "-mllvm", "-simplifycfg-sink-common=false"};
+static std::string disk_key_text(const std::string &src, const std::string &arch) {
+    int major = 0, minor = 0;
+    (void)hiprtcVersion(&major, &minor);
+    std::string key = "fr-jit-1|" + arch + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) + "|";
+    for (const char *o : kJitOptions) { key += o; key += ' '; }
+    key += "|\n";
+    key += src;
+    return key;
+}
+static std::string disk_path(const std::string &key_text) {
+    const char *dir = std::getenv("FR_JIT_CACHE");
+    if (!dir || !dir[0]) return "";
+    uint64_t h = 1469598103934665603ull;   // FNV-1a
+    for (unsigned char c : key_text) { h ^= c; h *= 1099511628211ull; }
+    char name[40];
+    std::snprintf(name, sizeof name, "/fr_%016llx.jitbin", (unsigned long long)h);
+    return std::string(dir) + name;
+}
+static bool disk_load(const std::string &path, const std::string &key_text, std::vector<char> &code) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    uint64_t hdr[3] = {0, 0, 0};   // magic, key length, code length
+    if (std::fread(hdr, sizeof hdr, 1, f) == 1 && hdr[0] == 0x314E49424A5246ull && hdr[1] == key_text.size() && hdr[2] > 0 && hdr[2] < (1ull << 30)) {
+        std::string k(hdr[1], '\0');
+        code.resize(hdr[2]);
+        ok = std::fread(&k[0], 1, k.size(), f) == k.size() && k == key_text && std::fread(code.data(), 1, code.size(), f) == code.size();
+    }
+    std::fclose(f);
+    if (!ok) code.clear();
+    return ok;
+}
+static void disk_store(const std::string &path, const std::string &key_text, const std::vector<char> &code) {
+    const std::string tmp = path + ".tmp" + std::to_string((unsigned long long)std::hash<std::thread::id>{}(std::this_thread::get_id()));
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const uint64_t hdr[3] = {0x314E49424A5246ull, key_text.size(), code.size()};
+    const bool ok = std::fwrite(hdr, sizeof hdr, 1, f) == 1 && std::fwrite(key_text.data(), 1, key_text.size(), f) == key_text.size() &&
+                    std::fwrite(code.data(), 1, code.size(), f) == code.size();
+    if (std::fclose(f) != 0 || !ok || std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
+}
+
 // hipRTC only: source text -> code object.  No HIP runtime state is touched, so it may run on any thread.
 static void compile_source(const std::string &src, const std::string &arch, std::vector<char> &code) {
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "fr_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         throw Error(FR_ERR_DEVICE, "jit: hiprtcCreateProgram failed");
-    const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
-                          "-fno-slp-vectorize", "-mllvm", "-simplifycfg-sink-common=false"};
-    hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+    std::vector<const char *> opts{arch.c_str()};
+    for (const char *o : kJitOptions) opts.push_back(o);
+    hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     if (rc != HIPRTC_SUCCESS) {
         size_t ls = 0;
         hiprtcGetProgramLogSize(prog, &ls);
@@ -229,12 +281,19 @@ std::shared_ptr<JitKernel> JitCache::get_source(const std::string &src, const ch
             auto t0 = std::chrono::steady_clock::now();
             std::vector<char> code;
             std::string error;
+            bool from_disk = false;
             try {
-                compile_source(src, arch, code);
+                const std::string key_text = disk_key_text(src, arch), path = disk_path(key_text);
+                from_disk = !path.empty() && disk_load(path, key_text, code);
+                if (!from_disk) {
+                    compile_source(src, arch, code);
+                    if (!path.empty()) disk_store(path, key_text, code);
+                }
             } catch (const std::exception &ex) {
                 error = ex.what();
             }
             std::lock_guard<std::mutex> g(impl->mu);
+            if (from_disk) ++impl->disk_hits;
             e->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             e->code = std::move(code);
             e->error = std::move(error);

@@ -128,6 +128,7 @@ public:
     uint64_t epoch() const;        // bumped whenever a background compile finishes (successfully or not)
     size_t compiled() const;
     double compile_ms() const;
+    size_t disk_hits() const;   // kernels whose code object came from FR_JIT_CACHE
 
 private:
     struct Impl;

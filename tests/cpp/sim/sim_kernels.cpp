@@ -222,6 +222,7 @@ JitCache::~JitCache() {}
 uint64_t JitCache::epoch() const { return 0; }
 size_t JitCache::compiled() const { return 0; }
 double JitCache::compile_ms() const { return 0; }
+size_t JitCache::disk_hits() const { return 0; }
 std::shared_ptr<JitKernel> JitCache::get(const LeafShape &, const std::vector<bool> &, const std::vector<uint32_t> &, const std::vector<uint32_t> &) {
     throw Error(FR_ERR_DEVICE, "jit: not available in the host-logic simulator");
 }

@@ -1491,3 +1491,62 @@ def test_power_of_two_fma_fold_in_compiled_voices(hip_lib, oracle_lib, c_pow2, c
             assert same_bits(got, exp), first_diff(got, exp)
         plan = hip.plan()
         assert plan["pull_rows"] == 0 and any(b["jit"] for b in plan["banks"]), plan
+
+
+# ---- compiled kernels kept on disk (FR_JIT_CACHE) -----------------------------------------------------------------------
+@pytest.mark.gpu
+def test_compiled_kernels_are_reused_from_disk(hip_lib, oracle_lib, tmp_path, monkeypatch):
+    """With FR_JIT_CACHE set, a second renderer -- a second process in real life -- loads the code object the first one
+    compiled instead of running hipRTC again: same bits, `jit_disk_hits` in the plan, first-call time without the ~0.1 s
+    compile.  A file whose recorded source text differs (a stale or colliding entry) is ignored."""
+    import time
+    monkeypatch.setenv("FR_JIT_CACHE", str(tmp_path))
+    tree = _triangle_tree(2, 64, True, False)
+    T = 128
+    rows = [synth.time_ramp(0, T), np.linspace(-1, 1, T).astype(np.float32)]
+    with Renderer(oracle_lib) as ref:
+        synth.install(ref, tree)
+        exp = ref.fill_buffer(2, 0, T, rows)
+    took = []
+    for attempt in range(3):
+        # (within one process every renderer has its own kernel cache: the second and third load the file the first wrote)
+        with Renderer(hip_lib) as hip:
+            synth.install(hip, tree)
+            t0 = time.perf_counter()
+            got = hip.fill_buffer(2, 0, T, rows)
+            took.append(time.perf_counter() - t0)
+            assert same_bits(got, exp)
+            plan = hip.plan()
+            assert plan["jit_kernels_compiled"] >= 1
+    files = sorted(tmp_path.glob("fr_*.jitbin"))
+    assert len(files) == 1, files                         # one kernel, written once
+    # a second process: ask a child interpreter to render the same thing and report where its kernel came from
+    import subprocess, sys, json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = (
+        f"import sys, json, numpy as np; sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})\n"
+        "import test_hip_parity as t, libfriendship_amd\n"
+        "from libfriendship_amd import synth\n"
+        "from libfriendship_amd.capi import Renderer\n"
+        "tree = t._triangle_tree(2, 64, True, False)\n"
+        "rows = [synth.time_ramp(0, 128), np.linspace(-1, 1, 128).astype(np.float32)]\n"
+        "with Renderer(libfriendship_amd.hip_lib()) as hip:\n"
+        "    synth.install(hip, tree)\n"
+        "    out = hip.fill_buffer(2, 0, 128, rows)\n"
+        "    p = hip.plan()\n"
+        "print(json.dumps({'hits': p['jit_disk_hits'], 'compiled': p['jit_kernels_compiled'], 'ms': p['jit_compile_ms'], 'sum': float(np.nansum(out))}))\n"
+    )
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=300, env=dict(os.environ, FR_JIT_CACHE=str(tmp_path)))
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["hits"] == 1 and rep["compiled"] == 1 and rep["ms"] < 50.0, rep      # loaded, not compiled (~110 ms)
+    assert rep["sum"] == float(np.nansum(exp))
+    # a corrupted entry is a miss: flip a byte of the recorded source text, the child compiles again and rewrites the file
+    data = bytearray(files[0].read_bytes())
+    data[24 + 40] ^= 0x20
+    files[0].write_bytes(bytes(data))
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=300, env=dict(os.environ, FR_JIT_CACHE=str(tmp_path)))
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["hits"] == 0 and rep["compiled"] == 1 and rep["sum"] == float(np.nansum(exp)), rep
