@@ -4,6 +4,7 @@ signal-driven delays) through every engine mode against the CPU oracle, with con
 Not part of the default test suite (minutes, not seconds).   usage: python tools/stress_parity.py [n_seeds [first_seed]]"""
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -40,18 +41,23 @@ def main():
         with Renderer(oracle) as ref, Renderer(oracle, semantics="sparkle") as ref_s:
             randgraph.install_steps(ref, steps)
             randgraph.install_steps(ref_s, steps)
-            modes = {m: Renderer(hip, mode=m) for m in ("auto", "staged", "pull")}
+            # FR_STRESS_ASYNC=1: the ABI's default -- hipRTC on a worker thread.  The first calls run on the interpreters, the
+            # tool then waits out the compile and the following calls find the plan switched over (rings rebuilt): same bits.
+            sync = not os.environ.get("FR_STRESS_ASYNC")
+            modes = {m: Renderer(hip, mode=m, sync_compile=sync) for m in ("auto", "staged", "pull")}
             sparkle = {m: Renderer(hip, mode=m, semantics="sparkle") for m in ("auto", "pull")}   # FR_SEMANTICS_SPARKLE vs its oracle
             for r in sparkle.values():
                 randgraph.install_steps(r, steps)
             os.environ["FR_STAGE_JIT"] = "force"          # read at renderer creation: every stage program through hipRTC
-            modes["staged+jit"] = Renderer(hip, mode="staged")
+            modes["staged+jit"] = Renderer(hip, mode="staged", sync_compile=sync)
             del os.environ["FR_STAGE_JIT"]
             for r in modes.values():
                 randgraph.install_steps(r, steps)
             for k, (s, e) in enumerate(calls):
                 e = e if e is not None else s + T
                 n_t = e - s
+                if not sync and k in (1, 3):
+                    time.sleep(0.14)
                 rows = [synth.time_ramp(s, e)[: n_t if k != 1 else int(rng.integers(0, n_t + 1))],
                         (rng.normal(size=n_t) * 3).astype(np.float32)]
                 try:
