@@ -511,7 +511,11 @@ def run():
             chk.close()
             result["parity"] = {"frames_checked": args.cpu_frames, "voices": V,
                                 "bit_exact": bool(np.array_equal(got.view(np.uint32), cpu_out.view(np.uint32))),
-                                "device_entry_bit_exact": bool(np.array_equal(got_dev.view(np.uint32), cpu_out.view(np.uint32)))}
+                                "device_entry_bit_exact": bool(np.array_equal(got_dev.view(np.uint32), cpu_out.view(np.uint32))),
+                                "against": "oracle/ref_renderer.cpp, a C++ restatement of RefRenderer (the Rust reference cannot be built here); "
+                                           "pinned by the reference's own 11 tests / 14 arrays (1 x 4 samples each) and cross-checked by an "
+                                           "independent numpy restatement; unpinned by any reference vector and therefore assumptions: "
+                                           "f32::min on ties / NaN, NaN as u64, everything oscillator-shaped (DESIGN.md section 2)"}
         except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
             result["cpu_baseline"] = {"error": repr(e)}
     result["checksum"] = float(np.abs(last[row_lo:row_hi].astype(np.float64)).sum())
