@@ -215,6 +215,11 @@ typedef struct fr_shard {
 /* ncclGetUniqueId through the engine, so that a host needs no RCCL binding of its own: call on one rank,
  * hand the bytes to the others by any means, pass them to fr_set_shard on every rank. */
 fr_status fr_comm_unique_id(uint8_t id[FR_COMM_ID_BYTES]);
+/* Diagnostic: one exchange of n_floats through the RCCL transport on `device` (-1 = current) with this rank as its own
+ * peer (a communicator of one rank; ncclSend + ncclRecv to self inside one group, on a stream), received data compared with
+ * what was sent.  Exercises the binding -- library lookup, symbols, argument order, datatype, stream -- on a machine with a
+ * single GPU, where the exchange of a sharded job can never run.  FR_OK, or FR_ERR_COMM / FR_ERR_DEVICE. */
+fr_status fr_comm_selftest(int32_t device, uint64_t n_floats);
 /* Collective when rccl_id is given (ncclCommInitRank): every rank calls it.  NULL or world <= 1 unshards. */
 fr_status fr_set_shard(fr_renderer *r, const fr_shard *shard);
 /* The block of output rows [*lo, *hi) this renderer owns when n_slots rows are rendered. */

@@ -190,6 +190,8 @@ class RendererLib:
         L.fr_host_register.restype = C.c_int32
         L.fr_host_unregister.argtypes = [vp, vp]
         L.fr_host_unregister.restype = C.c_int32
+        L.fr_comm_selftest.argtypes = [C.c_int32, C.c_uint64]
+        L.fr_comm_selftest.restype = C.c_int32
         L.fr_comm_unique_id.argtypes = [P(C.c_uint8)]
         L.fr_comm_unique_id.restype = C.c_int32
         if L.fr_abi_version() != FR_ABI_VERSION:
@@ -201,6 +203,12 @@ class RendererLib:
 
     def status_string(self, s):
         return self.lib.fr_status_string(s).decode()
+
+    def comm_selftest(self, n_floats=1 << 16, device=-1):
+        """One exchange through the RCCL transport with this rank as its own peer (fr_comm_selftest)."""
+        st = self.lib.fr_comm_selftest(device, n_floats)
+        if st != FR_OK:
+            raise RenderError(st, self.status_string(st), "fr_comm_selftest")
 
     def comm_unique_id(self):
         """ncclGetUniqueId through the engine: 128 bytes to hand to every rank's set_shard(rccl_id=...)."""

@@ -1382,6 +1382,38 @@ fr_status fr_comm_unique_id(uint8_t id[FR_COMM_ID_BYTES]) {
     }
 }
 
+fr_status fr_comm_selftest(int32_t device, uint64_t n_floats) {
+    if (n_floats == 0 || n_floats > (1ull << 28)) return FR_ERR_INVALID_ARG;
+    float *d_send = nullptr, *d_recv = nullptr;
+    hipStream_t st = nullptr;
+    fr_status rc = FR_OK;
+    try {
+        if (device >= 0) HIP_CHECK(hipSetDevice(device));
+        uint8_t id[FR_COMM_ID_BYTES];
+        rccl_unique_id(id);
+        std::unique_ptr<Transport> t = make_rccl_transport(id, 0, 1);
+        HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIP_CHECK(hipMalloc((void **)&d_send, n_floats * sizeof(float)));
+        HIP_CHECK(hipMalloc((void **)&d_recv, n_floats * sizeof(float)));
+        std::vector<float> h(n_floats), back(n_floats, -1.0f);
+        for (uint64_t i = 0; i < n_floats; ++i) h[i] = (float)(i % 8191) * 0.25f - 3.0f;
+        HIP_CHECK(hipMemcpyAsync(d_send, h.data(), n_floats * sizeof(float), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemsetAsync(d_recv, 0xFF, n_floats * sizeof(float), st));
+        t->sendrecv(0, d_send, n_floats, d_recv, n_floats, st);
+        HIP_CHECK(hipMemcpyAsync(back.data(), d_recv, n_floats * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (std::memcmp(h.data(), back.data(), n_floats * sizeof(float)) != 0) rc = FR_ERR_COMM;
+    } catch (const Error &e) {
+        rc = e.code;
+    } catch (...) {
+        rc = FR_ERR_DEVICE;
+    }
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (d_send) (void)hipFree(d_send);
+    if (d_recv) (void)hipFree(d_recv);
+    return rc;
+}
+
 fr_status fr_set_shard(fr_renderer *r, const fr_shard *sh) {
     return guarded(r, [&] {
         HIP_CHECK(hipSetDevice(r->device));

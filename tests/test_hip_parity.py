@@ -545,6 +545,14 @@ def test_rccl_is_loadable_and_hands_out_an_id(hip_lib):
     assert len(a) == 128 and a != b and any(a)
 
 
+def test_rccl_exchange_with_itself(hip_lib):
+    """fr_comm_selftest: a communicator of one rank, ncclSend + ncclRecv to itself in one group on a stream, through the very
+    Transport::sendrecv the partial-block exchange uses -- as much of the RCCL path as one GPU can run (every size class:
+    a few floats, a frame block, a 4800-frame x 256-voice slab)."""
+    for n in (7, 4800, 4800 * 256):
+        hip_lib.comm_selftest(n)
+
+
 # ---- boundary behaviour on the HIP engine ---------------------------------------------------------------
 def test_hip_error_codes(hip_lib):
     with Renderer(hip_lib) as r:
