@@ -100,8 +100,34 @@ struct Matcher {
         return L;
     }
 
-    // Collects the leaves of a complete Sum2 tree of the given height rooted at id.
+    // Collects the leaves of a complete Sum2 tree of the given height rooted at id.  Sub-trees of 64 leaves are remembered
+    // by node id: after an edit inside a voice (hash-consing gives every node on the path from the edited leaf to the root
+    // a new id and leaves all others alone) 63 of a 4096-leaf voice's 64 sub-trees are copied instead of walked
+    // (re-planning after one changed amplitude at config C: 0.80 -> 0.62 ms, tools/replan_bench.cpp).
+    struct SubTree { bool ok = false, fast_ok = true; uint32_t slot = 0; std::vector<float> params; };
+    static constexpr uint32_t SUB_H = 6;
+    std::unordered_map<uint32_t, SubTree> sub_memo;
     bool collect(uint32_t id, uint32_t height, std::vector<float> &params, uint32_t &slot, bool &first, bool &fast_ok) {
+        if (height == SUB_H) {
+            auto it = sub_memo.find(id);
+            if (it == sub_memo.end()) {
+                SubTree st;
+                bool f = true;
+                const FlatNode &x = n(id);
+                st.params.reserve(2u << SUB_H);
+                st.ok = x.op == OP_SUM2 && collect(x.a, height - 1, st.params, st.slot, f, st.fast_ok) &&
+                        collect(x.b, height - 1, st.params, st.slot, f, st.fast_ok);
+                if (!st.ok) { st.params.clear(); st.params.shrink_to_fit(); }
+                it = sub_memo.emplace(id, std::move(st)).first;
+            }
+            const SubTree &st = it->second;
+            if (!st.ok) return false;
+            if (first) { slot = st.slot; first = false; }
+            else if (slot != st.slot) return false;
+            params.insert(params.end(), st.params.begin(), st.params.end());
+            if (!st.fast_ok) fast_ok = false;
+            return true;
+        }
         if (height == 0) {
             Leaf L = match_leaf(id);
             if (!L.ok) return false;
@@ -399,7 +425,7 @@ void BankMatcher::retain_used() {
     for (auto &kv : memo_) live += used_.count(kv.first) ? 1 : 0;
     if (memo_.size() <= 2 * live + 64) return;
     std::unordered_map<uint32_t, int64_t> memo;
-    std::vector<VoiceMatch> found;
+    std::deque<VoiceMatch> found;
     for (auto &kv : memo_) {
         if (!used_.count(kv.first)) continue;
         if (kv.second < 0) { memo.emplace(kv.first, -1); continue; }

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <cstdint>
+#include <deque>
 #include <unordered_map>
 #include <vector>
 
@@ -45,7 +46,8 @@ public:
     BankMatcher &operator=(const BankMatcher &) = delete;
     // Is the expression rooted at `root` a voice?  Results (including failures) are memoised per node.
     bool try_voice(uint32_t root, VoiceMatch &out);
-    // The same without the copy: the memoised match, or null.  The pointer is valid until the next match()/try_voice().
+    // The same without the copy: the memoised match, or null.  The pointer stays valid until retain_used() (matches live in
+    // a deque: later matches do not move earlier ones), so a plan may hold it while it is being made.
     const VoiceMatch *match(uint32_t root);
     // A matcher kept across plans of the same (append-only, hash-consed) FlatGraph answers repeated roots from its
     // memo.  begin_plan() .. retain_used() bracket one plan: entries no plan has asked for since are dropped once
@@ -62,7 +64,7 @@ private:
     bool allow_jit_;
     bool allow_template_;   // false (FR_BANK_TEMPLATE=0, A/B runs only): skip the hand-matched partial template
     std::unordered_map<uint32_t, int64_t> memo_;   // root -> index into found_, or -1
-    std::vector<VoiceMatch> found_;
+    std::deque<VoiceMatch> found_;
     std::unordered_map<uint32_t, bool> used_;      // roots asked for since begin_plan()
 };
 

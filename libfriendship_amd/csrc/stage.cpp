@@ -32,7 +32,7 @@ struct Planner {
     const FlatGraph &g;
     BankMatcher *matcher;   // null: no fused banks
     std::unordered_map<uint32_t, int8_t> supported_memo;
-    std::unordered_map<uint32_t, VoiceMatch> bank_of;     // node -> voice
+    std::unordered_map<uint32_t, const VoiceMatch *> bank_of;   // node -> voice (owned by the matcher: 32 KB of parameters each at config C)
     std::unordered_set<uint32_t> cut;                     // program cut nodes (non-bank)
     std::unordered_set<uint32_t> visited;
 
@@ -125,9 +125,9 @@ struct Planner {
     bool is_voice(uint32_t n) {
         if (!matcher || g.nodes[n].op != OP_SUM2) return false;
         if (bank_of.count(n)) return true;
-        VoiceMatch vm;
-        if (!matcher->try_voice(n, vm)) return false;
-        bank_of.emplace(n, std::move(vm));
+        const VoiceMatch *vm = matcher->match(n);
+        if (!vm) return false;
+        bank_of.emplace(n, vm);
         return true;
     }
 
@@ -186,8 +186,7 @@ struct Planner {
 
 // Adds a voice to the launch that shares its kind (balanced: partial count; general: all together), time slot
 // and destination kind.
-void add_voice(std::vector<BankLaunch> &banks, std::unordered_map<std::string, size_t> &grp, const VoiceMatch &vm, uint32_t row, bool ring,
-               bool ws = false) {
+std::string voice_key(const VoiceMatch &vm, bool ring, bool ws) {
     std::string key = std::to_string(vm.general ? 63u : vm.log2_p) + "/" + std::to_string(vm.input_slot) + (vm.general ? "g" : "") + (ring ? "r" : "") + (ws ? "w" : "");
     if (vm.jit) {   // same generated source (shape, which columns vary, literal values) and same inputs share a launch
         key += "j" + vm.shape.key();
@@ -195,6 +194,14 @@ void add_voice(std::vector<BankLaunch> &banks, std::unordered_map<std::string, s
         for (size_t c = 0; c < vm.varying.size(); ++c)
             key += vm.varying[c] ? ("v" + std::to_string(vm.alias[c])) : ("l" + std::to_string(vm.literal_bits[c]));
     }
+    return key;
+}
+
+// `totals` (optional): parameter floats each launch will hold in the end, so that its array is allocated once -- grown by
+// doubling, a megabyte of parameters costs a second megabyte of first-touch page faults on every re-plan.
+void add_voice(std::vector<BankLaunch> &banks, std::unordered_map<std::string, size_t> &grp, const VoiceMatch &vm, uint32_t row, bool ring,
+               bool ws = false, const std::unordered_map<std::string, size_t> *totals = nullptr) {
+    const std::string key = voice_key(vm, ring, ws);
     auto gi = grp.find(key);
     if (gi == grp.end()) {
         gi = grp.emplace(key, banks.size()).first;
@@ -202,6 +209,10 @@ void add_voice(std::vector<BankLaunch> &banks, std::unordered_map<std::string, s
         bl.log2_p = vm.log2_p; bl.input_slot = vm.input_slot; bl.to_ring = ring; bl.to_ws = ws; bl.general = vm.general;
         if (vm.general) { bl.group_off.push_back(0); bl.group_off.push_back(0); }
         if (vm.jit) { bl.jit = true; bl.shape = vm.shape; bl.varying = vm.varying; bl.literal_bits = vm.literal_bits; bl.alias = vm.alias; bl.k = vm.k; }
+        if (totals) {
+            auto ti = totals->find(key);
+            if (ti != totals->end()) bl.params.reserve(ti->second);
+        }
         banks.push_back(std::move(bl));
     }
     BankLaunch &bl = banks[gi->second];
@@ -430,7 +441,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
             if (!mine(row)) continue;
             auto it = P.bank_of.find(g.outputs[row]);
             if (it == P.bank_of.end()) { fb.pull_rows.push_back(row); continue; }
-            const VoiceMatch &vm = it->second;
+            const VoiceMatch &vm = *it->second;
             add_voice(fb.banks, grp, vm, row, false);
         }
         std::sort(fb.pull_rows.begin(), fb.pull_rows.end());
@@ -526,8 +537,10 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         while ((1u << kbits) < world) ++kbits;
         struct Split { uint32_t key, node; SplitVoice sv; VoiceMatch sub; };
         std::vector<Split> splits;
+        struct Add { const VoiceMatch *vm; uint32_t dst; bool ring; };
+        std::vector<Add> adds;
         for (uint32_t n : bank_nodes) {
-            const VoiceMatch &vm = P.bank_of[n];
+            const VoiceMatch &vm = *P.bank_of[n];
             bool ring = needs_ring.count(n) != 0;
             auto ro = rows_of.find(n);
             if (!ring && ro == rows_of.end()) continue;   // unreachable
@@ -580,11 +593,14 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
             if (!ring) {
                 auto mr = my_rows_of.find(n);
                 if (mr == my_rows_of.end()) continue;
-                add_voice(sp.banks, grp, vm, mr->second[0], false);
+                adds.push_back(Add{&vm, mr->second[0], false});
             } else {
-                add_voice(sp.banks, grp, vm, ring_of[n], true);
+                adds.push_back(Add{&vm, ring_of[n], true});
             }
         }
+        std::unordered_map<std::string, size_t> totals;
+        for (const Add &a : adds) totals[voice_key(*a.vm, a.ring, false)] += a.vm->params.size();
+        for (const Add &a : adds) add_voice(sp.banks, grp, *a.vm, a.dst, a.ring, false, &totals);
         std::stable_sort(splits.begin(), splits.end(), [](const Split &a, const Split &b) { return a.key != b.key ? a.key < b.key : a.node < b.node; });
         for (size_t i = 0; i < splits.size(); ++i) {
             sp.split.push_back(splits[i].sv);

@@ -15,7 +15,9 @@ using namespace fr;
 using Clock = std::chrono::steady_clock;
 static double ms(Clock::time_point a) { return std::chrono::duration<double, std::milli>(Clock::now() - a).count(); }
 
+#include <malloc.h>
 int main(int argc, char **argv) {
+    if (getenv("REPLAN_NOMMAP")) { mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); }
     uint32_t V = argc > 1 ? atoi(argv[1]) : 64, P = argc > 2 ? atoi(argv[2]) : 4096;
     const bool effects = argc > 3 && std::string(argv[3]) == "effects";
     Mirror m;
