@@ -21,6 +21,7 @@
 #include <cmath>
 #include <functional>
 #include <unordered_map>
+#include <unordered_set>
 
 namespace fr {
 namespace {
@@ -107,6 +108,7 @@ struct Matcher {
     struct SubTree { bool ok = false, fast_ok = true; uint32_t slot = 0; std::vector<float> params; };
     static constexpr uint32_t SUB_H = 6;
     std::unordered_map<uint32_t, SubTree> sub_memo;
+    size_t sub_live = 0;   // entries the last pruning pass found in use (BankMatcher::retain_used)
     bool collect(uint32_t id, uint32_t height, std::vector<float> &params, uint32_t &slot, bool &first, bool &fast_ok) {
         if (height == SUB_H) {
             auto it = sub_memo.find(id);
@@ -421,6 +423,28 @@ BankMatcher::~BankMatcher() { delete impl_; }
 void BankMatcher::begin_plan() { used_.clear(); }
 
 void BankMatcher::retain_used() {
+    // remembered 64-leaf sub-trees: every edit inside a voice adds one (the edited one's new id); keep those the voices of
+    // this plan are made of once the others outnumber them
+    if (impl_->sub_memo.size() > 2 * impl_->sub_live + 4096) {   // (the walk below is not free: only when it can pay)
+        std::unordered_set<uint32_t> live_sub;
+        for (auto &kv : memo_) {
+            if (kv.second < 0 || !used_.count(kv.first)) continue;
+            const VoiceMatch &vm = found_[(size_t)kv.second];
+            if (vm.general || vm.jit || vm.log2_p < Impl::SUB_H) continue;
+            std::vector<uint32_t> level{kv.first};
+            for (uint32_t h = vm.log2_p; h > Impl::SUB_H; --h) {
+                std::vector<uint32_t> next;
+                next.reserve(level.size() * 2);
+                for (uint32_t id : level) { next.push_back(g_.nodes[id].a); next.push_back(g_.nodes[id].b); }
+                level.swap(next);
+            }
+            live_sub.insert(level.begin(), level.end());
+        }
+        if (impl_->sub_memo.size() > 2 * live_sub.size() + 1024)
+            for (auto it = impl_->sub_memo.begin(); it != impl_->sub_memo.end();)
+                it = live_sub.count(it->first) ? std::next(it) : impl_->sub_memo.erase(it);
+        impl_->sub_live = live_sub.size();
+    }
     size_t live = 0;
     for (auto &kv : memo_) live += used_.count(kv.first) ? 1 : 0;
     if (memo_.size() <= 2 * live + 64) return;
