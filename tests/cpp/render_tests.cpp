@@ -236,6 +236,90 @@ static void load_multby2() {
     std::filesystem::remove_all(dir);
 }
 
+// ---- the effect files this repository ships (effects/*.fnd, written by effects/make_effects.py) -----------------------
+// Every file is found through the host's ResMan by the sha256 of its bytes and instantiated as ONE composite node; the
+// same definition is then read back and its nodes placed at top level of a second graph (each of the effect's inputs wired
+// to the same source); both graphs render two contiguous ranges from the same external rows and must agree bit for bit.
+// (Which bits those are is the parity tests' business: tests/test_hip_parity.py renders composites of the same shapes on
+// the HIP engine against the oracle.)
+static std::string slurp(const std::string &path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot read " + path);
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+static void shipped_effect_files() {
+    const std::string dir = (std::filesystem::path(__FILE__).parent_path() / ".." / ".." / "effects").lexically_normal().string();
+    struct Src { bool external; uint32_t slot; float value; };   // what feeds input k of the effect
+    struct Case { const char *file, *name; std::vector<Src> in; };
+    const std::vector<Case> cases = {
+        {"partial.fnd", "Partial", {{true, 0, 0}, {false, 0, 0.0123f}, {false, 0, 0.7f}}},
+        {"triangle.fnd", "TrianglePartial", {{true, 0, 0}, {false, 0, 0.031f}, {false, 0, 0.4f}}},
+        {"envelope.fnd", "Envelope", {{true, 0, 0}, {true, 1, 0}}},
+        {"tap.fnd", "Tap", {{true, 1, 0}, {false, 0, 0.5f}, {false, 0, 3.0f}}},
+        {"voice4.fnd", "Voice4", {{true, 0, 0}, {false, 0, 0.004f}}},
+    };
+    for (const Case &cs : cases) {
+        const std::string text = slurp(dir + "/" + cs.file);
+        const auto sha = friendship::sha256(text);
+        const EffectDesc desc = EffectDesc::from_json_string(text);
+        if (desc.to_json_string() != text) throw std::runtime_error(std::string(cs.file) + ": not in the canonical wire form");
+        if (desc.meta.id.name != cs.name || desc.meta.inputs_.size() != cs.in.size()) throw std::runtime_error(std::string(cs.file) + ": unexpected meta");
+        auto [inst, rx_i] = test_setup();
+        auto [flat, rx_f] = test_setup();
+        const auto const_hnd = NodeHandle::make(5000);
+        for (TestDispatch *d : {&inst, &flat}) {
+            d->dispatch(OscResMan::AddDir{dir});
+            d->dispatch(OscRouteGraph::AddNode{const_hnd, const_id()});
+        }
+        auto source_edge = [&](const Src &s, NodeHandle to, uint32_t to_slot) {
+            return s.external ? Edge::new_from_null(to, EdgeWeight::make(s.slot, to_slot))
+                              : Edge::make(const_hnd, to, EdgeWeight::make(f32_to_bits(s.value), to_slot));
+        };
+        // (a) one composite node, looked up by hash
+        const auto hnd = NodeHandle::make(1);
+        inst.dispatch(OscRouteGraph::AddNode{hnd, EffectId::make(cs.name, sha, {})});
+        for (uint32_t k = 0; k < cs.in.size(); ++k) inst.dispatch(OscRouteGraph::AddEdge{source_edge(cs.in[k], hnd, k)});
+        inst.dispatch(OscRouteGraph::AddEdge{Edge::new_to_null(hnd, EdgeWeight::make(0, 0))});
+        // (b) the definition's own nodes at top level
+        const uint32_t off = 100;
+        for (auto &hn : desc.adjlist.nodes) flat.dispatch(OscRouteGraph::AddNode{NodeHandle::make(off + hn.first.node_handle), hn.second});
+        for (const Edge &e : desc.adjlist.edges) {
+            const NodeHandle to = e.to.is_toplevel() ? NodeHandle::toplevel() : NodeHandle::make(off + e.to.node_handle);
+            if (e.from.is_toplevel()) {
+                if (e.to.is_toplevel()) throw std::runtime_error("input wired straight to output: not in these files");
+                flat.dispatch(OscRouteGraph::AddEdge{source_edge(cs.in.at(e.weight.from_slot), to, e.weight.to_slot)});
+            } else {
+                flat.dispatch(OscRouteGraph::AddEdge{Edge::make(NodeHandle::make(off + e.from.node_handle), to, e.weight)});
+            }
+        }
+        bool any_nonzero = false;
+        for (auto range : {std::pair<uint64_t, uint64_t>{0, 64}, {64, 200}}) {
+            const size_t n = (size_t)(range.second - range.first);
+            std::vector<float> ramp(n), noise(n);
+            for (size_t i = 0; i < n; ++i) {
+                const uint64_t t = range.first + i;
+                ramp[i] = (float)t;
+                noise[i] = (float)(int)((t * 2654435761u >> 7) % 2001u) / 1000.0f - 1.0f;
+            }
+            Array2 got[2];
+            int which = 0;
+            for (auto pr : {std::pair<TestDispatch *, Channel>{&inst, rx_i}, {&flat, rx_f}}) {
+                Jagged2 rows;
+                rows.extend(ramp.data(), n);
+                rows.extend(noise.data(), n);
+                pr.first->dispatch(render_range(range.first, range.second, 1, rows));
+                got[which++] = recv(pr.second);
+            }
+            if (got[0].data.size() != n || got[1].data.size() != n || std::memcmp(got[0].data.data(), got[1].data.data(), n * sizeof(float)) != 0)
+                throw std::runtime_error(std::string(cs.file) + ": the instance and its definition placed at top level render different bits");
+            for (float v : got[0].data) any_nonzero = any_nonzero || v != 0.0f;
+        }
+        if (!any_nonzero) throw std::runtime_error(std::string(cs.file) + ": rendered nothing but zeros");
+    }
+}
+
 // The wire shape serde derives for EffectDesc, byte for byte, and its round trip.
 static void effect_desc_json() {
     auto desc = create_multby2();
@@ -367,7 +451,7 @@ int main(int argc, char **argv) {
         {"render_mult", render_mult}, {"render_sum2", render_sum2}, {"render_div", render_div},
         {"render_mod", render_mod}, {"render_min", render_min},
         {"ext_render_passthrough", ext_render_passthrough}, {"ext_render_delay", ext_render_delay},
-        {"load_multby2", load_multby2}, {"effect_desc_json", effect_desc_json},
+        {"load_multby2", load_multby2}, {"shipped_effect_files", shipped_effect_files}, {"effect_desc_json", effect_desc_json},
         {"routegraph_validation", routegraph_validation}, {"mpsc_client_and_queries", mpsc_client_and_queries}};
     int failed = 0, ran = 0;
     for (auto &t : tests) {
