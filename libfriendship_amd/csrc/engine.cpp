@@ -1383,7 +1383,7 @@ fr_status fr_comm_unique_id(uint8_t id[FR_COMM_ID_BYTES]) {
 }
 
 fr_status fr_comm_selftest(int32_t device, uint64_t n_floats) {
-    if (n_floats == 0 || n_floats > (1ull << 28)) return FR_ERR_INVALID_ARG;
+    if (n_floats == 0 || n_floats > (1ull << 26)) return FR_ERR_INVALID_ARG;   // (256 MB each way is plenty for a check)
     float *d_send = nullptr, *d_recv = nullptr;
     hipStream_t st = nullptr;
     fr_status rc = FR_OK;
