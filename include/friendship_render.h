@@ -250,6 +250,21 @@ fr_status fr_fill_buffer_device(fr_renderer *r, float *d_out, uint32_t n_slots, 
                                 uint64_t idx, const float *d_in_data,
                                 const uint64_t *in_row_offsets, uint32_t n_in_rows, void *stream);
 
+/* Block streaming, for a host that renders short blocks back to back in real time.  Through fr_fill_buffer every block pays
+ * for a kernel launch -- ~12 us from enqueue to first wave on this stack, 22 us host to host for a 64-frame block whose
+ * arithmetic takes 1.3 us.  fr_stream_begin launches ONE kernel that stays resident; fr_stream_block then hands it a block
+ * of 1..64 frames through a doorbell in mapped memory and returns when the rows have arrived in `out` ([n_slots, n_times],
+ * row-major): same bits as fr_fill_buffer(out, n_slots, n_times, idx, row, {0, row_len}, 1) renders for these frames.
+ * Served: plans that are one bank of balanced template voices, one voice per output row, at most 256 workgroups' worth
+ * (FR_ERR_UNSUPPORTED otherwise -- render such graphs with fr_fill_buffer).  `row` is the block's input row for slot 0
+ * (shorter than n_times: padded with its last value, reference.rs:72-73); such plans read no other input and no history.
+ * ANY other call on the renderer (an edit, fr_fill_buffer, fr_stream_end) first retires the resident launch; the frames
+ * streamed in between were not stored, so the call after that is a seek (reference.rs:52-58).  The kernel ends itself
+ * if no block arrives for about a second (fr_stream_block then returns FR_ERR_DEVICE: begin again). */
+fr_status fr_stream_begin(fr_renderer *r, uint32_t n_slots);
+fr_status fr_stream_block(fr_renderer *r, float *out, uint64_t n_times, uint64_t idx, const float *row, uint64_t row_len);
+fr_status fr_stream_end(fr_renderer *r);
+
 /* Optional: page-locks [p, p + bytes) and maps it for the device (hipHostRegister).  An `out` buffer of fr_fill_buffer
  * that lies inside a registered range is then written by the kernels themselves -- no device-to-host copy of the
  * samples at all (config C: 166 -> 142 us per call) -- for a host that REUSES its sample buffer between calls (the

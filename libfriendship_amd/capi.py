@@ -190,6 +190,12 @@ class RendererLib:
         L.fr_host_register.restype = C.c_int32
         L.fr_host_unregister.argtypes = [vp, vp]
         L.fr_host_unregister.restype = C.c_int32
+        L.fr_stream_begin.argtypes = [C.c_void_p, C.c_uint32]
+        L.fr_stream_begin.restype = C.c_int32
+        L.fr_stream_block.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.fr_stream_block.restype = C.c_int32
+        L.fr_stream_end.argtypes = [C.c_void_p]
+        L.fr_stream_end.restype = C.c_int32
         L.fr_comm_selftest.argtypes = [C.c_int32, C.c_uint64]
         L.fr_comm_selftest.restype = C.c_int32
         L.fr_comm_unique_id.argtypes = [P(C.c_uint8)]
@@ -227,6 +233,7 @@ class Renderer:
         what tests and benchmarks want); False = the ABI's default, compile on a worker thread and switch over when ready."""
         self.rlib = rlib
         self.L = rlib.lib
+        self._stream_slots = 0
         cfg = fr_config(FR_ABI_VERSION, device, MODES[mode] if isinstance(mode, str) else mode, FR_CONFIG_SYNC_COMPILE if sync_compile else 0,
                         SEMANTICS[semantics] if isinstance(semantics, str) else semantics, 0, history_frames)
         h = C.c_void_p()
@@ -257,6 +264,23 @@ class Renderer:
     def _check(self, st):
         if st != FR_OK:
             raise RenderError(st, self.rlib.status_string(st), self.L.fr_last_error(self.h).decode())
+
+    # --- block streaming (fr_stream_*): one resident launch serves blocks of up to 64 frames ---
+    def stream_begin(self, n_slots):
+        self._check(self.L.fr_stream_begin(self.h, n_slots))
+        self._stream_slots = n_slots
+
+    def stream_block(self, start, row, out=None):
+        """Render the frames [start, start + len(row)) of every slot from the block's input row (float32)."""
+        row = np.ascontiguousarray(row, dtype=np.float32)
+        n = len(row)
+        if out is None:
+            out = np.empty((self._stream_slots, n), dtype=np.float32)
+        self._check(self.L.fr_stream_block(self.h, out.ctypes.data, n, start, row.ctypes.data, n))
+        return out
+
+    def stream_end(self):
+        self._check(self.L.fr_stream_end(self.h))
 
     def host_register(self, array):
         """Page-lock a numpy buffer the caller reuses as `out=` / input rows (fr_host_register)."""

@@ -331,6 +331,20 @@ struct fr_renderer {
     bool timing = false;
     // A/B switches (environment, read at create; defaults are the measured best):
     uint32_t bank_leaf_variant = 1;      // FR_BANK_LEAF=0: product-form leaves (kernels.hpp BankArgs::leaf_variant)
+    // Block streaming (fr_stream_*): one resident launch renders 64-frame blocks on a doorbell (kernels.hpp BankStreamCtl)
+    bool streaming = false;
+    uint32_t stream_seq = 0, stream_slots = 0;
+    uint64_t stream_head = 0;
+    PinnedBuf h_stream_ctl, h_stream_out;
+    DevBuf d_stream_dev;
+    void end_stream() {
+        if (!streaming) return;
+        BankStreamCtl *ctl = (BankStreamCtl *)h_stream_ctl.p;
+        for (int i = 0; i < 64; ++i) __atomic_store_n(&ctl->row[i], (unsigned long long)BANK_STREAM_STOP << 32, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(stream);      // the kernel sees the stop within a poll, or ends itself after its bound
+        streaming = false;
+        head = UINT64_MAX;                       // the streamed frames were not stored: whatever comes next is a seek
+    }
     bool allow_jit = true;               // FR_JIT=0: no hipRTC specialisation (those voices run as programs / pull)
     bool allow_template = true;          // FR_BANK_TEMPLATE=0: template voices go through the JIT path literally
     bool allow_multi = true;             // FR_BANK_MULTI=0: never the whole-voices-per-wave kernel for small voices
@@ -351,6 +365,7 @@ struct fr_renderer {
 
     ~fr_renderer() {
         (void)hipSetDevice(device);
+        end_stream();
         for (TimerClass *tc : {&t_bank, &t_pull, &t_stage})
             for (auto &pr : tc->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
@@ -1078,9 +1093,10 @@ struct fr_renderer {
 namespace {
 
 template <class F>
-fr_status guarded(fr_renderer *r, F &&f) {
+fr_status guarded(fr_renderer *r, F &&f, bool keeps_stream = false) {
     if (!r) return FR_ERR_INVALID_ARG;
     try {
+        if (r->streaming && !keeps_stream) r->end_stream();   // any other call first retires the resident launch
         f();
         r->last_error.clear();
         return FR_OK;
@@ -1380,6 +1396,99 @@ fr_status fr_comm_unique_id(uint8_t id[FR_COMM_ID_BYTES]) {
     } catch (const Error &e) {
         return e.code;
     }
+}
+
+// ---- block streaming ------------------------------------------------------------------------------------------------------
+fr_status fr_stream_begin(fr_renderer *r, uint32_t n_slots) {
+    return guarded(r, [&] {
+        HIP_CHECK(hipSetDevice(r->device));
+        if (n_slots == 0) throw Error(FR_ERR_INVALID_ARG, "no output slots");
+        if (r->sharded()) throw Error(FR_ERR_UNSUPPORTED, "block streaming of a sharded renderer");
+        r->order_after_previous(r->stream);
+        r->ensure_plan(n_slots, r->stream);
+        const StagedPlan &sp = r->plan.sp;
+        // what one resident launch can serve: every row straight from one balanced template voice, nothing stored between calls
+        if (!r->plan_is_stateless(n_slots) || r->plan.banks.size() != 1)
+            throw Error(FR_ERR_UNSUPPORTED, "block streaming needs a plan that is one voice bank (this one: " + std::to_string(r->plan.banks.size()) + " bank launches, " +
+                                                std::to_string(sp.progs.size()) + " programs, " + std::to_string(r->plan.pull_rows.size()) + " pull rows" +
+                                                (sp.uses_rings() ? ", rings" : "") + (r->plan_current(n_slots) ? "" : ", plan not current") + ")");
+        const BankStage &bs = r->plan.banks[0];
+        if (bs.grp.general || bs.grp.jit || bs.grp.to_ring || bs.grp.to_ws || bs.grp.rows.size() != n_slots || !sp.pull_rows.empty())
+            throw Error(FR_ERR_UNSUPPORTED, "block streaming needs balanced template voices, one per output row");
+        if (r->bank_leaf_variant != 1) throw Error(FR_ERR_UNSUPPORTED, "block streaming with FR_BANK_LEAF=0");
+        if (bs.grp.log2_p < 7) throw Error(FR_ERR_UNSUPPORTED, "block streaming needs voices of at least 128 partials (16 waves x one group of 8)");
+        BankArgs a{};
+        a.params = bs.d_params.as<float2>();
+        a.rows = bs.d_rows.as<uint32_t>();
+        a.n_voices = n_slots;
+        a.log2_p = bs.grp.log2_p;
+        a.n_times = 64;
+        a.fast_ok = bs.grp.fast_ok ? 1u : 0u;
+        a.leaf_variant = 1;
+        a.small_call = 2;
+        a.waves_per_group = 16;
+        a.frames_per_lane = 1;
+        uint32_t c = a.log2_p;                    // chunks of >= 128 partials (a wave needs a group of 8) until the 256 workgroups are used
+        while (c > 7 && ((uint64_t)n_slots << (a.log2_p - c + 1)) <= BANK_STREAM_WGS && a.log2_p - c < 8) --c;
+        a.chunk_log2 = c;
+        if (((uint64_t)n_slots << (a.log2_p - c)) > BANK_STREAM_WGS) throw Error(FR_ERR_UNSUPPORTED, "block streaming serves at most 256 voices");
+        if (c != a.log2_p) {
+            r->d_bank_ws.ensure(((size_t)n_slots << (a.log2_p - c)) * 64 * sizeof(float));
+            a.ws = r->d_bank_ws.as<float>();
+            const size_t need = (size_t)n_slots * BANK_TICKET_STRIDE * sizeof(uint32_t);
+            if (need > r->d_tickets.bytes) {
+                r->d_tickets.ensure(need * 2);
+                HIP_CHECK(hipMemsetAsync(r->d_tickets.p, 0, r->d_tickets.bytes, r->stream));
+            }
+            a.tickets = r->d_tickets.as<uint32_t>();
+        }
+        r->h_stream_ctl.ensure(sizeof(BankStreamCtl));
+        r->h_stream_out.ensure((size_t)n_slots * 64 * sizeof(float));
+        r->d_stream_dev.ensure(sizeof(BankStreamDev));
+        std::memset(r->h_stream_ctl.p, 0, sizeof(BankStreamCtl));
+        HIP_CHECK(hipMemsetAsync(r->d_stream_dev.p, 0, sizeof(BankStreamDev), r->stream));
+        a.out = r->h_stream_out.as_dev<float>();
+        a.out_stride = 64;
+        HIP_CHECK(launch_bank_stream(a, r->h_stream_ctl.as_dev<BankStreamCtl>(), r->d_stream_dev.as<BankStreamDev>(), r->stream));
+        r->streaming = true;
+        r->stream_seq = 0;
+        r->stream_slots = n_slots;
+        r->last_pending = false;
+    });
+}
+
+fr_status fr_stream_block(fr_renderer *r, float *out, uint64_t n_times, uint64_t idx, const float *row, uint64_t row_len) {
+    return guarded(r, [&] {
+        if (!r->streaming) throw Error(FR_ERR_INVALID_ARG, "no stream is open (fr_stream_begin; any other call on the renderer closes it)");
+        if (!out || n_times == 0 || n_times > 64 || row_len > n_times || (row_len && !row)) throw Error(FR_ERR_INVALID_ARG, "a streamed block is 1..64 frames");
+        (void)idx;   // (a plan served here reads nothing but this block's row: the position does not enter the result)
+        BankStreamCtl *ctl = (BankStreamCtl *)r->h_stream_ctl.p;
+        // the row, padded with its last value like a short row of fill_buffer (reference.rs:72-73; no row: zeros), every
+        // word tagged with the block's number and length: the words are the doorbell (kernels.hpp BankStreamCtl)
+        r->stream_seq = (r->stream_seq + 1u) & 0xFFFFFFu;
+        if (r->stream_seq == 0 || r->stream_seq == 0xFFFFFFu) r->stream_seq = 1;
+        const uint32_t seq = r->stream_seq << 8 | (uint32_t)n_times;
+        for (uint64_t i = 0; i < 64; ++i) {
+            const float v = i < row_len ? row[i] : (row_len && i < n_times ? row[row_len - 1] : 0.0f);
+            uint32_t bits;
+            std::memcpy(&bits, &v, 4);
+            __atomic_store_n(&ctl->row[i], (unsigned long long)seq << 32 | bits, __ATOMIC_RELAXED);
+        }
+        uint64_t spins = 0;
+        while (__atomic_load_n(&ctl->done, __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 0xFFFFFu) == 0 && hipStreamQuery(r->stream) != hipErrorNotReady) {   // the launch is gone (its own bound, or a fault)
+                (void)hipStreamSynchronize(r->stream);
+                r->streaming = false;
+                throw Error(FR_ERR_DEVICE, "the resident launch ended before the block was rendered");
+            }
+        }
+        const float *res = r->h_stream_out.as<float>();
+        for (uint32_t v = 0; v < r->stream_slots; ++v) std::memcpy(out + (size_t)v * n_times, res + (size_t)v * 64, n_times * sizeof(float));
+    }, true);
+}
+
+fr_status fr_stream_end(fr_renderer *r) {
+    return guarded(r, [&] { HIP_CHECK(hipSetDevice(r->device)); });   // (guarded() itself retires the launch)
 }
 
 fr_status fr_comm_selftest(int32_t device, uint64_t n_floats) {

@@ -754,6 +754,175 @@ static hipError_t launch_bank_short(const BankArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Block streaming: the short-call kernel as ONE resident launch (kernels.hpp, BankStreamCtl).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) bank_stream_kernel(BankArgs a, BankStreamCtl *ctl, BankStreamDev *dev) {
+    constexpr int NW = 16;
+    __shared__ float sm[NW][64];
+    __shared__ unsigned long long zshared;
+    __shared__ uint32_t s_seq, s_T;
+    const uint32_t clog = a.log2_p - a.chunk_log2, nchunks = 1u << clog;
+    const uint32_t chunk = blockIdx.x & (nchunks - 1u);
+    const uint32_t voice = blockIdx.x >> clog;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t Pc = 1u << a.chunk_log2;
+    const uint32_t Pw = Pc / NW, ngroups = Pw >> 3;
+    uint32_t levels = 0;
+    while ((1u << levels) < ngroups) ++levels;
+    const bool working = voice < a.n_voices;                 // (spare workgroups only follow the doorbell, to end with the rest)
+    const float *mine = (const float *)(a.params + ((size_t)(working ? voice : 0u) << a.log2_p) + (size_t)chunk * Pc + (size_t)wave * Pw);
+    const size_t vstride = (size_t)a.n_voices * 64u;
+    uint32_t seen = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&ctl->alive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (;;) {
+        // ---- wait for the next block (bounded) ----
+        if (blockIdx.x == 0) {
+            if (wave == 0u) {
+                uint32_t tag = seen;
+                float v = 0.0f;
+                bool fresh = false;
+                for (uint32_t spin = 0; spin < (1u << 21); ++spin) {         // ~1 us per look across PCIe: about a second in all
+                    const unsigned long long word = __hip_atomic_load(&ctl->row[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    tag = (uint32_t)(word >> 32);
+                    v = __uint_as_float((uint32_t)word);
+                    fresh = __all(tag != seen) && __builtin_amdgcn_readfirstlane(tag) == tag;   // every lane holds the same new tag
+                    fresh = __all(fresh);
+                    if (fresh) break;
+                }
+                const uint32_t seq = fresh ? __builtin_amdgcn_readfirstlane(tag) : BANK_STREAM_STOP;   // nobody rang: end
+                uint32_t T = 0;
+                if (seq != BANK_STREAM_STOP) {
+                    T = seq & 0xFFu;
+                    T = T > 64u ? 64u : T;
+                    __hip_atomic_store(&dev->row[lane], lane < T ? v : 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (lane == 0u) {
+                    __hip_atomic_store(&dev->n_times, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&dev->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (row and n_times are acknowledged)
+                    s_seq = seq;
+                    s_T = T;
+                }
+            }
+        } else if (threadIdx.x == 0) {
+            uint32_t seq = seen;
+            for (uint32_t spin = 0; spin < (1u << 27); ++spin) {             // (device memory: ~0.3 us per look; outlasts workgroup 0's bound)
+                seq = __hip_atomic_load(&dev->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seq != seen) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (seq == seen) seq = BANK_STREAM_STOP;
+            s_seq = seq;
+            s_T = __hip_atomic_load(&dev->n_times, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const uint32_t seq = s_seq, T = s_T;
+        if (seq == BANK_STREAM_STOP) break;
+        seen = seq;
+        if (working) {
+            // ---- one (voice, chunk) of one tile, as bank_short_kernel ----
+            const bool live = lane < T;
+            ParamGroup first;
+            load_group(first, (const_f32_ptr)mine, 0);
+            const float t = live ? __hip_atomic_load(&dev->row[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+            const bool fast = a.fast_ok && __all(t >= 0.0f && t <= 4294967296.0f);
+            const float tt[1] = {t};
+            float r_wave[1];
+            if (fast) bank_wave_sum<1, true, false>(mine, ngroups, levels, tt, r_wave, &first);
+            else bank_wave_sum<1, false, false>(mine, ngroups, levels, tt, r_wave, &first);
+            sm[wave][lane] = r_wave[0];
+            __syncthreads();
+            float r = 0.0f;
+            if (wave == 0u) {
+                float s[NW];
+                static_for<0, NW>([&](auto w) { s[w] = sm[w][lane]; });
+                static_for<0, NW / 2>([&](auto i) { s[i] = s[2 * i] + s[2 * i + 1]; });
+                static_for<0, NW / 4>([&](auto i) { s[i] = s[2 * i] + s[2 * i + 1]; });
+                static_for<0, NW / 8>([&](auto i) { s[i] = s[2 * i] + s[2 * i + 1]; });
+                static_for<0, NW / 16>([&](auto i) { s[i] = s[2 * i] + s[2 * i + 1]; });
+                r = s[0];
+                const unsigned long long z = __ballot(live && r == 0.0f);
+                if (lane == 0u) zshared = z;
+            }
+            __syncthreads();
+            const unsigned long long zm = zshared;
+            if (zm != 0ull) {
+                const bool ok = fast ? wave_leaves_all_negzero<true>(mine, ngroups, t, zm) : wave_leaves_all_negzero<false>(mine, ngroups, t, zm);
+                sm[wave][lane] = ok ? 1.0f : 0.0f;
+                __syncthreads();
+                if (wave == 0u && ((zm >> lane) & 1ull)) {
+                    bool all = true;
+                    static_for<0, NW>([&](auto w) { all = all && sm[w][lane] != 0.0f; });
+                    r = all ? -0.0f : 0.0f;
+                }
+            }
+            if (wave == 0u) {
+                float *orow = a.out + (size_t)a.rows[voice] * 64u;
+                bool finished_voice = nchunks == 1u;
+                float result = r;
+                if (nchunks > 1u) {
+                    float *slot = a.ws + (size_t)voice * 64u;
+                    __hip_atomic_store(slot + (size_t)chunk * vstride + lane, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    uint32_t old = 0u;
+                    if (lane == 0u) old = __hip_atomic_fetch_add(a.tickets + (size_t)voice * TICKET_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    old = __builtin_amdgcn_readfirstlane(old);
+                    if (old == nchunks - 1u) {
+                        finished_voice = true;
+                        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f, c4 = 0.0f, c5 = 0.0f, c6 = 0.0f, c7 = 0.0f, c8 = 0.0f;
+                        for (uint32_t c = 0; c < nchunks; ++c) {
+                            float v = c == chunk ? r : __hip_atomic_load(slot + (size_t)c * vstride + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            do {
+                                if (!(c & 1u)) { c0 = v; break; } v = c0 + v;
+                                if (!(c & 2u)) { c1 = v; break; } v = c1 + v;
+                                if (!(c & 4u)) { c2 = v; break; } v = c2 + v;
+                                if (!(c & 8u)) { c3 = v; break; } v = c3 + v;
+                                if (!(c & 16u)) { c4 = v; break; } v = c4 + v;
+                                if (!(c & 32u)) { c5 = v; break; } v = c5 + v;
+                                if (!(c & 64u)) { c6 = v; break; } v = c6 + v;
+                                if (!(c & 128u)) { c7 = v; break; } v = c7 + v;
+                                c8 = v;
+                            } while (0);
+                        }
+                        result = c8;
+                        result = clog == 7u ? c7 : result; result = clog == 6u ? c6 : result; result = clog == 5u ? c5 : result;
+                        result = clog == 4u ? c4 : result; result = clog == 3u ? c3 : result; result = clog == 2u ? c2 : result;
+                        result = clog == 1u ? c1 : result;
+                        if (lane == 0u) __hip_atomic_store(a.tickets + (size_t)voice * TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (finished_voice) {
+                    // the row goes to the host: system-scope stores, acknowledged before the voice is counted in
+                    if (live) __hip_atomic_store(&orow[lane], result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0u) {
+                        const uint32_t n = __hip_atomic_fetch_add(&dev->voices_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (n == a.n_voices - 1u) {
+                            __hip_atomic_store(&dev->voices_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&ctl->done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (every row's stores were acknowledged before its voice was counted)
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();   // LDS is reused by the next block
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&ctl->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_bank_stream(const BankArgs &a, BankStreamCtl *ctl_dev, BankStreamDev *dev, hipStream_t s) {
+    if (a.chunk_log2 < 7 || a.chunk_log2 > 13 || a.chunk_log2 > a.log2_p || a.log2_p - a.chunk_log2 > 8) return hipErrorInvalidValue;
+    if (((uint64_t)a.n_voices << (a.log2_p - a.chunk_log2)) > BANK_STREAM_WGS || a.n_voices == 0) return hipErrorInvalidValue;
+    if ((1u << a.chunk_log2) / 16u < 8u) return hipErrorInvalidValue;          // a wave needs a whole group of 8 partials
+    if (a.chunk_log2 != a.log2_p && (!a.ws || !a.tickets)) return hipErrorInvalidValue;
+    if (a.leaf_variant != 1 || !a.out || !a.rows || !ctl_dev || !dev) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bank_stream_kernel, dim3(BANK_STREAM_WGS), dim3(1024), 0, s, a, ctl_dev, dev);
+    return hipGetLastError();
+}
+
 // Will launch_bank publish row-completion flags for these arguments (host_flags set)?  Only the time-major kernel with
 // one chunk per voice and the FMA-form leaves does.
 bool bank_publishes_rows(const BankArgs &a) {

@@ -85,6 +85,38 @@ struct BankArgs {
     const uint32_t *group_off;
 };
 constexpr uint32_t BANK_TICKET_STRIDE = 32;
+
+// ---- block streaming (fr_stream_*, engine.cpp): ONE resident launch renders block after block -------------------------
+// What a real-time host pays per 64-frame block through fr_fill_buffer is the launch path (~12 us from enqueue to first
+// wave on this stack, profiles/r02_host_short_blocks.txt), not the 1.3 us of arithmetic.  Here the kernel is launched once
+// and stays: the host rings a doorbell in mapped pinned memory, workgroup 0 sees it, copies the block's input row into
+// device memory and releases the other workgroups; each renders its (voice, chunk) exactly as bank_short_kernel does, the
+// chunk sums meet through the same tickets, finished rows go straight to mapped host memory and the workgroup that
+// completes the last voice writes the block's sequence number back.  No workgroup ever waits for another one's result
+// (tickets: the last arriver does the work), and every polling loop is bounded: without a doorbell for ~1 s the kernel
+// ends itself, so a host that dies leaves no spinning GPU behind.
+struct BankStreamCtl {        // mapped pinned host memory
+    // host -> device.  The doorbell IS the block's input row: word i = row[i] (low half) | tag (high half), tag = the block's
+    // sequence number << 8 | frames in the block (1..64; 0xFFFFFFFF = stop), written with one 8-byte store each.  Lane i of
+    // workgroup 0 polls word i: a word whose tag is new carries its value with it (8-byte loads do not tear), so one trip
+    // across PCIe brings both the news and the data (three dependent trips -- doorbell, length, row -- cost 5 us more).
+    unsigned long long row[64];
+    uint32_t done;            // device -> host: tag of the last finished block
+    uint32_t alive;           // device -> host: 1 while the kernel is resident, 0 once it has ended
+    uint32_t pad1[14];
+};
+struct BankStreamDev {        // device memory
+    uint32_t seq;             // the doorbell, republished by workgroup 0 (0xFFFFFFFF = stop)
+    uint32_t n_times;
+    uint32_t voices_done;
+    uint32_t pad[13];
+    float row[64];
+};
+constexpr uint32_t BANK_STREAM_STOP = 0xFFFFFFFFu;
+constexpr uint32_t BANK_STREAM_WGS = 256;      // one per CU; all resident (the same shape bank_short_kernel launches)
+// `a`: as for the short-call kernel (small_call == 2, 16 waves, chunk_log2 chosen so that voices * chunks <= BANK_STREAM_WGS),
+// out = device pointer of the mapped [n_voices][64] host result (out_stride = 64), ws / tickets allocated for 64 frames.
+hipError_t launch_bank_stream(const BankArgs &a, BankStreamCtl *ctl_dev, BankStreamDev *dev, hipStream_t s);
 void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane,
                 uint32_t &waves_per_group, uint32_t &small_call, uint32_t &voices_per_wave);
 uint64_t bank_blocks(const BankArgs &a);

@@ -481,6 +481,9 @@ fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t 
 fr_status fr_host_register(fr_renderer *r, void *, size_t) { return r ? FR_OK : FR_ERR_INVALID_ARG; }   // (nothing to pin on the CPU)
 fr_status fr_host_unregister(fr_renderer *r, void *) { return r ? FR_OK : FR_ERR_INVALID_ARG; }
 fr_status fr_comm_selftest(int32_t, uint64_t) { return FR_ERR_UNSUPPORTED; }
+fr_status fr_stream_begin(fr_renderer *, uint32_t) { return FR_ERR_UNSUPPORTED; }   // (a resident GPU launch has no CPU meaning)
+fr_status fr_stream_block(fr_renderer *, float *, uint64_t, uint64_t, const float *, uint64_t) { return FR_ERR_UNSUPPORTED; }
+fr_status fr_stream_end(fr_renderer *) { return FR_OK; }
 fr_status fr_comm_unique_id(uint8_t *) { return FR_ERR_UNSUPPORTED; }   // (RCCL is the product's transport)
 
 fr_status fr_set_shard(fr_renderer *r, const fr_shard *sh) {

@@ -1554,3 +1554,64 @@ def test_compiled_kernels_are_reused_from_disk(hip_lib, oracle_lib, tmp_path, mo
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["hits"] == 0 and rep["compiled"] == 1 and rep["sum"] == float(np.nansum(exp)), rep
+
+
+# ---- block streaming: one resident launch renders 64-frame blocks on a doorbell ------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,P", [(4, 512), (3, 128), (1, 4096), (16, 128), (5, 1024), (64, 256)])
+def test_block_streaming_renders_what_fill_buffer_renders(hip_lib, oracle_lib, V, P):
+    """fr_stream_begin / fr_stream_block: blocks of 1..64 frames through the resident kernel, ordinary and hostile input
+    rows, equal the oracle's fill_buffer of the same frames bit for bit; an edit retires the launch (the next block is
+    refused until the stream is begun again) and the new graph is what the next stream renders."""
+    tree = synth.additive_tree(V, P, params_as_nodes=bool(P % 3))
+    rng = np.random.default_rng(V * 1000 + P)
+    special = np.array([0.0, -0.0, -1.0, 0.5, 1e-42, 16777216.0, 4294967296.0, 4294967808.0, 1e30, np.inf, -np.inf, np.nan], np.float32)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        idx = 0
+        for rnd in range(2):
+            hip.stream_begin(V)
+            for k in range(40):
+                T = int(rng.choice([1, 2, 17, 63, 64, 64, 64]))
+                row = synth.time_ramp(idx, idx + T)
+                if k % 5 == 4:
+                    row = row.copy()
+                    row[rng.integers(T, size=max(1, T // 4))] = special[rng.integers(len(special), size=max(1, T // 4))]
+                got = hip.stream_block(idx, row)
+                exp = ref.fill_buffer(V, idx, idx + T, [row])
+                assert same_bits(got, exp), f"round {rnd} block {k} (T={T}): " + first_diff(got, exp)
+                idx += T
+            # an edit: one amplitude changes; the resident launch is retired by it
+            e = tree["edges"]
+            rows_c = np.nonzero((e[:, 0] == synth.CONST_HANDLE) & (e[:, 3] == 0) & np.isin(e[:, 2], synth.bits(tree["params"]["amp"][tree["params"]["amp"] < 0.4])))[0]   # (0.5 and 1.0 are also constants of the waveform)
+            j = int(rows_c[rng.integers(len(rows_c))])       # (an amplitude: the voices stay template voices)
+            new = f32_bits(np.float32(0.25 + 0.01 * rnd))
+            for r in (hip, ref):
+                r.on_del_edge(synth.CONST_HANDLE, int(e[j, 1]), int(e[j, 2]), 0)
+                r.on_add_edge(synth.CONST_HANDLE, int(e[j, 1]), new, 0)
+            e[j, 2] = new
+            with pytest.raises(RenderError):
+                hip.stream_block(idx, synth.time_ramp(idx, idx + 8))
+            # ordinary calls still work after a stream (the first one is a seek for the engine: nothing of the stream was stored)
+            row = synth.time_ramp(idx, idx + 100)
+            assert same_bits(hip.fill_buffer(V, idx, idx + 100, [row]), ref.fill_buffer(V, idx, idx + 100, [row]))
+            idx += 100
+        hip.stream_begin(V)
+        hip.stream_end()
+
+
+@pytest.mark.gpu
+def test_block_streaming_refuses_what_it_cannot_serve(hip_lib):
+    with Renderer(hip_lib) as hip:
+        synth.install(hip, synth.effects_tree(2, 64))      # delay taps: state between calls
+        with pytest.raises(RenderError) as ei:
+            hip.stream_begin(2)
+        assert ei.value.status == 10                        # FR_ERR_UNSUPPORTED
+        with pytest.raises(RenderError):
+            hip.stream_block(0, synth.time_ramp(0, 8))      # no stream open
+    with Renderer(hip_lib) as hip:
+        synth.install(hip, synth.additive_tree(2, 64))       # voices too small for 16 waves
+        with pytest.raises(RenderError) as ei:
+            hip.stream_begin(2)
+        assert ei.value.status == 10
