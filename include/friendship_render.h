@@ -260,7 +260,10 @@ fr_status fr_fill_buffer_device(fr_renderer *r, float *d_out, uint32_t n_slots, 
  * (shorter than n_times: padded with its last value, reference.rs:72-73); such plans read no other input and no history.
  * ANY other call on the renderer (an edit, fr_fill_buffer, fr_stream_end) first retires the resident launch; the frames
  * streamed in between were not stored, so the call after that is a seek (reference.rs:52-58).  The kernel ends itself
- * if no block arrives for about a second (fr_stream_block then returns FR_ERR_DEVICE: begin again). */
+ * if no block arrives for a few seconds (fr_stream_block then returns FR_ERR_DEVICE: begin again).
+ * The resident launch holds every compute unit's register file (256 workgroups x 16 waves x 120 VGPRs): while a stream is
+ * open NOTHING ELSE runs on the device -- other kernels, of this process or any other, queue up behind it until the stream is
+ * closed or ends itself.  It is meant for a host that owns the GPU for audio. */
 fr_status fr_stream_begin(fr_renderer *r, uint32_t n_slots);
 fr_status fr_stream_block(fr_renderer *r, float *out, uint64_t n_times, uint64_t idx, const float *row, uint64_t row_len);
 fr_status fr_stream_end(fr_renderer *r);

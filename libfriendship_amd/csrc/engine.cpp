@@ -1475,11 +1475,18 @@ fr_status fr_stream_block(fr_renderer *r, float *out, uint64_t n_times, uint64_t
             __atomic_store_n(&ctl->row[i], (unsigned long long)seq << 32 | bits, __ATOMIC_RELAXED);
         }
         uint64_t spins = 0;
+        const auto t_ring = std::chrono::steady_clock::now();
         while (__atomic_load_n(&ctl->done, __ATOMIC_ACQUIRE) != seq) {
-            if ((++spins & 0xFFFFFu) == 0 && hipStreamQuery(r->stream) != hipErrorNotReady) {   // the launch is gone (its own bound, or a fault)
+            if ((++spins & 0xFFFFFu) != 0) continue;
+            if (hipStreamQuery(r->stream) != hipErrorNotReady) {   // the launch is gone (its own bound, or a fault)
                 (void)hipStreamSynchronize(r->stream);
                 r->streaming = false;
+                r->head = UINT64_MAX;
                 throw Error(FR_ERR_DEVICE, "the resident launch ended before the block was rendered");
+            }
+            if (std::chrono::steady_clock::now() - t_ring > std::chrono::seconds(10)) {   // (not all of it resident? something else holds CUs)
+                r->end_stream();
+                throw Error(FR_ERR_DEVICE, "the resident launch did not answer within 10 s");
             }
         }
         const float *res = r->h_stream_out.as<float>();

@@ -1615,3 +1615,25 @@ def test_block_streaming_refuses_what_it_cannot_serve(hip_lib):
         with pytest.raises(RenderError) as ei:
             hip.stream_begin(2)
         assert ei.value.status == 10
+
+
+@pytest.mark.gpu
+def test_block_streaming_launch_ends_itself_without_a_host(hip_lib, oracle_lib):
+    """Nobody rings for a few seconds: the resident launch reaches the bound of its polling loop and ends (a host that
+    died leaves no spinning GPU behind); the next block is refused with FR_ERR_DEVICE, a new stream renders on."""
+    import time
+    V, P = 2, 256
+    tree = synth.additive_tree(V, P)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        hip.stream_begin(V)
+        row = synth.time_ramp(0, 64)
+        assert same_bits(hip.stream_block(0, row), ref.fill_buffer(V, 0, 64, [row]))
+        time.sleep(8.0)
+        with pytest.raises(RenderError) as ei:
+            hip.stream_block(64, synth.time_ramp(64, 128))
+        assert ei.value.status == 7   # FR_ERR_DEVICE
+        hip.stream_begin(V)
+        row = synth.time_ramp(64, 128)
+        assert same_bits(hip.stream_block(64, row), ref.fill_buffer(V, 64, 128, [row]))
