@@ -399,6 +399,38 @@ def run():
                 short_blocks[str(tb)]["two_streams_us_per_call"] = (time.perf_counter() - tb0) / 500 * 1e6
                 next_k += 8 + (520 * tb) // T + 1
 
+    # block streaming: the real-time case host to host -- one 64-frame block through fr_fill_buffer (a launch per block) and through
+    # the resident launch (fr_stream_block), with the 1.3 ms between blocks a 48 kHz host leaves
+    block_streaming = None
+    if extras and world == 1 and args.tree == "additive":
+        try:
+            tb, gap = 64, 1.3e-3
+            rows8 = [synth.time_ramp(k * tb, (k + 1) * tb) for k in range(8)]
+            o_blk = np.zeros((V, tb), np.float32)
+
+            def timed(call, n=250):
+                ts = []
+                for k in range(n):
+                    t1 = time.perf_counter()
+                    while time.perf_counter() - t1 < gap:
+                        pass
+                    t0 = time.perf_counter()
+                    call(k)
+                    ts.append((time.perf_counter() - t0) * 1e6)
+                return float(np.median(ts[50:])), float(np.percentile(ts[50:], 99))
+
+            base = (next_k + 64) * T
+            fb = timed(lambda k: hip.fill_buffer(V, base + k * tb, base + (k + 1) * tb, [rows8[k % 8]], out=o_blk))
+            hip.stream_begin(V)
+            sb = timed(lambda k: hip.stream_block(base + k * tb, rows8[k % 8], out=o_blk))
+            hip.stream_end()
+            block_streaming = {"frames_per_block": tb, "idle_between_blocks_us": gap * 1e6,
+                               "fill_buffer_us": fb[0], "fill_buffer_p99_us": fb[1], "stream_block_us": sb[0], "stream_block_p99_us": sb[1],
+                               "what": "host rows in, host buffer out, synchronous, through ctypes: one launch per block vs the resident launch "
+                                       "(fr_stream_begin / fr_stream_block; profiles/r02_block_streaming.txt)"}
+        except Exception as e:   # an extra; never lose the line over it
+            block_streaming = {"error": repr(e)}
+
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -471,6 +503,7 @@ def run():
         "roofline": roofline,
         "host_api": host_api,
         "short_blocks": short_blocks,
+        "block_streaming": block_streaming,
         "overlapped_calls": overlapped,
     }
     # HBM traffic per launch from PMC counters: rocprofv3 cannot wrap a process from inside it, so the figure is read from
