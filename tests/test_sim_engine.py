@@ -449,3 +449,14 @@ def test_streamed_host_output(sim, oracle_lib, monkeypatch):
                 exp = ref.fill_buffer(V, idx + c, idx + c + 1, [tt])
                 assert same_bits(a[:, c:c + 1], exp), f"call {k} frame {c}"
             idx += T
+
+
+def test_block_streaming_is_refused_where_no_launch_can_stay_resident(sim):
+    """fr_stream_begin on the host-logic simulator (no device, no resident launches): a clean error, the renderer stays usable."""
+    with Renderer(sim) as r:
+        synth.install(r, synth.additive_tree(2, 256))
+        with pytest.raises(RenderError):
+            r.stream_begin(2)
+        with pytest.raises(RenderError):
+            r.stream_block(0, synth.time_ramp(0, 8))
+        assert r.fill_buffer(2, 0, 8, [synth.time_ramp(0, 8)]).shape == (2, 8)
