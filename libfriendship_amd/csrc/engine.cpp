@@ -1416,6 +1416,7 @@ fr_status fr_stream_begin(fr_renderer *r, uint32_t n_slots) {
         if (bs.grp.general || bs.grp.jit || bs.grp.to_ring || bs.grp.to_ws || bs.grp.rows.size() != n_slots || !sp.pull_rows.empty())
             throw Error(FR_ERR_UNSUPPORTED, "block streaming needs balanced template voices, one per output row");
         if (r->bank_leaf_variant != 1) throw Error(FR_ERR_UNSUPPORTED, "block streaming with FR_BANK_LEAF=0");
+        if (bs.grp.input_slot != 0) throw Error(FR_ERR_UNSUPPORTED, "block streaming feeds input slot 0; these voices read another slot");
         if (bs.grp.log2_p < 7) throw Error(FR_ERR_UNSUPPORTED, "block streaming needs voices of at least 128 partials (16 waves x one group of 8)");
         BankArgs a{};
         a.params = bs.d_params.as<float2>();
