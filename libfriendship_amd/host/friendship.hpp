@@ -640,6 +640,9 @@ protected:
         decltype(&fr_backend_name) backend_name;
         decltype(&fr_set_shard) set_shard;
         decltype(&fr_shard_rows) shard_rows;
+        decltype(&fr_stream_begin) stream_begin;
+        decltype(&fr_stream_block) stream_block;
+        decltype(&fr_stream_end) stream_end;
     } api_{};
 
     template <class T>
@@ -699,6 +702,9 @@ public:
         sym(api_.backend_name, "fr_backend_name");
         sym(api_.set_shard, "fr_set_shard");
         sym(api_.shard_rows, "fr_shard_rows");
+        sym(api_.stream_begin, "fr_stream_begin");
+        sym(api_.stream_block, "fr_stream_block");
+        sym(api_.stream_end, "fr_stream_end");
         fr_config cfg{FR_ABI_VERSION, device, mode, flags, semantics, 0, history_frames};
         fr_status s = api_.create(&cfg, &h_);
         if (s != FR_OK) {
@@ -729,6 +735,20 @@ public:
         api_.shard_rows(h_, n_slots, &lo, &hi);
         return {lo, hi};
     }
+
+    // Block streaming (friendship_render.h fr_stream_*): a real-time host renders 1..64-frame blocks through one resident launch.
+    // stream_begin() returns false where the plugin or the graph cannot be served that way (render with fill_buffer then);
+    // any other call on the renderer closes the stream.
+    bool stream_begin(uint32_t n_slots) {
+        fr_status s = api_.stream_begin(h_, n_slots);
+        if (s == FR_ERR_UNSUPPORTED) return false;
+        check(s);
+        return true;
+    }
+    void stream_block(Array2 &buff, uint64_t idx, const std::vector<float> &row) {
+        check(api_.stream_block(h_, buff.data.data(), buff.cols, idx, row.data(), row.size()));
+    }
+    void stream_end() { check(api_.stream_end(h_)); }
 
     void on_add_node(const routing::NodeHandle &node, const routing::NodeData &data) override {
         auto ce = lower(*data);

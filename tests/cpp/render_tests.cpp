@@ -320,6 +320,64 @@ static void shipped_effect_files() {
     }
 }
 
+// ---- block streaming through the plugin (fr_stream_*; the HIP engine only -- the CPU oracle says "unsupported") --------------
+// A voice of 128 file-defined Partial instances under a Sum2 tree, rendered block by block through the resident launch and,
+// by a second renderer, through fill_buffer: same bits.
+static void block_streaming() {
+    const char *lib = std::getenv("FRIENDSHIP_RENDERER_LIB");
+    const std::string dir = (std::filesystem::path(__FILE__).parent_path() / ".." / ".." / "effects").lexically_normal().string();
+    const auto sha = friendship::sha256(slurp(dir + "/partial.fnd"));
+    resman::ResMan res;
+    res.add_dir(dir);
+    auto partial = routing::Effect::from_id(EffectId::make("Partial", sha, {}), res);
+    auto constant = routing::Effect::from_id(const_id(), res);
+    auto sum2 = routing::Effect::from_id(sum2_id(), res);
+    render::PluginRenderer streamed(lib), plain(lib);
+    const uint32_t P = 128;
+    for (render::PluginRenderer *r : {&streamed, &plain}) {
+        r->on_add_node(NodeHandle::make(1), constant);
+        std::vector<uint32_t> level;
+        uint32_t next = 2;
+        for (uint32_t k = 0; k < P; ++k) {
+            const auto h = NodeHandle::make(next++);
+            r->on_add_node(h, partial);
+            r->on_add_edge(Edge::new_from_null(h, EdgeWeight::make(0, 0)));
+            r->on_add_edge(Edge::make(NodeHandle::make(1), h, EdgeWeight::make(f32_to_bits(0.0011f * (float)(k + 1)), 1)));
+            r->on_add_edge(Edge::make(NodeHandle::make(1), h, EdgeWeight::make(f32_to_bits(1.0f / (float)(k + 1)), 2)));
+            level.push_back(h.node_handle);
+        }
+        while (level.size() > 1) {
+            std::vector<uint32_t> up;
+            for (size_t i = 0; i + 1 < level.size(); i += 2) {
+                const auto h = NodeHandle::make(next++);
+                r->on_add_node(h, sum2);
+                r->on_add_edge(Edge::make(NodeHandle::make(level[i]), h, EdgeWeight::make(0, 0)));
+                r->on_add_edge(Edge::make(NodeHandle::make(level[i + 1]), h, EdgeWeight::make(0, 1)));
+                up.push_back(h.node_handle);
+            }
+            level.swap(up);
+        }
+        r->on_add_edge(Edge::new_to_null(NodeHandle::make(level[0]), EdgeWeight::make(0, 0)));
+    }
+    if (!streamed.stream_begin(1)) {
+        if (streamed.backend() == "hip-gfx950") throw std::runtime_error("the HIP engine refused to stream a template voice");
+        return;   // the CPU oracle: nothing to stream with
+    }
+    uint64_t idx = 0;
+    for (size_t n : {64u, 17u, 64u, 1u, 40u}) {
+        std::vector<float> row(n);
+        for (size_t i = 0; i < n; ++i) row[i] = (float)(idx + i);
+        Array2 a{1, n, std::vector<float>(n, -1.0f)}, b{1, n, std::vector<float>(n, 0.0f)};
+        streamed.stream_block(a, idx, row);
+        Jagged2 rows;
+        rows.extend(row.data(), n);
+        plain.fill_buffer(b, idx, rows);
+        if (std::memcmp(a.data.data(), b.data.data(), n * sizeof(float)) != 0) throw std::runtime_error("a streamed block differs from fill_buffer");
+        idx += n;
+    }
+    streamed.stream_end();
+}
+
 // The wire shape serde derives for EffectDesc, byte for byte, and its round trip.
 static void effect_desc_json() {
     auto desc = create_multby2();
@@ -451,7 +509,7 @@ int main(int argc, char **argv) {
         {"render_mult", render_mult}, {"render_sum2", render_sum2}, {"render_div", render_div},
         {"render_mod", render_mod}, {"render_min", render_min},
         {"ext_render_passthrough", ext_render_passthrough}, {"ext_render_delay", ext_render_delay},
-        {"load_multby2", load_multby2}, {"shipped_effect_files", shipped_effect_files}, {"effect_desc_json", effect_desc_json},
+        {"load_multby2", load_multby2}, {"shipped_effect_files", shipped_effect_files}, {"block_streaming", block_streaming}, {"effect_desc_json", effect_desc_json},
         {"routegraph_validation", routegraph_validation}, {"mpsc_client_and_queries", mpsc_client_and_queries}};
     int failed = 0, ran = 0;
     for (auto &t : tests) {
