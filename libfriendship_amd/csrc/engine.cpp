@@ -333,6 +333,8 @@ struct fr_renderer {
     uint32_t bank_leaf_variant = 1;      // FR_BANK_LEAF=0: product-form leaves (kernels.hpp BankArgs::leaf_variant)
     // Block streaming (fr_stream_*): one resident launch renders 64-frame blocks on a doorbell (kernels.hpp BankStreamCtl)
     bool streaming = false;
+    double stream_trace_us[2] = {0, 0};
+    uint64_t stream_trace_n = 0;
     uint32_t stream_seq = 0, stream_slots = 0;
     uint64_t stream_head = 0;
     PinnedBuf h_stream_ctl, h_stream_out;
@@ -376,6 +378,9 @@ struct fr_renderer {
         // another renderer would otherwise meet a stale one)
         if (!registered.empty()) (void)hipStreamSynchronize(stream);
         for (auto &rg : registered) { if (hipHostUnregister(rg.first) != hipSuccess) (void)hipGetLastError(); }
+        if (host_trace && stream_trace_n)
+            std::fprintf(stderr, "fr_stream_block over %llu blocks: ring + wait %.1f us, copy out %.1f us\n", (unsigned long long)stream_trace_n,
+                         stream_trace_us[0] / stream_trace_n, stream_trace_us[1] / stream_trace_n);
         if (host_trace && trace_n)
             std::fprintf(stderr, "fr_fill_buffer phases over %llu calls (mapped out %d, mapped in %d): issue %.1f us, %s %.1f us, %s %.1f us\n",
                          (unsigned long long)trace_n, (int)host_out_mapped, (int)host_rows_mapped, trace_us[0] / trace_n,
@@ -1464,6 +1469,7 @@ fr_status fr_stream_block(fr_renderer *r, float *out, uint64_t n_times, uint64_t
         if (!out || n_times == 0 || n_times > 64 || row_len > n_times || (row_len && !row)) throw Error(FR_ERR_INVALID_ARG, "a streamed block is 1..64 frames");
         (void)idx;   // (a plan served here reads nothing but this block's row: the position does not enter the result)
         BankStreamCtl *ctl = (BankStreamCtl *)r->h_stream_ctl.p;
+        const auto t_in = std::chrono::steady_clock::now();
         // the row, padded with its last value like a short row of fill_buffer (reference.rs:72-73; no row: zeros), every
         // word tagged with the block's number and length: the words are the doorbell (kernels.hpp BankStreamCtl)
         r->stream_seq = (r->stream_seq + 1u) & 0xFFFFFFu;
@@ -1490,8 +1496,14 @@ fr_status fr_stream_block(fr_renderer *r, float *out, uint64_t n_times, uint64_t
                 throw Error(FR_ERR_DEVICE, "the resident launch did not answer within 10 s");
             }
         }
+        const auto t_done = std::chrono::steady_clock::now();
         const float *res = r->h_stream_out.as<float>();
         for (uint32_t v = 0; v < r->stream_slots; ++v) std::memcpy(out + (size_t)v * n_times, res + (size_t)v * 64, n_times * sizeof(float));
+        if (r->host_trace) {   // FR_HOST_TRACE=1: inside the call, without the caller's wrapper
+            r->stream_trace_us[0] += std::chrono::duration<double, std::micro>(t_done - t_in).count();
+            r->stream_trace_us[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_done).count();
+            ++r->stream_trace_n;
+        }
     }, true);
 }
 
