@@ -94,7 +94,94 @@ def cpu_baseline(tree, V, P, frames_1t, frames_mt):
     return one, many, out1
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, child_cmd=None, timeout=None):
+    """`python bench.py --gpus N` without a launcher around it: this process becomes the launcher.  It starts N children
+    of the same command, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would set
+    them), forwards rank 0's one JSON line and fails if any rank fails.  The parent never imports torch and never touches
+    HIP (a process that has initialised the GPU must not be replaced or forked on this pool): children are fresh
+    interpreters.  Returns (exit code, rank 0's last stdout line or None)."""
+    import subprocess
+    cmd = list(child_cmd) if child_cmd else [sys.executable, os.path.abspath(__file__)]
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "FR_BENCH_LAUNCHER": "self"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL between processes on this driver)
+        env.setdefault("OMP_NUM_THREADS", "1")
+        # rank 0's stdout carries the line; the others' goes where diagnostics go
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=sys.stderr, text=(r == 0)))
+    t_end = time.monotonic() + timeout if timeout else None
+    out0, failed = None, None
+    try:
+        pending = set(range(n))
+        while pending and failed is None:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if rc != 0:
+                    failed = (r, rc)
+                    break
+            if t_end and time.monotonic() > t_end:
+                failed = (-1, 124)
+            if pending and failed is None:
+                if 0 in pending:     # keep rank 0's pipe drained (one line, but never let it block on a full pipe)
+                    try:
+                        out0, _ = procs[0].communicate(timeout=0.2)
+                        continue
+                    except subprocess.TimeoutExpired:
+                        pass
+                else:
+                    time.sleep(0.05)
+    finally:
+        for p in procs:              # a failed or timed-out job: end exactly the processes started here
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:
+                pass
+    if out0 is None:
+        try:
+            out0, _ = procs[0].communicate(timeout=30)     # (exited: returns what the pipe still holds, incl. earlier partial reads)
+        except Exception:
+            out0 = None
+    if failed is not None:
+        who = "the job timed out" if failed[0] < 0 else f"rank {failed[0]} exited with code {failed[1]}"
+        log(f"bench.py launcher: {who}; the other ranks were stopped")
+        return (failed[1] if failed[1] else 1), None
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    return 0, (lines[-1] if lines else None)
+
+
 def main():
+    # `python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks here, before anything
+    # imports torch or touches the GPU.
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--gpus", type=int, default=1)
+    pre.add_argument("--launch-timeout", type=float, default=3000.0)
+    known, _ = pre.parse_known_args()
+    if known.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        rc, line = launch_ranks(known.gpus, sys.argv[1:], timeout=known.launch_timeout)
+        if rc == 0 and line is None:
+            log("bench.py launcher: rank 0 printed no result line")
+            rc = 1
+        if line is not None:
+            sys.stdout.write(line + "\n")
+            sys.stdout.flush()
+        sys.exit(rc)
     # Exactly ONE line may reach stdout.  Libraries write there too (RCCL prints a version banner at communicator
     # creation), so the process's stdout is pointed at stderr for the whole run and the JSON line goes to the saved
     # descriptor at the end.
@@ -135,6 +222,8 @@ def run():
                     help="nccl is RCCL on ROCm (default): torch.distributed for the barrier and the engine's own RCCL "
                          "communicator for the exchange; gloo = rehearsal on a one-GPU box (exchange through the host callback)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (plumbing check)")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0,
+                    help="--gpus N > 1 without a launcher (WORLD_SIZE unset): bench.py starts its own N ranks; seconds before it gives up on them")
     ap.add_argument("--wrap-voices", type=int, default=0,
                     help="effects tree only, shape sweeps: fundamentals repeat every N voices (synth.voice_params wrap); the "
                          "survey's 55*2^(v/12) puts voices beyond v~150 above any representable pitch (identically zero mixes)")
@@ -158,6 +247,7 @@ def run():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    launcher = "none" if world == 1 else ("bench.py (self-spawned ranks)" if os.environ.get("FR_BENCH_LAUNCHER") == "self" else "external (torch.distributed.run)")
     # (rehearsals on a one-GPU box: several ranks may share device 0 with --backend gloo)
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
@@ -265,14 +355,18 @@ def run():
     log(f"[rank {rank}] warmup ({W} steps incl. lowering): {time.perf_counter() - t0:.2f}s; plan: {hip.plan()}")
 
     def timed_loop(k0):
+        # barrier + synchronize, K steps, synchronize + barrier; every rank clocks its own K steps (from leaving the opening
+        # barrier to its own synchronize) and the job's time is the MAX over ranks -- the closing barrier's own latency
+        # (tens of microseconds over RCCL, as much as two steps of a voice-sharded job) is not rendering time
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(k0, k0 + K):
             step(k)
         torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
         barrier()
-        return max_over_ranks(time.perf_counter() - t0)
+        return max_over_ranks(dt)
 
     times = [timed_loop(W)]
     R = args.repeats or int(min(R_MAX, max(3, np.ceil(0.6 / max(times[0], 1e-6)))))
@@ -477,10 +571,13 @@ def run():
                 "note": "block rendering keeps partial state in registers/SGPRs for 4800 frames: HBM is not the bound"},
     }
 
-    workloads = {"additive": f"additive tree, {P} partials x {V} voices, 48 kHz, {T}-frame fill_buffer calls (BASELINE.json configs[2]"
-                             f"{'' if (V, P) == (64, 4096) else ' shape, other size'}); harmonics and /sr as graph nodes",
-                 "effects": f"harmonics + detune + ADSR + 4-tap delay chain, {P} partials x {V} voices (BASELINE.json configs[3] shape)",
-                 "chorus": f"chorus (Delay with an LFO amount) + 4-tap delay chain, {P} partials x {V} voices (diagnostic)"}
+    # (the BASELINE.json config the line is quoted on comes first: record parsers keep the head of the string)
+    same = (V, P) == (64, 4096)
+    workloads = {"additive": f"BASELINE.json configs[2]{'' if same else ' shape at another size'}: {P} partials x {V} voices additive tree, 48 kHz, "
+                             f"{T}-frame fill_buffer calls; harmonics and /sr as graph nodes",
+                 "effects": f"BASELINE.json configs[3]{'' if (V, P) == (128, 1024) else ' shape at another size'}: harmonics + detune + ADSR + 4-tap delay chain, "
+                            f"{P} partials x {V} voices, {T}-frame calls",
+                 "chorus": f"diagnostic (no BASELINE config): chorus (Delay with an LFO amount) + 4-tap delay chain, {P} partials x {V} voices"}
     shardings = {"none": "single GPU",
                  "time": "time stripes: independent replicas on different frames, no collective",
                  "voices": "voices: fr_set_shard(FR_SHARD_VOICES), rank r renders its block of output rows, no collective",
@@ -493,7 +590,10 @@ def run():
         "scaling": "weak" if shard_mode == "time" else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workloads[args.tree], "voices": V, "partials": P, "frames_per_call": T,
-                   "sharding": shardings[shard_mode], "transport": transport, "engine_mode": args.mode, "plan": plan},
+                   "sharding": shardings[shard_mode], "transport": transport, "engine_mode": args.mode,
+                   "ranks": world, "launcher": launcher, "shard_world": plan.get("shard", {}).get("world"),
+                   "rccl_ranks": world if transport == "rccl" else 0,
+                   "rows_of_rank0": [row_lo, row_hi], "plan": plan},
         "repeats": {"n": R, "statistic": "median of R timed loops of K steps each", "ms_per_step_min": min(times) / K * 1e3,
                     "ms_per_step_max": max(times) / K * 1e3, "ms_per_step_all": [t / K * 1e3 for t in times],
                     "timed_seconds_total": sum(times),

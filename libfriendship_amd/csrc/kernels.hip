@@ -12,6 +12,22 @@
 
 namespace fr {
 
+// Diagnostic build only (tools/fewvoice_bench.hip defines FR_DIAG_STAMPS): per-wave timestamps (s_memrealtime, 100 MHz) and
+// placement, written to a buffer the tool hangs on g_diag.  In the product no stamp executes and none of this exists.
+#ifdef FR_DIAG_STAMPS
+__device__ unsigned long long *g_diag = nullptr;     // [workgroup][16 waves][4]: start, compute done, end, HW_ID | XCC_ID << 32 | units << 40
+#define FR_DIAG_MARK(slot, extra)                                                                                          \
+    do {                                                                                                                   \
+        if (g_diag && (threadIdx.x & 63u) == 0u) {                                                                         \
+            unsigned long long v_ = __builtin_amdgcn_s_memrealtime();                                                      \
+            if ((slot) == 3) v_ = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) | ((unsigned long long)(__builtin_amdgcn_s_getreg(0xF814) & 15u) << 32) | ((unsigned long long)(extra) << 40); \
+            g_diag[((size_t)blockIdx.x * 16u + (threadIdx.x >> 6)) * 4u + (slot)] = v_;                                    \
+        }                                                                                                                  \
+    } while (0)
+#else
+#define FR_DIAG_MARK(slot, extra) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // Shared primitive arithmetic (bit-exact restatement of reference.rs:197-262)
 // ---------------------------------------------------------------------------------------------------
@@ -388,6 +404,8 @@ __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tile
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
+    FR_DIAG_MARK(0, 0);
+    FR_DIAG_MARK(3, 1);
     const uint64_t t0 = (uint64_t)tile * (64u * F);
     float t[F];
     bool nonneg = true;
@@ -413,12 +431,14 @@ __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tile
     constexpr bool EXACT = (MODE == 0);
     if (fast) bank_wave_sum<F, true, EXACT>(params, ngroups, levels, t, res);
     else bank_wave_sum<F, false, EXACT>(params, ngroups, levels, t, res);
+    FR_DIAG_MARK(1, 0);
 
     __shared__ float sm[NW][F][64];
     __shared__ unsigned long long zmask[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) sm[wave][f][lane] = res[f];
     __syncthreads();
+    FR_DIAG_MARK(2, 0);
     // one chunk: straight to the voice's output row; else to the workspace [chunk][voice][t]
     const bool direct = nchunks == 1u;
     float *orow = direct ? a.out + (size_t)a.rows[voice] * a.out_stride
@@ -667,6 +687,8 @@ __global__ void __launch_bounds__(64 * NW) bank_short_kernel(BankArgs a, uint32_
     uint32_t levels = 0;
     while ((1u << levels) < ngroups) ++levels;
     const float *mine = (const float *)(a.params + ((size_t)voice << a.log2_p) + (size_t)chunk * Pc + (size_t)wave * Pw);
+    FR_DIAG_MARK(0, 0);
+    FR_DIAG_MARK(3, 1);
     ParamGroup first;                                      // requested BEFORE the time row: the two trips to memory overlap
     load_group(first, (const_f32_ptr)mine, 0);
     const float t = bank_time(a, ti);
@@ -676,8 +698,10 @@ __global__ void __launch_bounds__(64 * NW) bank_short_kernel(BankArgs a, uint32_
     float r_wave[1];
     if (fast) bank_wave_sum<1, true, false>(mine, ngroups, levels, tt, r_wave, &first);
     else bank_wave_sum<1, false, false>(mine, ngroups, levels, tt, r_wave, &first);
+    FR_DIAG_MARK(1, 0);
     sm[wave][lane] = r_wave[0];
     __syncthreads();
+    FR_DIAG_MARK(2, 0);
     float r = 0.0f;
     if (wave == 0u) {   // the NW wave sums in tree order: adjacent pairs, level by level
         float s[NW];
@@ -755,6 +779,212 @@ static hipError_t launch_bank_short(const BankArgs &a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Few-voice launches (a GPU's share of a voice-sharded job: 8 x 4096 x 4800 is 600 (voice, tile) pairs on 256 CUs).
+// Whole workgroups of the kernels above deal 2 or 3 pairs to a CU (28 % idle); cutting pairs into chunks evens that out
+// but puts a ticket + read-back of chunk sums in HBM at the END of every pair, and the last of them is the launch's tail
+// (profiles/r02_short_calls.txt: 21.9 us for 15 us of VALU work, whatever the chunk size).  Here the split is STATIC and
+// exact, and the cross-workgroup part comes FIRST:
+//   * one workgroup of 16 waves per CU (`wgs` of them); a pair is 16 units of P/16 partials; workgroup g owns the units
+//     [O*g/wgs, O*(g+1)/wgs) of the linearised (tile, voice, unit) space, O = pairs * 16 -- equal shares to within one
+//     unit (8 x 4096 x 4800: 37 or 38 units each, 1.3 %), and with wgs <= pairs a pair is shared by at most two
+//     workgroups, logical neighbours (same XCD under round-robin placement);
+//   * inside the workgroup the 16 waves take units from a queue in LDS (one ds_add each), so a wave held up by a memory
+//     round trip just takes fewer; a unit's sum goes to its slot in LDS, and the wave whose arrival completes a pair (or
+//     the workgroup's share of one) folds it in the tree's own order -- no workgroup barrier after the set-up;
+//   * the shares of SPLIT pairs are first in the queue: their unit sums are published (sc1 stores, vmcnt(0), one
+//     agent-scope ticket add per workgroup and pair; the later of the two adds reads the other's units back and writes
+//     the row) while the other waves are already in the whole pairs, which end in LDS and a store and nothing else;
+//   * the LAST pair of the queue is cut four times finer (64 units of P/64), so that what a SIMD can be left holding
+//     when the queue runs dry is a quarter of a unit.
+// Zero signs are settled per unit (a sum tree of correctly signed sub-sums has the right sign by IEEE addition).
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t ST_RING = 3;          // pair slots in LDS (16 waves hold units of at most 2 consecutive pairs at a time)
+constexpr uint32_t ST_MAX_ITEMS = 24;    // pairs (whole or shared) per workgroup: pairs <= 16 * wgs -> at most 16 + 2
+
+struct StItem {
+    uint32_t tile, voice;
+    uint32_t u0, k;          // this workgroup's units [u0, u0 + k) of the pair, in coarse units (P/16)
+    uint32_t fine;           // 1: processed as 4k units of P/64
+    uint32_t split;          // 1: the pair is shared with the workgroup on the other side of `boundary`
+    uint32_t boundary;       // the pair straddles workgroups `boundary` and `boundary + 1`
+    uint32_t qbase;          // first queue index of the item
+};
+
+template <bool FAST>
+__device__ __forceinline__ float static_unit(const float *params, uint32_t ngroups, uint32_t levels, float t, bool live, uint32_t lane) {
+    const float tt[1] = {t};
+    float r[1];
+    bank_wave_sum<1, FAST, false>(params, ngroups, levels, tt, r);
+    const unsigned long long zm = __ballot(live && r[0] == 0.0f);
+    if (zm != 0ull) {   // the sign of a zero unit sum: -0 iff every leaf of the unit is -0 in the graph's arithmetic
+        const bool ok = wave_leaves_all_negzero<FAST>(params, ngroups, t, zm);
+        if ((zm >> lane) & 1ull) r[0] = ok ? -0.0f : 0.0f;
+    }
+    return r[0];
+}
+
+// consecutive unit sums folded in tree order: adjacent pairs, level by level
+__device__ __forceinline__ float static_fold4(const float (*u)[64], uint32_t lane) { return (u[0][lane] + u[1][lane]) + (u[2][lane] + u[3][lane]); }
+__device__ __forceinline__ float static_fold16(const float (*u)[64], uint32_t lane) {
+    return (static_fold4(u, lane) + static_fold4(u + 4, lane)) + (static_fold4(u + 8, lane) + static_fold4(u + 12, lane));
+}
+
+__global__ void __launch_bounds__(1024, 8) bank_static_kernel(BankArgs a, uint32_t tiles, uint32_t G) {
+    __shared__ float slots[ST_RING][64][64];          // per pair slot: 16 coarse or 64 fine unit sums per lane
+    __shared__ StItem s_items[ST_MAX_ITEMS + 1];
+    __shared__ uint32_t s_next, s_cnt[ST_RING], s_gen[ST_RING];
+    const uint32_t b = blockIdx.x;
+    const uint32_t g = (G % 8u == 0u) ? (b % 8u) * (G / 8u) + b / 8u : b;   // logical neighbours share an XCD
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t V = a.n_voices;
+    if (threadIdx.x < ST_RING) { s_cnt[threadIdx.x] = 0u; s_gen[threadIdx.x] = 0u; }
+    if (threadIdx.x == 0u) {
+        // this workgroup's share: [a0, 16) of pair pf (if a0 != 0), [0, b1) of pair pl (if b1 != 16), the whole pairs between
+        s_next = 0u;
+        const uint64_t O = ((uint64_t)tiles * V) << 4;
+        const uint64_t o0 = O * g / G, o1 = O * (g + 1u) / G;
+        uint32_t n = 0u;
+        auto push = [&](uint32_t pair, uint32_t u0, uint32_t k, uint32_t split, uint32_t boundary) {
+            const uint32_t tile = pair / V;               // (tile, voice) order: a workgroup's pairs share time rows
+            s_items[n] = StItem{tile, pair - tile * V, u0, k, 0u, split, boundary, 0u};
+            ++n;
+        };
+        if (o1 > o0) {
+            const uint32_t pf = (uint32_t)(o0 >> 4), a0 = (uint32_t)(o0 & 15u);
+            const uint32_t pl = (uint32_t)((o1 - 1u) >> 4), b1 = (uint32_t)(o1 - ((uint64_t)pl << 4));
+            if (a0 != 0u) push(pf, a0, (pl == pf ? b1 : 16u) - a0, 1u, g - 1u);   // (pl == pf here only when wgs > pairs: refused by the launcher)
+            if (b1 != 16u && (pl != pf || a0 == 0u)) push(pl, 0u, b1, 1u, g);
+            for (uint32_t p = pf + (a0 != 0u ? 1u : 0u); p < pl + (b1 == 16u ? 1u : 0u) && n < ST_MAX_ITEMS; ++p) push(p, 0u, 16u, 0u, 0u);
+        }
+        if (n) s_items[n - 1u].fine = 1u;
+        if (a.static_fine) for (uint32_t i = 0; i < n; ++i) s_items[i].fine = 1u;
+        uint32_t q = 0u;
+        for (uint32_t i = 0; i < n; ++i) { s_items[i].qbase = q; q += s_items[i].k << (s_items[i].fine ? 2 : 0); }
+        s_items[n] = StItem{0u, 0u, 0u, 0u, 0u, 0u, 0u, q};   // sentinel: qbase = units in all
+        for (uint32_t i = n + 1u; i <= ST_MAX_ITEMS; ++i) s_items[i] = s_items[n];
+    }
+    __syncthreads();
+
+    uint32_t item = 0u, cur_tile = 0xFFFFFFFFu;
+    float t = 0.0f;
+    bool fast = false, live = false;
+    uint64_t ti = 0;
+    FR_DIAG_MARK(0, 0);
+    uint32_t diag_units = 0u;
+    (void)diag_units;
+    for (;;) {
+#if defined(FR_DIAG_EXP) && FR_DIAG_EXP >= 4
+        const uint32_t c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + 16u * (diag_units & 255u);   // diagnostic: static round-robin, no queue
+#else
+        uint32_t c = 0u;
+        if (lane == 0u) c = __hip_atomic_fetch_add(&s_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        c = __builtin_amdgcn_readfirstlane(c);
+#endif
+        // ---- which unit (a wave's claims only grow, so its item index only moves forward) ----
+        while (item < ST_MAX_ITEMS && c >= (uint32_t)__builtin_amdgcn_readfirstlane(s_items[item + 1u].qbase)) ++item;
+        if (item >= ST_MAX_ITEMS || c >= (uint32_t)__builtin_amdgcn_readfirstlane(s_items[ST_MAX_ITEMS].qbase)) break;
+        ++diag_units;
+        if (fast) diag_units += 256u;
+        const uint32_t tile = __builtin_amdgcn_readfirstlane(s_items[item].tile), voice = __builtin_amdgcn_readfirstlane(s_items[item].voice);
+        const uint32_t u0 = __builtin_amdgcn_readfirstlane(s_items[item].u0), k = __builtin_amdgcn_readfirstlane(s_items[item].k);
+        const uint32_t fine = __builtin_amdgcn_readfirstlane(s_items[item].fine), qbase = __builtin_amdgcn_readfirstlane(s_items[item].qbase);
+        const uint32_t fshift = fine ? 2u : 0u;
+        const uint32_t unit = (u0 << fshift) + (c - qbase);                 // within the pair, at this item's granularity
+        const uint32_t ulog = a.log2_p - 4u - fshift;                       // log2(partials per unit)
+        if (tile != cur_tile) {
+            cur_tile = tile;
+            ti = (uint64_t)tile * 64u + lane;
+            t = bank_time(a, ti);
+            live = ti < a.n_times;
+            fast = a.fast_ok && __all(t >= 0.0f && t <= 4294967296.0f);
+        }
+        if (a.hist_dst && voice == 0u && unit == 0u && ti < a.time_valid) a.hist_dst[ti] = t;   // (one unit per tile)
+        const uint32_t slot = item % ST_RING, want = item / ST_RING;
+        // the slot is free once the pair that used it before has been folded (practically always: that pair's units were all
+        // taken two pairs ago)
+#if !(defined(FR_DIAG_EXP) && FR_DIAG_EXP >= 3)
+        while (__hip_atomic_load(&s_gen[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(2);
+#endif
+        const float *up = (const float *)(a.params + ((size_t)voice << a.log2_p) + ((size_t)unit << ulog));
+        const uint32_t ngroups = 1u << (ulog - 3u), levels = ulog - 3u;
+#if defined(FR_DIAG_EXP) && FR_DIAG_EXP == 1
+        const float r = static_unit<true>(up, ngroups, levels, t, live, lane);
+#else
+        const float r = fast ? static_unit<true>(up, ngroups, levels, t, live, lane) : static_unit<false>(up, ngroups, levels, t, live, lane);
+#endif
+        slots[slot][unit][lane] = r;
+        FR_DIAG_MARK(1, 0);
+#if defined(FR_DIAG_EXP) && FR_DIAG_EXP >= 3
+        continue;      // diagnostic: compute only (no arrival, no fold, no output; the slot wait is compiled out too)
+#endif
+        // ---- arrival: the wave that completes the workgroup's share of the pair folds it ----
+        uint32_t old = 0u;
+        if (lane == 0u) old = __hip_atomic_fetch_add(&s_cnt[slot], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != (k << fshift) - 1u) continue;
+        float *orow = a.out + (size_t)a.rows[voice] * a.out_stride;
+        const uint32_t split = __builtin_amdgcn_readfirstlane(s_items[item].split);
+        float v[16];                                                        // the pair's 16 coarse unit sums (mine: from LDS)
+        static_for<0, 16>([&](auto j) {
+            v[j] = 0.0f;
+            if ((uint32_t)j >= u0 && (uint32_t)j < u0 + k) v[j] = fine ? static_fold4(slots[slot] + 4u * (uint32_t)j, lane) : slots[slot][(uint32_t)j][lane];
+        });
+        if (lane == 0u) {   // the slot may be used again (its sums are in registers now)
+            __hip_atomic_store(&s_cnt[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&s_gen[slot], want + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (split) {
+            // publish this share's unit sums, take the pair's ticket; if the other share is already there, finish the pair
+            const uint32_t boundary = __builtin_amdgcn_readfirstlane(s_items[item].boundary);
+            float *wsp = a.ws + (size_t)boundary * (16u * 64u) + lane;
+            static_for<0, 16>([&](auto j) {
+                if ((uint32_t)j >= u0 && (uint32_t)j < u0 + k) __hip_atomic_store(wsp + (uint32_t)j * 64u, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            });
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            uint32_t before = 0u;
+            if (lane == 0u) before = __hip_atomic_fetch_add(a.tickets + (size_t)boundary * TICKET_STRIDE, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            before = __builtin_amdgcn_readfirstlane(before);
+            if (before + k != 16u) continue;
+            static_for<0, 16>([&](auto j) {
+                if (!((uint32_t)j >= u0 && (uint32_t)j < u0 + k)) v[j] = __hip_atomic_load(wsp + (uint32_t)j * 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            });
+            if (lane == 0u) __hip_atomic_store(a.tickets + (size_t)boundary * TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+        }
+        const float res = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) + (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+        if (live) __builtin_nontemporal_store(res, &orow[bank_out_index(a, ti)]);
+    }
+    FR_DIAG_MARK(2, 0);
+    FR_DIAG_MARK(3, diag_units);
+}
+
+// CUs of the current device (all devices of a node are the same chip), read once.
+uint32_t bank_device_cus() {
+    static const uint32_t cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+        return (uint32_t)(n > 0 ? n : 0);
+    }();
+    return cus;
+}
+
+// Workgroups the static kernel would use for this shape on a chip of `cus` CUs (0: the shape is not one of its).
+uint32_t bank_static_wgs(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t cus) {
+    const uint64_t pairs = ((n_times + 63) / 64) * n_voices;
+    if (log2_p < 10 || log2_p > 15 || cus == 0 || pairs < cus || pairs > 16ull * cus) return 0;
+    return cus;
+}
+
+static hipError_t launch_bank_static(const BankArgs &a, hipStream_t s) {
+    const uint64_t tiles = (a.n_times + 63) / 64;
+    const uint64_t pairs = tiles * a.n_voices;
+    // a unit is P/16 (P/64 in a workgroup's last pair): at least one group of 8 partials, at most 2048 per wave
+    if (a.log2_p < 9 || a.log2_p > 15 || !a.static_wgs || a.static_wgs > pairs || pairs > 16ull * a.static_wgs) return hipErrorInvalidValue;
+    if (!a.ws || !a.tickets || a.leaf_variant != 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bank_static_kernel, dim3(a.static_wgs), dim3(1024), 0, s, a, (uint32_t)tiles, a.static_wgs);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Block streaming: the short-call kernel as ONE resident launch (kernels.hpp, BankStreamCtl).
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) bank_stream_kernel(BankArgs a, BankStreamCtl *ctl, BankStreamDev *dev) {
@@ -787,7 +1017,7 @@ __global__ void __launch_bounds__(1024) bank_stream_kernel(BankArgs a, BankStrea
                     const unsigned long long word = __hip_atomic_load(&ctl->row[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     tag = (uint32_t)(word >> 32);
                     v = __uint_as_float((uint32_t)word);
-                    fresh = __all(tag != seen) && __builtin_amdgcn_readfirstlane(tag) == tag;   // every lane holds the same new tag
+                    fresh = __all(tag != seen) && (uint32_t)__builtin_amdgcn_readfirstlane(tag) == tag;   // every lane holds the same new tag
                     fresh = __all(fresh);
                     if (fresh) break;
                 }
@@ -981,6 +1211,18 @@ void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &
     voices_per_wave = 0;
     small_call = 0;
     {
+        // few-voice launches: between one and a dozen (voice, tile) pairs per CU -- equal static shares (bank_static_kernel)
+        static const int mode = [] { const char *e = std::getenv("FR_BANK_STATIC"); return e ? std::atoi(e) : 0; }();
+        static const uint64_t max_pairs = [] { const char *e = std::getenv("FR_STATIC_MAX_PAIRS"); return e ? (uint64_t)std::atoll(e) : 3072ull; }();
+        const uint64_t pairs = ((n_times + 63) / 64) * n_voices;
+        if (mode && pairs <= max_pairs && bank_static_wgs(log2_p, n_voices, n_times, bank_device_cus())) {
+            small_call = 3;
+            chunk_log2 = log2_p;      // (no chunk workspace of the other kernels' kind; the engine sizes ws / tickets by static_wgs)
+            waves_per_group = 16;
+            return;
+        }
+    }
+    {
         // short calls: few (voice, tile) pairs.  Chunks of >= 512 partials until there are ~256 workgroups of 16 waves.
         // Measured at 64 x 4096 (tools/short_call_probe.py, profiles/r02_short_calls.txt), us per call, this kernel vs the
         // time-major one: T <= 64: 7.4 vs 11.2; 128: 8.3 vs 11.4; 256: 10.6 vs 11.6; 512: 19.5 vs 17.8 -- hence pairs <= 320.
@@ -1068,6 +1310,7 @@ void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &
 }
 
 hipError_t launch_bank(const BankArgs &a, hipStream_t s) {
+    if (a.small_call == 3) return launch_bank_static(a, s);
     if (a.small_call == 2) {   // short calls: chunks over workgroups, LDS-staged parameters, in-launch combine
         if (a.chunk_log2 < 7 || a.chunk_log2 > 13 || a.chunk_log2 > a.log2_p || a.log2_p - a.chunk_log2 > 8) return hipErrorInvalidValue;
         if (a.chunk_log2 != a.log2_p && (!a.ws || !a.tickets)) return hipErrorInvalidValue;

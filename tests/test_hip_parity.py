@@ -450,6 +450,63 @@ def test_short_call_kernel_equals_block_render(hip_lib, V, P, T, block):
             assert same_bits(whole, parts), f"pass {rep}: " + first_diff(parts, whole)
 
 
+@pytest.mark.parametrize("V,P,T,block", [(8, 4096, 4800, 1024), (16, 4096, 4800, 640), (5, 2048, 4777, 1000), (3, 16384, 6400, 704),
+                                         (32, 4096, 4800, 448), (9, 8192, 2000, 512)])
+def test_few_voice_static_kernel_equals_block_render(hip_lib, V, P, T, block):
+    """A GPU's share of a voice-sharded job -- few voices, a long call: 256..3072 (voice, tile) pairs -- runs the static-share
+    kernel (bank_static_kernel: one workgroup per CU, equal shares of the (tile, voice, piece) space, split pairs meeting
+    through piece sums + a ticket).  The same frames rendered in blocks take other kernels (fewer pairs): every frame of
+    every voice must be the same bits, several passes over the same tickets."""
+    tree = synth.additive_tree(V, P, seed=V + P, detune=True)
+    t = synth.time_ramp(0, T)
+    with Renderer(hip_lib) as a, Renderer(hip_lib) as b:
+        synth.install(a, tree)
+        synth.install(b, tree)
+        parts = np.concatenate([b.fill_buffer(V, s, min(s + block, T), [t[s:min(s + block, T)]]) for s in range(0, T, block)], axis=1)
+        for rep in range(5):
+            whole = a.fill_buffer(V, rep * T, (rep + 1) * T, [t])     # contiguous calls, the same time VALUES every pass
+            assert same_bits(whole, parts), f"pass {rep}: " + first_diff(whole, parts)
+
+
+def test_few_voice_static_kernel_against_oracle(hip_lib, oracle_lib):
+    """The static-share kernel against the oracle at the size it was built for (8 voices x 4096 partials x 4800 frames, a
+    GPU's share of config C on 8 GPUs): sampled frames of every voice incl. t = 0 (exact zeros whose sign the units settle),
+    a silent voice and one with -0 amplitudes (every unit sum a zero), then hostile time rows (negative, fractional, huge,
+    NaN: the general fract path), and the input history the launch appended."""
+    V, P, T = 8, 4096, 4800
+    p = synth.voice_params(V, P, seed=11, detune=True)
+    w, amp = p["w"].copy(), p["amp"].copy()
+    amp[2, :] = 0.0
+    amp[5, :] = -0.0
+    amp[6, 1::2] = 0.0
+    g = synth.GraphArrays()
+    roots = synth.sum_tree(g, synth.partial_leaves(g, w, amp).reshape(V, P))
+    d = g.binop(synth.K_DELAY, synth.IN(0), synth.C(np.float32(3.0)), 1)      # row 0: the time input 3 frames ago (reads the appended history)
+    g.edge(d, 0, 0, 0)
+    g.edge(roots, 0, 0, np.arange(1, V + 1, dtype=np.uint32))                  # rows 1..V: the voices
+    tree = g.finish(V + 1)
+    rng = np.random.default_rng(5)
+    hostile = (rng.normal(size=T) * 1000).astype(np.float32)
+    hostile[::97] = np.nan
+    hostile[5::211] = np.float32(2.0 ** 33)
+    hostile[7::301] = -0.0
+    rows = [synth.time_ramp(0, T), synth.time_ramp(T, 2 * T), hostile, synth.time_ramp(3 * T, 4 * T)]
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        for i, row in enumerate(rows):
+            got = hip.fill_buffer(V + 1, i * T, (i + 1) * T, [row])
+            ref.fill_buffer(1, i * T, (i + 1) * T, [row])                    # (the oracle stores the row and renders only the cheap slot)
+            cols = np.unique(np.concatenate([[0, 1, 2, 3, 63, 64, 2047, T - 1], rng.integers(0, T, 24), np.arange(0, T, 97)[:8]]))
+            slots = np.repeat(np.arange(V + 1), len(cols)).astype(np.uint32)
+            times = np.tile(cols + i * T, V + 1).astype(np.uint64)
+            exp = oracle_tools.eval_samples(ref, slots, times).reshape(V + 1, len(cols))
+            assert same_bits(got[:, cols], exp), f"row {i}: " + first_diff(got[:, cols], exp)
+            assert i == 2 or (not got[3].any() and not got[6].any() and got[7].any())   # (a NaN time makes every voice NaN)
+        plan = hip.plan()
+        assert plan["pull_rows"] == 0 and [(b["voices"], b["partials"]) for b in plan["banks"]] == [(V, P)], plan
+
+
 def test_short_call_kernel_against_oracle(hip_lib, oracle_lib):
     """Short calls of a chunked voice against the oracle, t = 0 (an exact zero whose sign the chunks must settle), negative
     and fractional times (the general fract path) included."""
