@@ -15,13 +15,15 @@ namespace fr {
 // Diagnostic build only (tools/fewvoice_bench.hip defines FR_DIAG_STAMPS): per-wave timestamps (s_memrealtime, 100 MHz) and
 // placement, written to a buffer the tool hangs on g_diag.  In the product no stamp executes and none of this exists.
 #ifdef FR_DIAG_STAMPS
-__device__ unsigned long long *g_diag = nullptr;     // [workgroup][16 waves][4]: start, compute done, end, HW_ID | XCC_ID << 32 | units << 40
+__device__ unsigned long long *g_diag = nullptr;     // [workgroup][16 waves][8]: start, compute done, end, HW_ID | XCC_ID << 32 | units << 40, then the
+                                                     // same three moments on the shader clock (s_memtime) in slots 4..6
 #define FR_DIAG_MARK(slot, extra)                                                                                          \
     do {                                                                                                                   \
         if (g_diag && (threadIdx.x & 63u) == 0u) {                                                                         \
             unsigned long long v_ = __builtin_amdgcn_s_memrealtime();                                                      \
             if ((slot) == 3) v_ = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) | ((unsigned long long)(__builtin_amdgcn_s_getreg(0xF814) & 15u) << 32) | ((unsigned long long)(extra) << 40); \
-            g_diag[((size_t)blockIdx.x * 16u + (threadIdx.x >> 6)) * 4u + (slot)] = v_;                                    \
+            g_diag[((size_t)blockIdx.x * 16u + (threadIdx.x >> 6)) * 8u + (slot)] = v_;                                    \
+            if ((slot) != 3) g_diag[((size_t)blockIdx.x * 16u + (threadIdx.x >> 6)) * 8u + 4u + (slot)] = __builtin_amdgcn_s_memtime(); \
         }                                                                                                                  \
     } while (0)
 #else
@@ -774,7 +776,7 @@ static hipError_t launch_bank_short(const BankArgs &a, hipStream_t s) {
     const uint64_t nb = (tiles * a.n_voices) << (a.log2_p - a.chunk_log2);
     if (nb == 0) return hipSuccess;
     if (nb > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((bank_short_kernel<NW>), dim3((uint32_t)nb), dim3(64 * NW), 0, s, a, (uint32_t)tiles);
+    hipLaunchKernelGGL((bank_short_kernel<NW>), dim3((uint32_t)nb), dim3(64 * NW), a.lds_pad, s, a, (uint32_t)tiles);
     return hipGetLastError();
 }
 
@@ -955,6 +957,272 @@ __global__ void __launch_bounds__(1024, 8) bank_static_kernel(BankArgs a, uint32
     }
     FR_DIAG_MARK(2, 0);
     FR_DIAG_MARK(3, diag_units);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Parameter-stationary bank kernel ("rect"), for launches with few voices and many tiles -- a GPU's share of a
+// voice-sharded job.  What the diagnostic stamps showed about the kernels above on such launches (tools/fewvoice_diag.hip,
+// profiles/r03_fewvoices.txt): every 8 partials cost a wave one s_load_dwordx16, ~600 cycles when it misses the scalar
+// cache; the time-major kernel hides that only because neighbouring workgroups stream the SAME voice's parameters in
+// lockstep (scalar-cache hits) and because 6-8 waves share a SIMD; a wave left alone on its SIMD at the end of a launch
+// runs at a fifth of the VALU rate, and whole workgroups deal unevenly over the CUs.  Here the roles are swapped:
+//   * a workgroup (16 waves, one per CU) owns a RECTANGLE: one voice, one piece of 128 * NG consecutive partials, a
+//     contiguous range of the call's 64-frame tiles; a wave owns 8 * NG partials whose {w, A4} it loads ONCE into SGPRs
+//     (NG <= 4 groups: 64 scalar registers) and then walks the tiles, two per iteration: the inner loop has no memory
+//     operation at all except the tile's time values, and runs at the VALU rate at any occupancy;
+//   * per iteration the 16 wave sums meet in an LDS ring slot (arrival counter, no workgroup barrier); the iteration's
+//     publisher -- the waves take turns -- folds them in tree order and, when the voice has more than one piece, publishes
+//     the piece sum (sc1 store) and one iteration later adds to the (voice, tile) ticket; the wave whose add is the last of
+//     the voice's pieces reads the others back, folds them in tree order and writes the row.  Each step of that hand-off is
+//     issued one iteration before its result is needed, so no wave waits on memory except after the very last tile;
+//   * voices x pieces x tile ranges = the number of CUs (8 x 4096 x 4800: 8 voices x 8 pieces x 4 ranges of 18 or 19
+//     tiles), so every CU carries the same load to within a tile.
+// Same bits as the graph: leaves in FMA form with zero signs settled per wave sum from the product form, every add the
+// tree's own (8 leaves, NG groups, 16 waves, the pieces: all aligned powers of two).
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t RC_RING = 4;          // iterations the fastest wave of a workgroup may be ahead of its publisher
+#ifndef FR_RC_F
+#define FR_RC_F 2
+#endif
+constexpr int RC_F = FR_RC_F;            // tiles per iteration
+
+template <int NG, bool FAST, bool EXACT>
+__device__ __forceinline__ float rect_wave_sum(const ParamGroup (&pg)[NG], float t) {
+    float gs[NG];
+    static_for<0, NG>([&](auto g) {
+        const float l0 = bank_leaf<FAST, EXACT>(t, pg[g].w[0], pg[g].A[0]), l1 = bank_leaf<FAST, EXACT>(t, pg[g].w[1], pg[g].A[1]);
+        const float l2 = bank_leaf<FAST, EXACT>(t, pg[g].w[2], pg[g].A[2]), l3 = bank_leaf<FAST, EXACT>(t, pg[g].w[3], pg[g].A[3]);
+        const float l4 = bank_leaf<FAST, EXACT>(t, pg[g].w[4], pg[g].A[4]), l5 = bank_leaf<FAST, EXACT>(t, pg[g].w[5], pg[g].A[5]);
+        const float l6 = bank_leaf<FAST, EXACT>(t, pg[g].w[6], pg[g].A[6]), l7 = bank_leaf<FAST, EXACT>(t, pg[g].w[7], pg[g].A[7]);
+        gs[g] = ((l0 + l1) + (l2 + l3)) + ((l4 + l5) + (l6 + l7));
+    });
+    if constexpr (NG == 1) return gs[0];
+    else if constexpr (NG == 2) return gs[0] + gs[1];
+    else return (gs[0] + gs[1]) + (gs[2] + gs[3]);
+}
+
+// every leaf of the wave's share exactly -0.0 in the graph's arithmetic (product-form leaves)?
+template <int NG, bool FAST>
+__device__ __forceinline__ bool rect_all_negzero(const ParamGroup (&pg)[NG], float t) {
+    uint32_t all_and = 0xFFFFFFFFu, all_or = 0u;
+    static_for<0, NG>([&](auto g) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t b = __float_as_uint(bank_leaf<FAST, true>(t, pg[g].w[j], pg[g].A[j]));
+            all_and &= b;
+            all_or |= b;
+        }
+    });
+    return all_and == 0x80000000u && all_or == 0x80000000u;
+}
+
+template <int N>
+__device__ __forceinline__ float rect_fold(const float (&v)[16]) {   // v[0..N) in tree order
+    if constexpr (N == 1) return v[0];
+    else if constexpr (N == 2) return v[0] + v[1];
+    else if constexpr (N == 4) return (v[0] + v[1]) + (v[2] + v[3]);
+    else if constexpr (N == 8) return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    else return (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) + (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+}
+
+template <int NG>
+__global__ void __launch_bounds__(1024) bank_rect_kernel(BankArgs a, uint32_t tiles, uint32_t ts, uint32_t pe_log2) {
+    __shared__ float sm[RC_RING][RC_F][16][64];          // 32 KB: the 16 wave sums of an iteration's tiles
+    __shared__ uint32_t s_cnt[RC_RING], s_gen[RC_RING];
+    const uint32_t G = gridDim.x, b = blockIdx.x;
+    const uint32_t g = (G % 8u == 0u) ? (b % 8u) * (G / 8u) + b / 8u : b;   // the pieces of a (voice, tile range) are neighbours on one XCD
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t pe = 1u << pe_log2, e = g & (pe - 1u);
+    const uint32_t vr = g >> pe_log2, voice = vr / ts, rr = vr - voice * ts;
+    const uint32_t tb = (uint32_t)((uint64_t)tiles * rr / ts), te = (uint32_t)((uint64_t)tiles * (rr + 1u) / ts);
+    if (threadIdx.x < RC_RING) { s_cnt[threadIdx.x] = 0u; s_gen[threadIdx.x] = 0u; }
+    // the wave's parameters: 8 * NG partials, loaded once, stationary in scalar registers
+    const_f32_ptr pp = (const_f32_ptr)(a.params + ((size_t)voice << a.log2_p) + (size_t)e * (128u * NG) + (size_t)wave * (8u * NG));
+    ParamGroup pg[NG];
+    static_for<0, NG>([&](auto k) { load_group(pg[k], pp, (uint32_t)k); });
+    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+
+    const size_t vt0 = (size_t)voice * tiles;             // (voice, tile) index base: tickets and the piece-sum workspace
+    float *const orow = a.out + (size_t)a.rows[voice] * a.out_stride;
+    // the publisher's hand-off in flight (at most one per wave: a wave publishes every 16th iteration)
+    uint32_t pub_stage = 0u, pub_tile = 0u, pub_nf = 0u;
+    float pub_ps[RC_F] = {};
+    uint32_t pub_old[RC_F] = {};
+    auto pub_step = [&]() {
+        if (pub_stage == 1u) {          // the piece sums were stored an iteration ago: acknowledged by now -> count this piece in
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int f = 0; f < RC_F; ++f)
+                if ((uint32_t)f < pub_nf && lane == 0u)
+                    pub_old[f] = __hip_atomic_fetch_add(a.tickets + (vt0 + pub_tile + (uint32_t)f) * TICKET_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pub_stage = 2u;
+            return;
+        }
+        // stage 2 -- the adds have returned: the last piece of a (voice, tile) reads the others back (a round trip this wave
+        // waits for while the other 15 compute: the ring absorbs it), adds the voice's top levels and writes the row
+#pragma unroll
+        for (int f = 0; f < RC_F; ++f) {
+            const uint32_t old = __builtin_amdgcn_readfirstlane(pub_old[f]);
+            if (!((uint32_t)f < pub_nf && old == pe - 1u)) continue;
+            const float *src = a.ws + ((vt0 + pub_tile + (uint32_t)f) << pe_log2) * 64u + lane;
+            float v[16];
+            static_for<0, 16>([&](auto j) {
+                v[j] = 0.0f;
+                if ((uint32_t)j < pe) v[j] = (uint32_t)j == e ? pub_ps[f] : __hip_atomic_load(src + (uint32_t)j * 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            });
+            float res;
+            switch (pe_log2) {
+            case 1: res = rect_fold<2>(v); break;
+            case 2: res = rect_fold<4>(v); break;
+            case 3: res = rect_fold<8>(v); break;
+            default: res = rect_fold<16>(v); break;
+            }
+            const uint64_t ti = (uint64_t)(pub_tile + (uint32_t)f) * 64u + lane;
+            if (ti < a.n_times) __builtin_nontemporal_store(res, &orow[bank_out_index(a, ti)]);
+            if (lane == 0u) __hip_atomic_store(a.tickets + (vt0 + pub_tile + (uint32_t)f) * TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        pub_stage = 0u;
+    };
+
+    // frames as 32-bit numbers (tiles < 2^24 here): the stored part of the time row is [t_lo, t_hi) of the window
+    const uint32_t t_lo = (uint32_t)(a.time_skip < 0x7FFFFFFFull ? a.time_skip : 0x7FFFFFFFull);
+    const uint32_t t_hi = (uint32_t)(a.time_skip + a.time_valid < 0x7FFFFFFFull ? a.time_skip + a.time_valid : 0x7FFFFFFFull);
+    const uint32_t n_frames = (uint32_t)(a.n_times < 0x7FFFFFFFull ? a.n_times : 0x7FFFFFFFull);
+    const float *const tbase = a.time - a.time_skip;                        // (read only inside [t_lo, t_hi))
+    const bool appends = a.hist_dst && voice == 0u && e == 0u && wave == 0u; // this wave also appends the row to the input history
+    auto load_t = [&](uint32_t tile_, uint32_t f_) -> float {
+        const uint32_t ti = (tile_ + f_) * 64u + lane;
+        return (tile_ + f_ < te && ti >= t_lo && ti < t_hi) ? tbase[ti] : 0.0f;
+    };
+    float tn[RC_F];                                                         // the NEXT iteration's time values, requested one iteration ahead
+#pragma unroll
+    for (int f = 0; f < RC_F; ++f) tn[f] = load_t(tb, (uint32_t)f);
+    uint32_t it = 0u;
+    FR_DIAG_MARK(0, 0);
+    for (uint32_t tile = tb; tile < te; tile += RC_F, ++it) {
+        const uint32_t nf = te - tile < (uint32_t)RC_F ? te - tile : (uint32_t)RC_F;
+        if (pub_stage != 0u) pub_step();
+        const uint32_t slot = it % RC_RING, want = it / RC_RING;
+        float t[RC_F];
+        bool in_range = true;
+#pragma unroll
+        for (int f = 0; f < RC_F; ++f) {
+            t[f] = tn[f];
+            tn[f] = load_t(tile + (uint32_t)RC_F, (uint32_t)f);
+            in_range = in_range && t[f] >= 0.0f && t[f] <= 4294967296.0f;
+            const uint32_t ti = (tile + (uint32_t)f) * 64u + lane;
+            if (appends && (uint32_t)f < nf && ti >= t_lo && ti < t_hi) a.hist_dst[ti - t_lo] = t[f];
+        }
+        const bool fast = a.fast_ok && __all(in_range);
+        float r[RC_F];
+        if (fast) {
+#pragma unroll
+            for (int f = 0; f < RC_F; ++f) r[f] = rect_wave_sum<NG, true, false>(pg, t[f]);
+        } else {
+#pragma unroll
+            for (int f = 0; f < RC_F; ++f) r[f] = rect_wave_sum<NG, false, false>(pg, t[f]);
+        }
+#pragma unroll
+        for (int f = 0; f < RC_F; ++f) {   // the sign of a zero wave sum: -0 iff every leaf of the wave's share is -0
+            const uint32_t ti = (tile + (uint32_t)f) * 64u + lane;
+            if (__ballot((uint32_t)f < nf && ti < n_frames && r[f] == 0.0f) != 0ull) {
+                const bool ok = fast ? rect_all_negzero<NG, true>(pg, t[f]) : rect_all_negzero<NG, false>(pg, t[f]);
+                if (r[f] == 0.0f) r[f] = ok ? -0.0f : 0.0f;
+            }
+        }
+#if defined(FR_DIAG_EXP) && FR_DIAG_EXP == 6
+#pragma unroll
+        for (int f = 0; f < RC_F; ++f) sm[slot][f][wave][lane] = r[f];      // diagnostic: compute and LDS store only, no hand-off at all
+        continue;
+#endif
+        // the ring slot is free once the iteration that used it before has been folded (RC_RING iterations ago)
+        while (__hip_atomic_load(&s_gen[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int f = 0; f < RC_F; ++f) sm[slot][f][wave][lane] = r[f];
+        if (lane == 0u) __hip_atomic_fetch_add(&s_cnt[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (wave != (it & 15u)) continue;
+        // ---- this iteration's publisher: the 16 wave sums in tree order ----
+        while (__hip_atomic_load(&s_cnt[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 16u) __builtin_amdgcn_s_sleep(1);
+        float ps[RC_F];
+#pragma unroll
+        for (int f = 0; f < RC_F; ++f) {
+            float v[16];
+            static_for<0, 16>([&](auto w) { v[w] = sm[slot][f][w][lane]; });
+            ps[f] = rect_fold<16>(v);
+        }
+        if (lane == 0u) {
+            __hip_atomic_store(&s_cnt[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&s_gen[slot], want + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#if defined(FR_DIAG_EXP) && FR_DIAG_EXP == 5
+        continue;                                   // diagnostic: the LDS ring and the fold, nothing leaves the workgroup
+#endif
+#pragma unroll
+        for (int f = 0; f < RC_F; ++f) {
+            if ((uint32_t)f >= nf) continue;
+            const uint64_t ti = (uint64_t)(tile + (uint32_t)f) * 64u + lane;
+            if (pe == 1u) {
+                if (ti < a.n_times) __builtin_nontemporal_store(ps[f], &orow[bank_out_index(a, ti)]);
+            } else {
+                __hip_atomic_store(a.ws + (((vt0 + tile + (uint32_t)f) << pe_log2) + e) * 64u + lane, ps[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pub_ps[f] = ps[f];
+            }
+        }
+        if (pe != 1u) {
+            while (pub_stage != 0u) pub_step();     // (only when a workgroup has fewer than 16 iterations between a wave's turns: never)
+            pub_stage = 1u;
+            pub_tile = tile;
+            pub_nf = nf;
+        }
+    }
+    FR_DIAG_MARK(1, 0);
+    while (pub_stage != 0u) pub_step();             // after the last tile: the hand-off's round trips are paid here, once
+    FR_DIAG_MARK(2, 0);
+    FR_DIAG_MARK(3, it);
+}
+
+// Shape of the parameter-stationary launch for (P, voices, frames) on `cus` CUs: groups per wave `ng` (1, 2, 4), tile
+// ranges `ts`; returns the workgroup count (voices * pieces * ts <= cus), or 0 when the shape is not one of its.
+uint32_t bank_rect_plan(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t cus, uint32_t &ng, uint32_t &ts) {
+    const uint64_t tiles = (n_times + 63) / 64;
+    ng = ts = 0;
+    if (!cus || !n_voices || tiles < 8 || tiles > 0x00FFFFFFull) return 0;
+    double best = 0.0;
+    uint32_t best_wgs = 0;
+    for (uint32_t cand = 4; cand >= 1; cand >>= 1) {
+        const uint32_t lg = cand == 4 ? 2u : (cand == 2 ? 1u : 0u);
+        if (log2_p < 7u + lg) continue;
+        const uint32_t pe_log2 = log2_p - 7u - lg;
+        if (pe_log2 > 4u) continue;                                  // at most 16 pieces per voice (the finisher holds them in registers)
+        const uint64_t cols = (uint64_t)n_voices << pe_log2;
+        if (cols > cus) continue;
+        uint64_t split = cus / cols;
+        if (split > tiles / 8) split = tiles / 8;                     // at least 8 tiles per workgroup
+        if (split == 0) continue;
+        const uint64_t per_wg = (tiles + split - 1) / split;
+        const double cost = (double)((per_wg + 1) / 2) * (2.0 * 49.0 * cand + 50.0);   // VALU instructions per wave: leaves + per-iteration overhead
+        if (cols * split * 10 < (uint64_t)cus * 8) continue;         // must use at least 80 % of the chip
+        if (!best_wgs || cost < best) { best = cost; best_wgs = (uint32_t)(cols * split); ng = cand; ts = (uint32_t)split; }
+    }
+    return best_wgs;
+}
+
+static hipError_t launch_bank_rect(const BankArgs &a, hipStream_t s) {
+    const uint64_t tiles = (a.n_times + 63) / 64;
+    uint32_t lg = a.rect_ng == 4 ? 2u : (a.rect_ng == 2 ? 1u : 0u);
+    if ((a.rect_ng != 1 && a.rect_ng != 2 && a.rect_ng != 4) || a.log2_p < 7u + lg || !a.rect_ts || a.rect_ts > tiles) return hipErrorInvalidValue;
+    const uint32_t pe_log2 = a.log2_p - 7u - lg;
+    if (pe_log2 > 4u || a.leaf_variant != 1 || (pe_log2 && (!a.ws || !a.tickets))) return hipErrorInvalidValue;
+    const uint64_t wgs = ((uint64_t)a.n_voices << pe_log2) * a.rect_ts;
+    if (wgs == 0 || wgs > 0x7FFFFFFFull || tiles > 0x00FFFFFFull) return hipErrorInvalidValue;
+    switch (a.rect_ng) {
+    case 4: hipLaunchKernelGGL((bank_rect_kernel<4>), dim3((uint32_t)wgs), dim3(1024), 0, s, a, (uint32_t)tiles, a.rect_ts, pe_log2); break;
+    case 2: hipLaunchKernelGGL((bank_rect_kernel<2>), dim3((uint32_t)wgs), dim3(1024), 0, s, a, (uint32_t)tiles, a.rect_ts, pe_log2); break;
+    default: hipLaunchKernelGGL((bank_rect_kernel<1>), dim3((uint32_t)wgs), dim3(1024), 0, s, a, (uint32_t)tiles, a.rect_ts, pe_log2); break;
+    }
+    return hipGetLastError();
 }
 
 // CUs of the current device (all devices of a node are the same chip), read once.
@@ -1174,16 +1442,16 @@ static hipError_t launch_bank_f(const BankArgs &a, hipStream_t s) {
     uint32_t tiles = (uint32_t)((a.n_times + 64 * F - 1) / (64 * F)), nblocks = (uint32_t)nblocks64;
     const bool w8 = a.waves_per_group == 8;
     if (a.leaf_variant == 0) {
-        if (w8) hipLaunchKernelGGL((bank_kernel<F, 0, 8>), dim3(nblocks), dim3(512), 0, s, a, tiles, nblocks);
-        else hipLaunchKernelGGL((bank_kernel<F, 0, 4>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
+        if (w8) hipLaunchKernelGGL((bank_kernel<F, 0, 8>), dim3(nblocks), dim3(512), a.lds_pad, s, a, tiles, nblocks);
+        else hipLaunchKernelGGL((bank_kernel<F, 0, 4>), dim3(nblocks), dim3(256), a.lds_pad, s, a, tiles, nblocks);
     } else if (a.leaf_variant == 1 && a.host_flags && a.chunk_log2 == a.log2_p) {   // (bank_publishes_rows)
-        if (w8) hipLaunchKernelGGL((bank_kernel<F, 1, 8, true>), dim3(nblocks), dim3(512), 0, s, a, tiles, nblocks);
-        else hipLaunchKernelGGL((bank_kernel<F, 1, 4, true>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
+        if (w8) hipLaunchKernelGGL((bank_kernel<F, 1, 8, true>), dim3(nblocks), dim3(512), a.lds_pad, s, a, tiles, nblocks);
+        else hipLaunchKernelGGL((bank_kernel<F, 1, 4, true>), dim3(nblocks), dim3(256), a.lds_pad, s, a, tiles, nblocks);
     } else if (a.leaf_variant == 1) {
-        if (w8) hipLaunchKernelGGL((bank_kernel<F, 1, 8>), dim3(nblocks), dim3(512), 0, s, a, tiles, nblocks);
-        else hipLaunchKernelGGL((bank_kernel<F, 1, 4>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
+        if (w8) hipLaunchKernelGGL((bank_kernel<F, 1, 8>), dim3(nblocks), dim3(512), a.lds_pad, s, a, tiles, nblocks);
+        else hipLaunchKernelGGL((bank_kernel<F, 1, 4>), dim3(nblocks), dim3(256), a.lds_pad, s, a, tiles, nblocks);
     } else {
-        hipLaunchKernelGGL((bank_kernel<F, 2, 4>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
+        hipLaunchKernelGGL((bank_kernel<F, 2, 4>), dim3(nblocks), dim3(256), a.lds_pad, s, a, tiles, nblocks);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || a.chunk_log2 == a.log2_p) return e;
@@ -1310,6 +1578,7 @@ void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &
 }
 
 hipError_t launch_bank(const BankArgs &a, hipStream_t s) {
+    if (a.small_call == 4) return launch_bank_rect(a, s);
     if (a.small_call == 3) return launch_bank_static(a, s);
     if (a.small_call == 2) {   // short calls: chunks over workgroups, LDS-staged parameters, in-launch combine
         if (a.chunk_log2 < 7 || a.chunk_log2 > 13 || a.chunk_log2 > a.log2_p || a.log2_p - a.chunk_log2 > 8) return hipErrorInvalidValue;

@@ -37,8 +37,8 @@ int main(int argc, char **argv) {
     float *d_params, *d_time, *d_out, *d_ws; uint32_t *d_rows, *d_tickets; unsigned long long *d_diag;
     const size_t max_wgs = (size_t)V * ((T + 63) / 64) * 8 + 4096;
     CK(hipMalloc(&d_params, params.size() * 4)); CK(hipMalloc(&d_time, T * 4)); CK(hipMalloc(&d_out, (size_t)V * T * 4));
-    CK(hipMalloc(&d_ws, std::max<size_t>((size_t)V * T * 8, (size_t)cus * 4096) * 4)); CK(hipMalloc(&d_rows, V * 4));
-    CK(hipMalloc(&d_tickets, max_wgs * fr::BANK_TICKET_STRIDE * 4)); CK(hipMalloc(&d_diag, max_wgs * 16 * 4 * 8));
+    CK(hipMalloc(&d_ws, (std::max<size_t>((size_t)V * T * 8, (size_t)cus * 4096) + (size_t)V * ((T + 63) / 64) * 16 * 64) * 4)); CK(hipMalloc(&d_rows, V * 4));
+    CK(hipMalloc(&d_tickets, max_wgs * fr::BANK_TICKET_STRIDE * 4)); CK(hipMalloc(&d_diag, max_wgs * 16 * 8 * 8));
     CK(hipMemcpy(d_params, params.data(), params.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_time, time.data(), T * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_rows, rows.data(), V * 4, hipMemcpyHostToDevice));
@@ -46,7 +46,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpyToSymbol(HIP_SYMBOL(fr::g_diag), &d_diag, sizeof(d_diag)));
     struct Var { std::string name; uint32_t small, chunk, nw, mult; };
     std::vector<Var> vars = {{"time-major 8 waves", 0, (uint32_t)log2p, 8, 1}, {"short 2 chunks x 8 waves", 2, (uint32_t)log2p - 1, 8, 1},
-                             {"static x1", 3, (uint32_t)log2p, 16, 1}, {"static x2 fine", 3, (uint32_t)log2p, 16, 2}};
+                             {"static x1", 3, (uint32_t)log2p, 16, 1}, {"rect", 4, (uint32_t)log2p, 16, 1}};
     hipStream_t st;
     CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (const Var &v : vars) {
@@ -57,30 +57,44 @@ int main(int argc, char **argv) {
         a.ws = d_ws; a.tickets = d_tickets;
         if (v.small == 3) { a.static_wgs = fr::bank_static_wgs(log2p, V, T, cus * v.mult); a.static_fine = v.mult > 1; }
         if (v.small == 3 && !a.static_wgs) continue;
+        if (v.small == 4 && !fr::bank_rect_plan(log2p, V, T, cus, a.rect_ng, a.rect_ts)) continue;
+        if (v.small == 4) std::printf("rect plan: ng %u ts %u\n", a.rect_ng, a.rect_ts);
         for (int k = 0; k < 30; ++k) {
-            if (k == 29) CK(hipMemsetAsync(d_diag, 0, max_wgs * 16 * 4 * 8, st));
+            if (k == 29) CK(hipMemsetAsync(d_diag, 0, max_wgs * 16 * 8 * 8, st));
             if (fr::launch_bank(a, st) != hipSuccess) { std::printf("%s: launch failed\n", v.name.c_str()); break; }
         }
         CK(hipStreamSynchronize(st));
-        std::vector<unsigned long long> d(max_wgs * 16 * 4);
+        std::vector<unsigned long long> d(max_wgs * 16 * 8);
         CK(hipMemcpy(d.data(), d_diag, d.size() * 8, hipMemcpyDeviceToHost));
         unsigned long long t_min = ~0ull, t_max = 0;
         size_t waves = 0;
         for (size_t w = 0; w < max_wgs * 16; ++w)
-            if (d[w * 4]) { t_min = std::min(t_min, d[w * 4]); t_max = std::max(t_max, std::max(d[w * 4 + 2], d[w * 4 + 1])); ++waves; }
+            if (d[w * 8]) { t_min = std::min(t_min, d[w * 8]); t_max = std::max(t_max, std::max(d[w * 8 + 2], d[w * 8 + 1])); ++waves; }
         std::vector<double> starts, ends, comp, units, fastu;
         std::map<unsigned, double> simd_end, simd_start, simd_busy;   // key: xcc, se, sh, cu, simd
         for (size_t w = 0; w < max_wgs * 16; ++w) {
-            if (!d[w * 4]) continue;
-            const double s0 = (d[w * 4] - t_min) * 0.01, c1 = (d[w * 4 + 1] - t_min) * 0.01, e2 = (std::max(d[w * 4 + 2], d[w * 4 + 1]) - t_min) * 0.01;
+            if (!d[w * 8]) continue;
+            const double s0 = (d[w * 8] - t_min) * 0.01, c1 = (d[w * 8 + 1] - t_min) * 0.01, e2 = (std::max(d[w * 8 + 2], d[w * 8 + 1]) - t_min) * 0.01;
             starts.push_back(s0); ends.push_back(e2); comp.push_back(c1 - s0);
-            const unsigned hw = (unsigned)(d[w * 4 + 3] & 0xFFFFFFFFu), xcc = (unsigned)((d[w * 4 + 3] >> 32) & 15u);
-            units.push_back((double)((d[w * 4 + 3] >> 40) & 255u)); fastu.push_back((double)(d[w * 4 + 3] >> 48));
+            const unsigned hw = (unsigned)(d[w * 8 + 3] & 0xFFFFFFFFu), xcc = (unsigned)((d[w * 8 + 3] >> 32) & 15u);
+            units.push_back((double)((d[w * 8 + 3] >> 40) & 255u)); fastu.push_back((double)(d[w * 8 + 3] >> 48));
             const unsigned key = (xcc << 16) | (((hw >> 13) & 7u) << 12) | (((hw >> 12) & 1u) << 11) | (((hw >> 8) & 15u) << 4) | ((hw >> 4) & 3u);
             simd_end[key] = std::max(simd_end[key], e2);
             if (!simd_start.count(key)) simd_start[key] = s0; else simd_start[key] = std::min(simd_start[key], s0);
             simd_busy[key] += (v.small == 3 ? e2 - s0 : c1 - s0);
         }
+        std::vector<double> clk;
+        std::map<unsigned, int> simd_waves;
+        for (size_t w = 0; w < max_wgs * 16; ++w) {
+            if (!d[w * 8]) continue;
+            const double rt = (double)(std::max(d[w * 8 + 2], d[w * 8 + 1]) - d[w * 8]) * 10e-9;       // seconds (100 MHz)
+            const double cy = (double)(std::max(d[w * 8 + 6], d[w * 8 + 5]) - d[w * 8 + 4]);
+            if (rt > 0) clk.push_back(cy / rt / 1e9);
+            const unsigned hw = (unsigned)(d[w * 8 + 3] & 0xFFFFFFFFu), xcc = (unsigned)((d[w * 8 + 3] >> 32) & 15u);
+            ++simd_waves[(xcc << 16) | (((hw >> 13) & 7u) << 12) | (((hw >> 12) & 1u) << 11) | (((hw >> 8) & 15u) << 4) | ((hw >> 4) & 3u)];
+        }
+        std::vector<double> wps;
+        for (auto &kv : simd_waves) wps.push_back(kv.second);
         std::vector<double> se, ss, sb;
         for (auto &kv : simd_end) { se.push_back(kv.second); ss.push_back(simd_start[kv.first]); sb.push_back(simd_busy[kv.first]); }
         std::printf("\n== %s: %d x %d x %d; %zu waves stamped, span %.2f us (first start -> last end)\n", v.name.c_str(), V, P, T, waves, (t_max - t_min) * 0.01);
@@ -90,6 +104,8 @@ int main(int argc, char **argv) {
         std::printf("   units a wave took with the fast path known at claim time: p0 %.0f p50 %.0f p100 %.0f\n", pct(fastu, 0), pct(fastu, .5), pct(fastu, 1));
         std::printf("   %zu SIMDs seen; a SIMD's first wave starts: p0 %.2f p50 %.2f p100 %.2f; its last wave ends: p0 %.2f p10 %.2f p50 %.2f p90 %.2f p100 %.2f\n", se.size(),
                     pct(ss, 0), pct(ss, .5), pct(ss, 1), pct(se, 0), pct(se, .1), pct(se, .5), pct(se, .9), pct(se, 1));
+        std::printf("   shader clock seen by the waves (s_memtime / s_memrealtime) GHz: p0 %.2f p50 %.2f p100 %.2f; waves stamped per SIMD: p0 %.0f p50 %.0f p100 %.0f\n",
+                    pct(clk, 0), pct(clk, .5), pct(clk, 1), pct(wps, 0), pct(wps, .5), pct(wps, 1));
         std::printf("   sum over a SIMD's waves of (start -> done) us: p0 %.1f p50 %.1f p100 %.1f\n", pct(sb, 0), pct(sb, .5), pct(sb, 1));
     }
     return 0;
