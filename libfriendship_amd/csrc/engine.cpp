@@ -954,18 +954,7 @@ struct fr_renderer {
                 a.flag_value = flag_out.value;
                 if (!bank_publishes_rows(a)) throw Error(FR_ERR_DEVICE, "internal: a bank launch cannot publish row flags");
             }
-            if (a.small_call == 3) {   // few-voice launches: equal static shares, split pairs meet through [wgs][16][64] unit sums + a ticket each
-                used_scratch = true;
-                a.static_wgs = bank_static_wgs(a.log2_p, a.n_voices, blen, bank_device_cus());
-                d_bank_ws.ensure((size_t)a.static_wgs * 16 * 64 * sizeof(float));
-                a.ws = d_bank_ws.as<float>();
-                const size_t need = (size_t)a.static_wgs * BANK_TICKET_STRIDE * sizeof(uint32_t);
-                if (need > d_tickets.bytes) {
-                    d_tickets.ensure(need * 2);
-                    HIP_CHECK(hipMemsetAsync(d_tickets.p, 0, d_tickets.bytes, st));
-                }
-                a.tickets = d_tickets.as<uint32_t>();
-            } else if (a.chunk_log2 != a.log2_p) {
+            if (a.chunk_log2 != a.log2_p) {
                 used_scratch = true;
                 d_bank_ws.ensure(((size_t)a.n_voices << (a.log2_p - a.chunk_log2)) * blen * sizeof(float));
                 a.ws = d_bank_ws.as<float>();

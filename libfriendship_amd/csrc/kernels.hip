@@ -12,22 +12,23 @@
 
 namespace fr {
 
-// Diagnostic build only (tools/fewvoice_bench.hip defines FR_DIAG_STAMPS): per-wave timestamps (s_memrealtime, 100 MHz) and
-// placement, written to a buffer the tool hangs on g_diag.  In the product no stamp executes and none of this exists.
+// Diagnostic build only (tools/fewvoice_diag.hip defines FR_DIAG_STAMPS): per-wave timestamps (s_memrealtime at 100 MHz,
+// s_memtime on the shader clock) and placement (HW_ID, XCC_ID), written to a buffer the tool hangs on g_diag.  In the
+// product no stamp executes and none of this exists.
 #ifdef FR_DIAG_STAMPS
-__device__ unsigned long long *g_diag = nullptr;     // [workgroup][16 waves][8]: start, compute done, end, HW_ID | XCC_ID << 32 | units << 40, then the
-                                                     // same three moments on the shader clock (s_memtime) in slots 4..6
-#define FR_DIAG_MARK(slot, extra)                                                                                          \
+__device__ unsigned long long *g_diag = nullptr;     // [workgroup][16 waves][8]: start, compute done, end, HW_ID | XCC_ID << 32, then the
+                                                     // same three moments on the shader clock in slots 4..6
+#define FR_DIAG_MARK(slot)                                                                                                 \
     do {                                                                                                                   \
         if (g_diag && (threadIdx.x & 63u) == 0u) {                                                                         \
             unsigned long long v_ = __builtin_amdgcn_s_memrealtime();                                                      \
-            if ((slot) == 3) v_ = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) | ((unsigned long long)(__builtin_amdgcn_s_getreg(0xF814) & 15u) << 32) | ((unsigned long long)(extra) << 40); \
+            if ((slot) == 3) v_ = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) | ((unsigned long long)(__builtin_amdgcn_s_getreg(0xF814) & 15u) << 32); \
             g_diag[((size_t)blockIdx.x * 16u + (threadIdx.x >> 6)) * 8u + (slot)] = v_;                                    \
             if ((slot) != 3) g_diag[((size_t)blockIdx.x * 16u + (threadIdx.x >> 6)) * 8u + 4u + (slot)] = __builtin_amdgcn_s_memtime(); \
         }                                                                                                                  \
     } while (0)
 #else
-#define FR_DIAG_MARK(slot, extra) do { } while (0)
+#define FR_DIAG_MARK(slot) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------------
@@ -406,8 +407,8 @@ __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tile
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    FR_DIAG_MARK(0, 0);
-    FR_DIAG_MARK(3, 1);
+    FR_DIAG_MARK(0);
+    FR_DIAG_MARK(3);
     const uint64_t t0 = (uint64_t)tile * (64u * F);
     float t[F];
     bool nonneg = true;
@@ -433,14 +434,14 @@ __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tile
     constexpr bool EXACT = (MODE == 0);
     if (fast) bank_wave_sum<F, true, EXACT>(params, ngroups, levels, t, res);
     else bank_wave_sum<F, false, EXACT>(params, ngroups, levels, t, res);
-    FR_DIAG_MARK(1, 0);
+    FR_DIAG_MARK(1);
 
     __shared__ float sm[NW][F][64];
     __shared__ unsigned long long zmask[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) sm[wave][f][lane] = res[f];
     __syncthreads();
-    FR_DIAG_MARK(2, 0);
+    FR_DIAG_MARK(2);
     // one chunk: straight to the voice's output row; else to the workspace [chunk][voice][t]
     const bool direct = nchunks == 1u;
     float *orow = direct ? a.out + (size_t)a.rows[voice] * a.out_stride
@@ -689,8 +690,8 @@ __global__ void __launch_bounds__(64 * NW) bank_short_kernel(BankArgs a, uint32_
     uint32_t levels = 0;
     while ((1u << levels) < ngroups) ++levels;
     const float *mine = (const float *)(a.params + ((size_t)voice << a.log2_p) + (size_t)chunk * Pc + (size_t)wave * Pw);
-    FR_DIAG_MARK(0, 0);
-    FR_DIAG_MARK(3, 1);
+    FR_DIAG_MARK(0);
+    FR_DIAG_MARK(3);
     ParamGroup first;                                      // requested BEFORE the time row: the two trips to memory overlap
     load_group(first, (const_f32_ptr)mine, 0);
     const float t = bank_time(a, ti);
@@ -700,10 +701,10 @@ __global__ void __launch_bounds__(64 * NW) bank_short_kernel(BankArgs a, uint32_
     float r_wave[1];
     if (fast) bank_wave_sum<1, true, false>(mine, ngroups, levels, tt, r_wave, &first);
     else bank_wave_sum<1, false, false>(mine, ngroups, levels, tt, r_wave, &first);
-    FR_DIAG_MARK(1, 0);
+    FR_DIAG_MARK(1);
     sm[wave][lane] = r_wave[0];
     __syncthreads();
-    FR_DIAG_MARK(2, 0);
+    FR_DIAG_MARK(2);
     float r = 0.0f;
     if (wave == 0u) {   // the NW wave sums in tree order: adjacent pairs, level by level
         float s[NW];
@@ -776,479 +777,7 @@ static hipError_t launch_bank_short(const BankArgs &a, hipStream_t s) {
     const uint64_t nb = (tiles * a.n_voices) << (a.log2_p - a.chunk_log2);
     if (nb == 0) return hipSuccess;
     if (nb > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((bank_short_kernel<NW>), dim3((uint32_t)nb), dim3(64 * NW), a.lds_pad, s, a, (uint32_t)tiles);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Few-voice launches (a GPU's share of a voice-sharded job: 8 x 4096 x 4800 is 600 (voice, tile) pairs on 256 CUs).
-// Whole workgroups of the kernels above deal 2 or 3 pairs to a CU (28 % idle); cutting pairs into chunks evens that out
-// but puts a ticket + read-back of chunk sums in HBM at the END of every pair, and the last of them is the launch's tail
-// (profiles/r02_short_calls.txt: 21.9 us for 15 us of VALU work, whatever the chunk size).  Here the split is STATIC and
-// exact, and the cross-workgroup part comes FIRST:
-//   * one workgroup of 16 waves per CU (`wgs` of them); a pair is 16 units of P/16 partials; workgroup g owns the units
-//     [O*g/wgs, O*(g+1)/wgs) of the linearised (tile, voice, unit) space, O = pairs * 16 -- equal shares to within one
-//     unit (8 x 4096 x 4800: 37 or 38 units each, 1.3 %), and with wgs <= pairs a pair is shared by at most two
-//     workgroups, logical neighbours (same XCD under round-robin placement);
-//   * inside the workgroup the 16 waves take units from a queue in LDS (one ds_add each), so a wave held up by a memory
-//     round trip just takes fewer; a unit's sum goes to its slot in LDS, and the wave whose arrival completes a pair (or
-//     the workgroup's share of one) folds it in the tree's own order -- no workgroup barrier after the set-up;
-//   * the shares of SPLIT pairs are first in the queue: their unit sums are published (sc1 stores, vmcnt(0), one
-//     agent-scope ticket add per workgroup and pair; the later of the two adds reads the other's units back and writes
-//     the row) while the other waves are already in the whole pairs, which end in LDS and a store and nothing else;
-//   * the LAST pair of the queue is cut four times finer (64 units of P/64), so that what a SIMD can be left holding
-//     when the queue runs dry is a quarter of a unit.
-// Zero signs are settled per unit (a sum tree of correctly signed sub-sums has the right sign by IEEE addition).
-// ---------------------------------------------------------------------------------------------------
-constexpr uint32_t ST_RING = 3;          // pair slots in LDS (16 waves hold units of at most 2 consecutive pairs at a time)
-constexpr uint32_t ST_MAX_ITEMS = 24;    // pairs (whole or shared) per workgroup: pairs <= 16 * wgs -> at most 16 + 2
-
-struct StItem {
-    uint32_t tile, voice;
-    uint32_t u0, k;          // this workgroup's units [u0, u0 + k) of the pair, in coarse units (P/16)
-    uint32_t fine;           // 1: processed as 4k units of P/64
-    uint32_t split;          // 1: the pair is shared with the workgroup on the other side of `boundary`
-    uint32_t boundary;       // the pair straddles workgroups `boundary` and `boundary + 1`
-    uint32_t qbase;          // first queue index of the item
-};
-
-template <bool FAST>
-__device__ __forceinline__ float static_unit(const float *params, uint32_t ngroups, uint32_t levels, float t, bool live, uint32_t lane) {
-    const float tt[1] = {t};
-    float r[1];
-    bank_wave_sum<1, FAST, false>(params, ngroups, levels, tt, r);
-    const unsigned long long zm = __ballot(live && r[0] == 0.0f);
-    if (zm != 0ull) {   // the sign of a zero unit sum: -0 iff every leaf of the unit is -0 in the graph's arithmetic
-        const bool ok = wave_leaves_all_negzero<FAST>(params, ngroups, t, zm);
-        if ((zm >> lane) & 1ull) r[0] = ok ? -0.0f : 0.0f;
-    }
-    return r[0];
-}
-
-// consecutive unit sums folded in tree order: adjacent pairs, level by level
-__device__ __forceinline__ float static_fold4(const float (*u)[64], uint32_t lane) { return (u[0][lane] + u[1][lane]) + (u[2][lane] + u[3][lane]); }
-__device__ __forceinline__ float static_fold16(const float (*u)[64], uint32_t lane) {
-    return (static_fold4(u, lane) + static_fold4(u + 4, lane)) + (static_fold4(u + 8, lane) + static_fold4(u + 12, lane));
-}
-
-__global__ void __launch_bounds__(1024, 8) bank_static_kernel(BankArgs a, uint32_t tiles, uint32_t G) {
-    __shared__ float slots[ST_RING][64][64];          // per pair slot: 16 coarse or 64 fine unit sums per lane
-    __shared__ StItem s_items[ST_MAX_ITEMS + 1];
-    __shared__ uint32_t s_next, s_cnt[ST_RING], s_gen[ST_RING];
-    const uint32_t b = blockIdx.x;
-    const uint32_t g = (G % 8u == 0u) ? (b % 8u) * (G / 8u) + b / 8u : b;   // logical neighbours share an XCD
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t V = a.n_voices;
-    if (threadIdx.x < ST_RING) { s_cnt[threadIdx.x] = 0u; s_gen[threadIdx.x] = 0u; }
-    if (threadIdx.x == 0u) {
-        // this workgroup's share: [a0, 16) of pair pf (if a0 != 0), [0, b1) of pair pl (if b1 != 16), the whole pairs between
-        s_next = 0u;
-        const uint64_t O = ((uint64_t)tiles * V) << 4;
-        const uint64_t o0 = O * g / G, o1 = O * (g + 1u) / G;
-        uint32_t n = 0u;
-        auto push = [&](uint32_t pair, uint32_t u0, uint32_t k, uint32_t split, uint32_t boundary) {
-            const uint32_t tile = pair / V;               // (tile, voice) order: a workgroup's pairs share time rows
-            s_items[n] = StItem{tile, pair - tile * V, u0, k, 0u, split, boundary, 0u};
-            ++n;
-        };
-        if (o1 > o0) {
-            const uint32_t pf = (uint32_t)(o0 >> 4), a0 = (uint32_t)(o0 & 15u);
-            const uint32_t pl = (uint32_t)((o1 - 1u) >> 4), b1 = (uint32_t)(o1 - ((uint64_t)pl << 4));
-            if (a0 != 0u) push(pf, a0, (pl == pf ? b1 : 16u) - a0, 1u, g - 1u);   // (pl == pf here only when wgs > pairs: refused by the launcher)
-            if (b1 != 16u && (pl != pf || a0 == 0u)) push(pl, 0u, b1, 1u, g);
-            for (uint32_t p = pf + (a0 != 0u ? 1u : 0u); p < pl + (b1 == 16u ? 1u : 0u) && n < ST_MAX_ITEMS; ++p) push(p, 0u, 16u, 0u, 0u);
-        }
-        if (n) s_items[n - 1u].fine = 1u;
-        if (a.static_fine) for (uint32_t i = 0; i < n; ++i) s_items[i].fine = 1u;
-        uint32_t q = 0u;
-        for (uint32_t i = 0; i < n; ++i) { s_items[i].qbase = q; q += s_items[i].k << (s_items[i].fine ? 2 : 0); }
-        s_items[n] = StItem{0u, 0u, 0u, 0u, 0u, 0u, 0u, q};   // sentinel: qbase = units in all
-        for (uint32_t i = n + 1u; i <= ST_MAX_ITEMS; ++i) s_items[i] = s_items[n];
-    }
-    __syncthreads();
-
-    uint32_t item = 0u, cur_tile = 0xFFFFFFFFu;
-    float t = 0.0f;
-    bool fast = false, live = false;
-    uint64_t ti = 0;
-    FR_DIAG_MARK(0, 0);
-    uint32_t diag_units = 0u;
-    (void)diag_units;
-    for (;;) {
-#if defined(FR_DIAG_EXP) && FR_DIAG_EXP >= 4
-        const uint32_t c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + 16u * (diag_units & 255u);   // diagnostic: static round-robin, no queue
-#else
-        uint32_t c = 0u;
-        if (lane == 0u) c = __hip_atomic_fetch_add(&s_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        c = __builtin_amdgcn_readfirstlane(c);
-#endif
-        // ---- which unit (a wave's claims only grow, so its item index only moves forward) ----
-        while (item < ST_MAX_ITEMS && c >= (uint32_t)__builtin_amdgcn_readfirstlane(s_items[item + 1u].qbase)) ++item;
-        if (item >= ST_MAX_ITEMS || c >= (uint32_t)__builtin_amdgcn_readfirstlane(s_items[ST_MAX_ITEMS].qbase)) break;
-        ++diag_units;
-        if (fast) diag_units += 256u;
-        const uint32_t tile = __builtin_amdgcn_readfirstlane(s_items[item].tile), voice = __builtin_amdgcn_readfirstlane(s_items[item].voice);
-        const uint32_t u0 = __builtin_amdgcn_readfirstlane(s_items[item].u0), k = __builtin_amdgcn_readfirstlane(s_items[item].k);
-        const uint32_t fine = __builtin_amdgcn_readfirstlane(s_items[item].fine), qbase = __builtin_amdgcn_readfirstlane(s_items[item].qbase);
-        const uint32_t fshift = fine ? 2u : 0u;
-        const uint32_t unit = (u0 << fshift) + (c - qbase);                 // within the pair, at this item's granularity
-        const uint32_t ulog = a.log2_p - 4u - fshift;                       // log2(partials per unit)
-        if (tile != cur_tile) {
-            cur_tile = tile;
-            ti = (uint64_t)tile * 64u + lane;
-            t = bank_time(a, ti);
-            live = ti < a.n_times;
-            fast = a.fast_ok && __all(t >= 0.0f && t <= 4294967296.0f);
-        }
-        if (a.hist_dst && voice == 0u && unit == 0u && ti < a.time_valid) a.hist_dst[ti] = t;   // (one unit per tile)
-        const uint32_t slot = item % ST_RING, want = item / ST_RING;
-        // the slot is free once the pair that used it before has been folded (practically always: that pair's units were all
-        // taken two pairs ago)
-#if !(defined(FR_DIAG_EXP) && FR_DIAG_EXP >= 3)
-        while (__hip_atomic_load(&s_gen[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(2);
-#endif
-        const float *up = (const float *)(a.params + ((size_t)voice << a.log2_p) + ((size_t)unit << ulog));
-        const uint32_t ngroups = 1u << (ulog - 3u), levels = ulog - 3u;
-#if defined(FR_DIAG_EXP) && FR_DIAG_EXP == 1
-        const float r = static_unit<true>(up, ngroups, levels, t, live, lane);
-#else
-        const float r = fast ? static_unit<true>(up, ngroups, levels, t, live, lane) : static_unit<false>(up, ngroups, levels, t, live, lane);
-#endif
-        slots[slot][unit][lane] = r;
-        FR_DIAG_MARK(1, 0);
-#if defined(FR_DIAG_EXP) && FR_DIAG_EXP >= 3
-        continue;      // diagnostic: compute only (no arrival, no fold, no output; the slot wait is compiled out too)
-#endif
-        // ---- arrival: the wave that completes the workgroup's share of the pair folds it ----
-        uint32_t old = 0u;
-        if (lane == 0u) old = __hip_atomic_fetch_add(&s_cnt[slot], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        old = __builtin_amdgcn_readfirstlane(old);
-        if (old != (k << fshift) - 1u) continue;
-        float *orow = a.out + (size_t)a.rows[voice] * a.out_stride;
-        const uint32_t split = __builtin_amdgcn_readfirstlane(s_items[item].split);
-        float v[16];                                                        // the pair's 16 coarse unit sums (mine: from LDS)
-        static_for<0, 16>([&](auto j) {
-            v[j] = 0.0f;
-            if ((uint32_t)j >= u0 && (uint32_t)j < u0 + k) v[j] = fine ? static_fold4(slots[slot] + 4u * (uint32_t)j, lane) : slots[slot][(uint32_t)j][lane];
-        });
-        if (lane == 0u) {   // the slot may be used again (its sums are in registers now)
-            __hip_atomic_store(&s_cnt[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&s_gen[slot], want + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (split) {
-            // publish this share's unit sums, take the pair's ticket; if the other share is already there, finish the pair
-            const uint32_t boundary = __builtin_amdgcn_readfirstlane(s_items[item].boundary);
-            float *wsp = a.ws + (size_t)boundary * (16u * 64u) + lane;
-            static_for<0, 16>([&](auto j) {
-                if ((uint32_t)j >= u0 && (uint32_t)j < u0 + k) __hip_atomic_store(wsp + (uint32_t)j * 64u, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            });
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            uint32_t before = 0u;
-            if (lane == 0u) before = __hip_atomic_fetch_add(a.tickets + (size_t)boundary * TICKET_STRIDE, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            before = __builtin_amdgcn_readfirstlane(before);
-            if (before + k != 16u) continue;
-            static_for<0, 16>([&](auto j) {
-                if (!((uint32_t)j >= u0 && (uint32_t)j < u0 + k)) v[j] = __hip_atomic_load(wsp + (uint32_t)j * 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            });
-            if (lane == 0u) __hip_atomic_store(a.tickets + (size_t)boundary * TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
-        }
-        const float res = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) + (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
-        if (live) __builtin_nontemporal_store(res, &orow[bank_out_index(a, ti)]);
-    }
-    FR_DIAG_MARK(2, 0);
-    FR_DIAG_MARK(3, diag_units);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Parameter-stationary bank kernel ("rect"), for launches with few voices and many tiles -- a GPU's share of a
-// voice-sharded job.  What the diagnostic stamps showed about the kernels above on such launches (tools/fewvoice_diag.hip,
-// profiles/r03_fewvoices.txt): every 8 partials cost a wave one s_load_dwordx16, ~600 cycles when it misses the scalar
-// cache; the time-major kernel hides that only because neighbouring workgroups stream the SAME voice's parameters in
-// lockstep (scalar-cache hits) and because 6-8 waves share a SIMD; a wave left alone on its SIMD at the end of a launch
-// runs at a fifth of the VALU rate, and whole workgroups deal unevenly over the CUs.  Here the roles are swapped:
-//   * a workgroup (16 waves, one per CU) owns a RECTANGLE: one voice, one piece of 128 * NG consecutive partials, a
-//     contiguous range of the call's 64-frame tiles; a wave owns 8 * NG partials whose {w, A4} it loads ONCE into SGPRs
-//     (NG <= 4 groups: 64 scalar registers) and then walks the tiles, two per iteration: the inner loop has no memory
-//     operation at all except the tile's time values, and runs at the VALU rate at any occupancy;
-//   * per iteration the 16 wave sums meet in an LDS ring slot (arrival counter, no workgroup barrier); the iteration's
-//     publisher -- the waves take turns -- folds them in tree order and, when the voice has more than one piece, publishes
-//     the piece sum (sc1 store) and one iteration later adds to the (voice, tile) ticket; the wave whose add is the last of
-//     the voice's pieces reads the others back, folds them in tree order and writes the row.  Each step of that hand-off is
-//     issued one iteration before its result is needed, so no wave waits on memory except after the very last tile;
-//   * voices x pieces x tile ranges = the number of CUs (8 x 4096 x 4800: 8 voices x 8 pieces x 4 ranges of 18 or 19
-//     tiles), so every CU carries the same load to within a tile.
-// Same bits as the graph: leaves in FMA form with zero signs settled per wave sum from the product form, every add the
-// tree's own (8 leaves, NG groups, 16 waves, the pieces: all aligned powers of two).
-// ---------------------------------------------------------------------------------------------------
-constexpr uint32_t RC_RING = 4;          // iterations the fastest wave of a workgroup may be ahead of its publisher
-#ifndef FR_RC_F
-#define FR_RC_F 2
-#endif
-constexpr int RC_F = FR_RC_F;            // tiles per iteration
-
-template <int NG, bool FAST, bool EXACT>
-__device__ __forceinline__ float rect_wave_sum(const ParamGroup (&pg)[NG], float t) {
-    float gs[NG];
-    static_for<0, NG>([&](auto g) {
-        const float l0 = bank_leaf<FAST, EXACT>(t, pg[g].w[0], pg[g].A[0]), l1 = bank_leaf<FAST, EXACT>(t, pg[g].w[1], pg[g].A[1]);
-        const float l2 = bank_leaf<FAST, EXACT>(t, pg[g].w[2], pg[g].A[2]), l3 = bank_leaf<FAST, EXACT>(t, pg[g].w[3], pg[g].A[3]);
-        const float l4 = bank_leaf<FAST, EXACT>(t, pg[g].w[4], pg[g].A[4]), l5 = bank_leaf<FAST, EXACT>(t, pg[g].w[5], pg[g].A[5]);
-        const float l6 = bank_leaf<FAST, EXACT>(t, pg[g].w[6], pg[g].A[6]), l7 = bank_leaf<FAST, EXACT>(t, pg[g].w[7], pg[g].A[7]);
-        gs[g] = ((l0 + l1) + (l2 + l3)) + ((l4 + l5) + (l6 + l7));
-    });
-    if constexpr (NG == 1) return gs[0];
-    else if constexpr (NG == 2) return gs[0] + gs[1];
-    else return (gs[0] + gs[1]) + (gs[2] + gs[3]);
-}
-
-// every leaf of the wave's share exactly -0.0 in the graph's arithmetic (product-form leaves)?
-template <int NG, bool FAST>
-__device__ __forceinline__ bool rect_all_negzero(const ParamGroup (&pg)[NG], float t) {
-    uint32_t all_and = 0xFFFFFFFFu, all_or = 0u;
-    static_for<0, NG>([&](auto g) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t b = __float_as_uint(bank_leaf<FAST, true>(t, pg[g].w[j], pg[g].A[j]));
-            all_and &= b;
-            all_or |= b;
-        }
-    });
-    return all_and == 0x80000000u && all_or == 0x80000000u;
-}
-
-template <int N>
-__device__ __forceinline__ float rect_fold(const float (&v)[16]) {   // v[0..N) in tree order
-    if constexpr (N == 1) return v[0];
-    else if constexpr (N == 2) return v[0] + v[1];
-    else if constexpr (N == 4) return (v[0] + v[1]) + (v[2] + v[3]);
-    else if constexpr (N == 8) return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-    else return (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) + (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
-}
-
-template <int NG>
-__global__ void __launch_bounds__(1024) bank_rect_kernel(BankArgs a, uint32_t tiles, uint32_t ts, uint32_t pe_log2) {
-    __shared__ float sm[RC_RING][RC_F][16][64];          // 32 KB: the 16 wave sums of an iteration's tiles
-    __shared__ uint32_t s_cnt[RC_RING], s_gen[RC_RING];
-    const uint32_t G = gridDim.x, b = blockIdx.x;
-    const uint32_t g = (G % 8u == 0u) ? (b % 8u) * (G / 8u) + b / 8u : b;   // the pieces of a (voice, tile range) are neighbours on one XCD
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t pe = 1u << pe_log2, e = g & (pe - 1u);
-    const uint32_t vr = g >> pe_log2, voice = vr / ts, rr = vr - voice * ts;
-    const uint32_t tb = (uint32_t)((uint64_t)tiles * rr / ts), te = (uint32_t)((uint64_t)tiles * (rr + 1u) / ts);
-    if (threadIdx.x < RC_RING) { s_cnt[threadIdx.x] = 0u; s_gen[threadIdx.x] = 0u; }
-    // the wave's parameters: 8 * NG partials, loaded once, stationary in scalar registers
-    const_f32_ptr pp = (const_f32_ptr)(a.params + ((size_t)voice << a.log2_p) + (size_t)e * (128u * NG) + (size_t)wave * (8u * NG));
-    ParamGroup pg[NG];
-    static_for<0, NG>([&](auto k) { load_group(pg[k], pp, (uint32_t)k); });
-    __syncthreads();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-
-    const size_t vt0 = (size_t)voice * tiles;             // (voice, tile) index base: tickets and the piece-sum workspace
-    float *const orow = a.out + (size_t)a.rows[voice] * a.out_stride;
-    // the publisher's hand-off in flight (at most one per wave: a wave publishes every 16th iteration)
-    uint32_t pub_stage = 0u, pub_tile = 0u, pub_nf = 0u;
-    float pub_ps[RC_F] = {};
-    uint32_t pub_old[RC_F] = {};
-    auto pub_step = [&]() {
-        if (pub_stage == 1u) {          // the piece sums were stored an iteration ago: acknowledged by now -> count this piece in
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int f = 0; f < RC_F; ++f)
-                if ((uint32_t)f < pub_nf && lane == 0u)
-                    pub_old[f] = __hip_atomic_fetch_add(a.tickets + (vt0 + pub_tile + (uint32_t)f) * TICKET_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pub_stage = 2u;
-            return;
-        }
-        // stage 2 -- the adds have returned: the last piece of a (voice, tile) reads the others back (a round trip this wave
-        // waits for while the other 15 compute: the ring absorbs it), adds the voice's top levels and writes the row
-#pragma unroll
-        for (int f = 0; f < RC_F; ++f) {
-            const uint32_t old = __builtin_amdgcn_readfirstlane(pub_old[f]);
-            if (!((uint32_t)f < pub_nf && old == pe - 1u)) continue;
-            const float *src = a.ws + ((vt0 + pub_tile + (uint32_t)f) << pe_log2) * 64u + lane;
-            float v[16];
-            static_for<0, 16>([&](auto j) {
-                v[j] = 0.0f;
-                if ((uint32_t)j < pe) v[j] = (uint32_t)j == e ? pub_ps[f] : __hip_atomic_load(src + (uint32_t)j * 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            });
-            float res;
-            switch (pe_log2) {
-            case 1: res = rect_fold<2>(v); break;
-            case 2: res = rect_fold<4>(v); break;
-            case 3: res = rect_fold<8>(v); break;
-            default: res = rect_fold<16>(v); break;
-            }
-            const uint64_t ti = (uint64_t)(pub_tile + (uint32_t)f) * 64u + lane;
-            if (ti < a.n_times) __builtin_nontemporal_store(res, &orow[bank_out_index(a, ti)]);
-            if (lane == 0u) __hip_atomic_store(a.tickets + (vt0 + pub_tile + (uint32_t)f) * TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        pub_stage = 0u;
-    };
-
-    // frames as 32-bit numbers (tiles < 2^24 here): the stored part of the time row is [t_lo, t_hi) of the window
-    const uint32_t t_lo = (uint32_t)(a.time_skip < 0x7FFFFFFFull ? a.time_skip : 0x7FFFFFFFull);
-    const uint32_t t_hi = (uint32_t)(a.time_skip + a.time_valid < 0x7FFFFFFFull ? a.time_skip + a.time_valid : 0x7FFFFFFFull);
-    const uint32_t n_frames = (uint32_t)(a.n_times < 0x7FFFFFFFull ? a.n_times : 0x7FFFFFFFull);
-    const float *const tbase = a.time - a.time_skip;                        // (read only inside [t_lo, t_hi))
-    const bool appends = a.hist_dst && voice == 0u && e == 0u && wave == 0u; // this wave also appends the row to the input history
-    auto load_t = [&](uint32_t tile_, uint32_t f_) -> float {
-        const uint32_t ti = (tile_ + f_) * 64u + lane;
-        return (tile_ + f_ < te && ti >= t_lo && ti < t_hi) ? tbase[ti] : 0.0f;
-    };
-    float tn[RC_F];                                                         // the NEXT iteration's time values, requested one iteration ahead
-#pragma unroll
-    for (int f = 0; f < RC_F; ++f) tn[f] = load_t(tb, (uint32_t)f);
-    uint32_t it = 0u;
-    FR_DIAG_MARK(0, 0);
-    for (uint32_t tile = tb; tile < te; tile += RC_F, ++it) {
-        const uint32_t nf = te - tile < (uint32_t)RC_F ? te - tile : (uint32_t)RC_F;
-        if (pub_stage != 0u) pub_step();
-        const uint32_t slot = it % RC_RING, want = it / RC_RING;
-        float t[RC_F];
-        bool in_range = true;
-#pragma unroll
-        for (int f = 0; f < RC_F; ++f) {
-            t[f] = tn[f];
-            tn[f] = load_t(tile + (uint32_t)RC_F, (uint32_t)f);
-            in_range = in_range && t[f] >= 0.0f && t[f] <= 4294967296.0f;
-            const uint32_t ti = (tile + (uint32_t)f) * 64u + lane;
-            if (appends && (uint32_t)f < nf && ti >= t_lo && ti < t_hi) a.hist_dst[ti - t_lo] = t[f];
-        }
-        const bool fast = a.fast_ok && __all(in_range);
-        float r[RC_F];
-        if (fast) {
-#pragma unroll
-            for (int f = 0; f < RC_F; ++f) r[f] = rect_wave_sum<NG, true, false>(pg, t[f]);
-        } else {
-#pragma unroll
-            for (int f = 0; f < RC_F; ++f) r[f] = rect_wave_sum<NG, false, false>(pg, t[f]);
-        }
-#pragma unroll
-        for (int f = 0; f < RC_F; ++f) {   // the sign of a zero wave sum: -0 iff every leaf of the wave's share is -0
-            const uint32_t ti = (tile + (uint32_t)f) * 64u + lane;
-            if (__ballot((uint32_t)f < nf && ti < n_frames && r[f] == 0.0f) != 0ull) {
-                const bool ok = fast ? rect_all_negzero<NG, true>(pg, t[f]) : rect_all_negzero<NG, false>(pg, t[f]);
-                if (r[f] == 0.0f) r[f] = ok ? -0.0f : 0.0f;
-            }
-        }
-#if defined(FR_DIAG_EXP) && FR_DIAG_EXP == 6
-#pragma unroll
-        for (int f = 0; f < RC_F; ++f) sm[slot][f][wave][lane] = r[f];      // diagnostic: compute and LDS store only, no hand-off at all
-        continue;
-#endif
-        // the ring slot is free once the iteration that used it before has been folded (RC_RING iterations ago)
-        while (__hip_atomic_load(&s_gen[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-        for (int f = 0; f < RC_F; ++f) sm[slot][f][wave][lane] = r[f];
-        if (lane == 0u) __hip_atomic_fetch_add(&s_cnt[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (wave != (it & 15u)) continue;
-        // ---- this iteration's publisher: the 16 wave sums in tree order ----
-        while (__hip_atomic_load(&s_cnt[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 16u) __builtin_amdgcn_s_sleep(1);
-        float ps[RC_F];
-#pragma unroll
-        for (int f = 0; f < RC_F; ++f) {
-            float v[16];
-            static_for<0, 16>([&](auto w) { v[w] = sm[slot][f][w][lane]; });
-            ps[f] = rect_fold<16>(v);
-        }
-        if (lane == 0u) {
-            __hip_atomic_store(&s_cnt[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&s_gen[slot], want + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-#if defined(FR_DIAG_EXP) && FR_DIAG_EXP == 5
-        continue;                                   // diagnostic: the LDS ring and the fold, nothing leaves the workgroup
-#endif
-#pragma unroll
-        for (int f = 0; f < RC_F; ++f) {
-            if ((uint32_t)f >= nf) continue;
-            const uint64_t ti = (uint64_t)(tile + (uint32_t)f) * 64u + lane;
-            if (pe == 1u) {
-                if (ti < a.n_times) __builtin_nontemporal_store(ps[f], &orow[bank_out_index(a, ti)]);
-            } else {
-                __hip_atomic_store(a.ws + (((vt0 + tile + (uint32_t)f) << pe_log2) + e) * 64u + lane, ps[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pub_ps[f] = ps[f];
-            }
-        }
-        if (pe != 1u) {
-            while (pub_stage != 0u) pub_step();     // (only when a workgroup has fewer than 16 iterations between a wave's turns: never)
-            pub_stage = 1u;
-            pub_tile = tile;
-            pub_nf = nf;
-        }
-    }
-    FR_DIAG_MARK(1, 0);
-    while (pub_stage != 0u) pub_step();             // after the last tile: the hand-off's round trips are paid here, once
-    FR_DIAG_MARK(2, 0);
-    FR_DIAG_MARK(3, it);
-}
-
-// Shape of the parameter-stationary launch for (P, voices, frames) on `cus` CUs: groups per wave `ng` (1, 2, 4), tile
-// ranges `ts`; returns the workgroup count (voices * pieces * ts <= cus), or 0 when the shape is not one of its.
-uint32_t bank_rect_plan(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t cus, uint32_t &ng, uint32_t &ts) {
-    const uint64_t tiles = (n_times + 63) / 64;
-    ng = ts = 0;
-    if (!cus || !n_voices || tiles < 8 || tiles > 0x00FFFFFFull) return 0;
-    double best = 0.0;
-    uint32_t best_wgs = 0;
-    for (uint32_t cand = 4; cand >= 1; cand >>= 1) {
-        const uint32_t lg = cand == 4 ? 2u : (cand == 2 ? 1u : 0u);
-        if (log2_p < 7u + lg) continue;
-        const uint32_t pe_log2 = log2_p - 7u - lg;
-        if (pe_log2 > 4u) continue;                                  // at most 16 pieces per voice (the finisher holds them in registers)
-        const uint64_t cols = (uint64_t)n_voices << pe_log2;
-        if (cols > cus) continue;
-        uint64_t split = cus / cols;
-        if (split > tiles / 8) split = tiles / 8;                     // at least 8 tiles per workgroup
-        if (split == 0) continue;
-        const uint64_t per_wg = (tiles + split - 1) / split;
-        const double cost = (double)((per_wg + 1) / 2) * (2.0 * 49.0 * cand + 50.0);   // VALU instructions per wave: leaves + per-iteration overhead
-        if (cols * split * 10 < (uint64_t)cus * 8) continue;         // must use at least 80 % of the chip
-        if (!best_wgs || cost < best) { best = cost; best_wgs = (uint32_t)(cols * split); ng = cand; ts = (uint32_t)split; }
-    }
-    return best_wgs;
-}
-
-static hipError_t launch_bank_rect(const BankArgs &a, hipStream_t s) {
-    const uint64_t tiles = (a.n_times + 63) / 64;
-    uint32_t lg = a.rect_ng == 4 ? 2u : (a.rect_ng == 2 ? 1u : 0u);
-    if ((a.rect_ng != 1 && a.rect_ng != 2 && a.rect_ng != 4) || a.log2_p < 7u + lg || !a.rect_ts || a.rect_ts > tiles) return hipErrorInvalidValue;
-    const uint32_t pe_log2 = a.log2_p - 7u - lg;
-    if (pe_log2 > 4u || a.leaf_variant != 1 || (pe_log2 && (!a.ws || !a.tickets))) return hipErrorInvalidValue;
-    const uint64_t wgs = ((uint64_t)a.n_voices << pe_log2) * a.rect_ts;
-    if (wgs == 0 || wgs > 0x7FFFFFFFull || tiles > 0x00FFFFFFull) return hipErrorInvalidValue;
-    switch (a.rect_ng) {
-    case 4: hipLaunchKernelGGL((bank_rect_kernel<4>), dim3((uint32_t)wgs), dim3(1024), 0, s, a, (uint32_t)tiles, a.rect_ts, pe_log2); break;
-    case 2: hipLaunchKernelGGL((bank_rect_kernel<2>), dim3((uint32_t)wgs), dim3(1024), 0, s, a, (uint32_t)tiles, a.rect_ts, pe_log2); break;
-    default: hipLaunchKernelGGL((bank_rect_kernel<1>), dim3((uint32_t)wgs), dim3(1024), 0, s, a, (uint32_t)tiles, a.rect_ts, pe_log2); break;
-    }
-    return hipGetLastError();
-}
-
-// CUs of the current device (all devices of a node are the same chip), read once.
-uint32_t bank_device_cus() {
-    static const uint32_t cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 0; }
-        return (uint32_t)(n > 0 ? n : 0);
-    }();
-    return cus;
-}
-
-// Workgroups the static kernel would use for this shape on a chip of `cus` CUs (0: the shape is not one of its).
-uint32_t bank_static_wgs(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t cus) {
-    const uint64_t pairs = ((n_times + 63) / 64) * n_voices;
-    if (log2_p < 10 || log2_p > 15 || cus == 0 || pairs < cus || pairs > 16ull * cus) return 0;
-    return cus;
-}
-
-static hipError_t launch_bank_static(const BankArgs &a, hipStream_t s) {
-    const uint64_t tiles = (a.n_times + 63) / 64;
-    const uint64_t pairs = tiles * a.n_voices;
-    // a unit is P/16 (P/64 in a workgroup's last pair): at least one group of 8 partials, at most 2048 per wave
-    if (a.log2_p < 9 || a.log2_p > 15 || !a.static_wgs || a.static_wgs > pairs || pairs > 16ull * a.static_wgs) return hipErrorInvalidValue;
-    if (!a.ws || !a.tickets || a.leaf_variant != 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(bank_static_kernel, dim3(a.static_wgs), dim3(1024), 0, s, a, (uint32_t)tiles, a.static_wgs);
+    hipLaunchKernelGGL((bank_short_kernel<NW>), dim3((uint32_t)nb), dim3(64 * NW), 0, s, a, (uint32_t)tiles);
     return hipGetLastError();
 }
 
@@ -1442,16 +971,16 @@ static hipError_t launch_bank_f(const BankArgs &a, hipStream_t s) {
     uint32_t tiles = (uint32_t)((a.n_times + 64 * F - 1) / (64 * F)), nblocks = (uint32_t)nblocks64;
     const bool w8 = a.waves_per_group == 8;
     if (a.leaf_variant == 0) {
-        if (w8) hipLaunchKernelGGL((bank_kernel<F, 0, 8>), dim3(nblocks), dim3(512), a.lds_pad, s, a, tiles, nblocks);
-        else hipLaunchKernelGGL((bank_kernel<F, 0, 4>), dim3(nblocks), dim3(256), a.lds_pad, s, a, tiles, nblocks);
+        if (w8) hipLaunchKernelGGL((bank_kernel<F, 0, 8>), dim3(nblocks), dim3(512), 0, s, a, tiles, nblocks);
+        else hipLaunchKernelGGL((bank_kernel<F, 0, 4>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
     } else if (a.leaf_variant == 1 && a.host_flags && a.chunk_log2 == a.log2_p) {   // (bank_publishes_rows)
-        if (w8) hipLaunchKernelGGL((bank_kernel<F, 1, 8, true>), dim3(nblocks), dim3(512), a.lds_pad, s, a, tiles, nblocks);
-        else hipLaunchKernelGGL((bank_kernel<F, 1, 4, true>), dim3(nblocks), dim3(256), a.lds_pad, s, a, tiles, nblocks);
+        if (w8) hipLaunchKernelGGL((bank_kernel<F, 1, 8, true>), dim3(nblocks), dim3(512), 0, s, a, tiles, nblocks);
+        else hipLaunchKernelGGL((bank_kernel<F, 1, 4, true>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
     } else if (a.leaf_variant == 1) {
-        if (w8) hipLaunchKernelGGL((bank_kernel<F, 1, 8>), dim3(nblocks), dim3(512), a.lds_pad, s, a, tiles, nblocks);
-        else hipLaunchKernelGGL((bank_kernel<F, 1, 4>), dim3(nblocks), dim3(256), a.lds_pad, s, a, tiles, nblocks);
+        if (w8) hipLaunchKernelGGL((bank_kernel<F, 1, 8>), dim3(nblocks), dim3(512), 0, s, a, tiles, nblocks);
+        else hipLaunchKernelGGL((bank_kernel<F, 1, 4>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
     } else {
-        hipLaunchKernelGGL((bank_kernel<F, 2, 4>), dim3(nblocks), dim3(256), a.lds_pad, s, a, tiles, nblocks);
+        hipLaunchKernelGGL((bank_kernel<F, 2, 4>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || a.chunk_log2 == a.log2_p) return e;
@@ -1478,18 +1007,6 @@ void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &
     frames_per_lane = 1;
     voices_per_wave = 0;
     small_call = 0;
-    {
-        // few-voice launches: between one and a dozen (voice, tile) pairs per CU -- equal static shares (bank_static_kernel)
-        static const int mode = [] { const char *e = std::getenv("FR_BANK_STATIC"); return e ? std::atoi(e) : 0; }();
-        static const uint64_t max_pairs = [] { const char *e = std::getenv("FR_STATIC_MAX_PAIRS"); return e ? (uint64_t)std::atoll(e) : 3072ull; }();
-        const uint64_t pairs = ((n_times + 63) / 64) * n_voices;
-        if (mode && pairs <= max_pairs && bank_static_wgs(log2_p, n_voices, n_times, bank_device_cus())) {
-            small_call = 3;
-            chunk_log2 = log2_p;      // (no chunk workspace of the other kernels' kind; the engine sizes ws / tickets by static_wgs)
-            waves_per_group = 16;
-            return;
-        }
-    }
     {
         // short calls: few (voice, tile) pairs.  Chunks of >= 512 partials until there are ~256 workgroups of 16 waves.
         // Measured at 64 x 4096 (tools/short_call_probe.py, profiles/r02_short_calls.txt), us per call, this kernel vs the
@@ -1578,8 +1095,6 @@ void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &
 }
 
 hipError_t launch_bank(const BankArgs &a, hipStream_t s) {
-    if (a.small_call == 4) return launch_bank_rect(a, s);
-    if (a.small_call == 3) return launch_bank_static(a, s);
     if (a.small_call == 2) {   // short calls: chunks over workgroups, LDS-staged parameters, in-launch combine
         if (a.chunk_log2 < 7 || a.chunk_log2 > 13 || a.chunk_log2 > a.log2_p || a.log2_p - a.chunk_log2 > 8) return hipErrorInvalidValue;
         if (a.chunk_log2 != a.log2_p && (!a.ws || !a.tickets)) return hipErrorInvalidValue;

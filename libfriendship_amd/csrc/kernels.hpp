@@ -77,14 +77,7 @@ struct BankArgs {
     uint32_t *host_flags;
     uint32_t flag_value;
     uint32_t *tickets;         // small_call == 2 with chunks: [n_voices][tiles] arrival counters, BANK_TICKET_STRIDE words
-                               // apart, all zero between launches; small_call == 3: [static_wgs] of them
-    uint32_t lds_pad;          // extra dynamic LDS bytes per workgroup (time-major and short-call launches): caps the workgroups a CU takes,
-                               // which evens out how the dispatcher deals a launch of a few hundred workgroups (bank_shape)
-    uint32_t rect_ng, rect_ts; // small_call == 4 (parameter-stationary kernel, bank_rect_plan): groups of 8 partials per wave, tile ranges;
-                               // ws = [n_voices][tiles][pieces][64] floats, tickets = [n_voices][tiles], when a voice has several pieces
-    uint32_t static_fine;      // small_call == 3: every pair in units of P/64 (more workgroups than CUs: fewer units per wave)
-    uint32_t static_wgs;       // small_call == 3 (few-voice launches, bank_static_kernel): workgroups of 16 waves, one per CU,
-                               // each with an equal static share of the (tile, voice, unit) space; ws = [static_wgs][16][64] floats
+                               // apart, all zero between launches
     // general voices (launch_gbank): groups[i] = log2(item leaves, <= 11) | merges_after << 4; params = the items'
     // {w, -4*amp} pairs in order, items of < 8 leaves padded to 8 pairs; voice v owns items
     // [group_off[2v], group_off[2v+2]) and its parameters start at pair 8 * group_off[2v+1]
@@ -127,11 +120,6 @@ hipError_t launch_bank_stream(const BankArgs &a, BankStreamCtl *ctl_dev, BankStr
 void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane,
                 uint32_t &waves_per_group, uint32_t &small_call, uint32_t &voices_per_wave);
 uint64_t bank_blocks(const BankArgs &a);
-// Workgroups bank_static_kernel would use for this shape on a chip of `cus` CUs; 0 when the shape is not one of its
-// (bank_shape asks with the current device's CU count and FR_BANK_STATIC).
-uint32_t bank_static_wgs(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t cus);
-uint32_t bank_device_cus();
-uint32_t bank_rect_plan(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t cus, uint32_t &ng, uint32_t &ts);
 bool bank_publishes_rows(const BankArgs &a);
 hipError_t launch_bank(const BankArgs &a, hipStream_t s);
 hipError_t launch_gbank(const BankArgs &a, hipStream_t s);   // voices that are arbitrary Sum2 trees (schedule form)

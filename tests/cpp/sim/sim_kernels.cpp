@@ -102,8 +102,6 @@ void bank_shape(uint32_t log2_p, uint32_t, uint64_t, uint32_t &chunk_log2, uint3
     voices_per_wave = 0;
 }
 uint64_t bank_blocks(const BankArgs &a) { return ((a.n_times + 63) / 64) * a.n_voices; }
-uint32_t bank_static_wgs(uint32_t, uint32_t, uint64_t, uint32_t) { return 0; }   // (the few-voice kernel is a device matter)
-uint32_t bank_device_cus() { return 0; }
 bool bank_publishes_rows(const BankArgs &a) { return a.host_flags && !a.small_call && !a.voices_per_wave && a.leaf_variant == 1 && a.chunk_log2 == a.log2_p; }
 
 hipError_t launch_bank_stream(const BankArgs &, BankStreamCtl *, BankStreamDev *, hipStream_t) { return hipErrorNotSupported; }   // (no resident launches on the simulator)

@@ -452,10 +452,10 @@ def test_short_call_kernel_equals_block_render(hip_lib, V, P, T, block):
 
 @pytest.mark.parametrize("V,P,T,block", [(8, 4096, 4800, 1024), (16, 4096, 4800, 640), (5, 2048, 4777, 1000), (3, 16384, 6400, 704),
                                          (32, 4096, 4800, 448), (9, 8192, 2000, 512)])
-def test_few_voice_static_kernel_equals_block_render(hip_lib, V, P, T, block):
-    """A GPU's share of a voice-sharded job -- few voices, a long call: 256..3072 (voice, tile) pairs -- runs the static-share
-    kernel (bank_static_kernel: one workgroup per CU, equal shares of the (tile, voice, piece) space, split pairs meeting
-    through piece sums + a ticket).  The same frames rendered in blocks take other kernels (fewer pairs): every frame of
+def test_few_voice_launch_equals_block_render(hip_lib, V, P, T, block):
+    """A GPU's share of a voice-sharded job -- few voices, a long call: a few hundred to a few thousand (voice, tile) pairs,
+    8 x 4096 x 4800 being one GPU's step of config C on 8 GPUs -- takes the short-call kernel with chunks + tickets or the
+    time-major kernel (bank_shape).  The same frames rendered in blocks take other shapes of those kernels: every frame of
     every voice must be the same bits, several passes over the same tickets."""
     tree = synth.additive_tree(V, P, seed=V + P, detune=True)
     t = synth.time_ramp(0, T)
@@ -468,11 +468,11 @@ def test_few_voice_static_kernel_equals_block_render(hip_lib, V, P, T, block):
             assert same_bits(whole, parts), f"pass {rep}: " + first_diff(whole, parts)
 
 
-def test_few_voice_static_kernel_against_oracle(hip_lib, oracle_lib):
-    """The static-share kernel against the oracle at the size it was built for (8 voices x 4096 partials x 4800 frames, a
-    GPU's share of config C on 8 GPUs): sampled frames of every voice incl. t = 0 (exact zeros whose sign the units settle),
-    a silent voice and one with -0 amplitudes (every unit sum a zero), then hostile time rows (negative, fractional, huge,
-    NaN: the general fract path), and the input history the launch appended."""
+def test_few_voice_launch_against_oracle(hip_lib, oracle_lib):
+    """A GPU's share of config C on 8 GPUs (8 voices x 4096 partials x 4800 frames) against the oracle: sampled frames of
+    every voice incl. t = 0 (exact zeros whose sign the chunks settle), a silent voice and one with -0 amplitudes (every
+    chunk sum a zero), then hostile time rows (negative, fractional, huge, NaN: the general fract path), and the input
+    history the launch appended (row 0 reads it back through a Delay)."""
     V, P, T = 8, 4096, 4800
     p = synth.voice_params(V, P, seed=11, detune=True)
     w, amp = p["w"].copy(), p["amp"].copy()

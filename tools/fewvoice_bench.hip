@@ -1,5 +1,7 @@
-// fewvoice_bench.hip -- a GPU's share of a voice-sharded job (few voices, long calls): the time-major kernel, the short-call
-// kernel with chunks + ticket combine, and the static-share kernel (bank_static_kernel), in ONE process, interleaved rounds.
+// fewvoice_bench.hip -- a GPU's share of a voice-sharded job (few voices, long calls): the time-major kernel and the short-call
+// kernel with chunks + ticket combine at several shapes, in ONE process, interleaved rounds.  (Round 3 also ran two new
+// kernels through it -- equal static shares per CU, and parameters stationary in SGPRs with tiles streaming -- both slower;
+// they live in the history at commit f986746, the numbers in profiles/r03_fewvoices.txt.)
 // Per variant: kernel time from HIP events around single launches (median / min), wall time per launch of a back-to-back
 // train on one stream (what consecutive fill_buffer calls pay: includes the launch boundary), and whether the bits equal
 // the product-form reference launch.  Not part of the product; includes the kernels' translation unit directly.
@@ -22,7 +24,7 @@
 
 static double median(std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 
-struct Var { std::string name; uint32_t small, chunk, nw, leaf; uint32_t wg_mult = 1; uint32_t pad = 0; };
+struct Var { std::string name; uint32_t small, chunk, nw, leaf; };
 
 int main(int argc, char **argv) {
     int rounds = argc > 1 ? std::atoi(argv[1]) : 15;
@@ -65,24 +67,13 @@ int main(int argc, char **argv) {
         vars.push_back({"time-major 4 waves", 0, (uint32_t)log2p, 4, 1});
         if (log2p >= 10) vars.push_back({"short-call kernel, 2 chunks x 8 waves", 2, (uint32_t)log2p - 1, 8, 1});
         if (log2p >= 11) vars.push_back({"short-call kernel, 4 chunks x 8 waves", 2, (uint32_t)log2p - 2, 8, 1});
-        vars.push_back({"time-major 8 waves, at most 4 workgroups per CU", 0, (uint32_t)log2p, 8, 1, 1, 36u << 10});
-        vars.push_back({"time-major 8 waves, at most 3 workgroups per CU", 0, (uint32_t)log2p, 8, 1, 1, 50u << 10});
-        vars.push_back({"time-major 8 waves, at most 2 workgroups per CU", 0, (uint32_t)log2p, 8, 1, 1, 76u << 10});
-        if (log2p >= 10) vars.push_back({"short-call 2 chunks x 8 waves, at most 3 per CU", 2, (uint32_t)log2p - 1, 8, 1, 1, 50u << 10});
-        if (log2p >= 10) vars.push_back({"short-call 2 chunks x 8 waves, at most 2 per CU", 2, (uint32_t)log2p - 1, 8, 1, 1, 76u << 10});
-        if (log2p >= 11) vars.push_back({"short-call 4 chunks x 8 waves, at most 3 per CU", 2, (uint32_t)log2p - 2, 8, 1, 1, 50u << 10});
-        if (log2p >= 11) vars.push_back({"short-call 4 chunks x 4 waves", 2, (uint32_t)log2p - 2, 4, 1});
-        if (log2p >= 11) vars.push_back({"short-call 4 chunks x 4 waves, at most 6 per CU", 2, (uint32_t)log2p - 2, 4, 1, 1, 25u << 10});
-        vars.push_back({"static shares, 16 waves x 1 per CU", 3, (uint32_t)log2p, 16, 1});
-        vars.push_back({"parameter-stationary (rect)", 4, (uint32_t)log2p, 16, 1});
+        if (log2p >= 11) vars.push_back({"short-call kernel, 4 chunks x 4 waves", 2, (uint32_t)log2p - 2, 4, 1});
         auto make = [&](const Var &v) {
             fr::BankArgs a{};
             a.params = (const float2 *)d_params; a.time = d_time; a.time_valid = T; a.out = d_out; a.rows = d_rows;
             a.n_voices = V; a.log2_p = log2p; a.n_times = T; a.fast_ok = 1; a.out_stride = T;
             a.chunk_log2 = v.chunk; a.frames_per_lane = 1; a.waves_per_group = v.nw; a.small_call = v.small; a.leaf_variant = v.leaf;
-            a.ws = d_ws; a.tickets = d_tickets; a.hist_dst = d_hist; a.lds_pad = v.pad;
-            if (v.small == 3) { a.static_wgs = fr::bank_static_wgs(log2p, V, T, cus * v.wg_mult); a.static_fine = v.wg_mult > 1; }
-            if (v.small == 4 && !fr::bank_rect_plan(log2p, V, T, cus, a.rect_ng, a.rect_ts)) a.rect_ng = 0;
+            a.ws = d_ws; a.tickets = d_tickets; a.hist_dst = d_hist;
             return a;
         };
         std::vector<std::vector<double>> kt(vars.size());
@@ -93,7 +84,6 @@ int main(int argc, char **argv) {
         for (int r = 0; r <= rounds; ++r)
             for (size_t i = 0; i < vars.size(); ++i) {
                 fr::BankArgs a = make(vars[i]);
-                if ((vars[i].small == 3 && !a.static_wgs) || (vars[i].small == 4 && !a.rect_ng)) { same[i] = -2; continue; }
                 if (r == 0) { CK(hipMemsetAsync(d_out, 0xFF, (size_t)V * T * 4, st)); CK(hipMemsetAsync(d_hist, 0xFF, T * 4, st)); }
                 CK(hipEventRecord(e0, st));
                 if (fr::launch_bank(a, st) != hipSuccess) { (void)hipGetLastError(); same[i] = -2; continue; }

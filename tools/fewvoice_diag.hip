@@ -46,7 +46,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpyToSymbol(HIP_SYMBOL(fr::g_diag), &d_diag, sizeof(d_diag)));
     struct Var { std::string name; uint32_t small, chunk, nw, mult; };
     std::vector<Var> vars = {{"time-major 8 waves", 0, (uint32_t)log2p, 8, 1}, {"short 2 chunks x 8 waves", 2, (uint32_t)log2p - 1, 8, 1},
-                             {"static x1", 3, (uint32_t)log2p, 16, 1}, {"rect", 4, (uint32_t)log2p, 16, 1}};
+                             {"short 4 chunks x 4 waves", 2, (uint32_t)log2p - 2, 4, 1}};
     hipStream_t st;
     CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (const Var &v : vars) {
@@ -55,10 +55,6 @@ int main(int argc, char **argv) {
         a.n_voices = V; a.log2_p = log2p; a.n_times = T; a.fast_ok = 1; a.out_stride = T;
         a.chunk_log2 = v.chunk; a.frames_per_lane = 1; a.waves_per_group = v.nw; a.small_call = v.small; a.leaf_variant = 1;
         a.ws = d_ws; a.tickets = d_tickets;
-        if (v.small == 3) { a.static_wgs = fr::bank_static_wgs(log2p, V, T, cus * v.mult); a.static_fine = v.mult > 1; }
-        if (v.small == 3 && !a.static_wgs) continue;
-        if (v.small == 4 && !fr::bank_rect_plan(log2p, V, T, cus, a.rect_ng, a.rect_ts)) continue;
-        if (v.small == 4) std::printf("rect plan: ng %u ts %u\n", a.rect_ng, a.rect_ts);
         for (int k = 0; k < 30; ++k) {
             if (k == 29) CK(hipMemsetAsync(d_diag, 0, max_wgs * 16 * 8 * 8, st));
             if (fr::launch_bank(a, st) != hipSuccess) { std::printf("%s: launch failed\n", v.name.c_str()); break; }
@@ -70,18 +66,18 @@ int main(int argc, char **argv) {
         size_t waves = 0;
         for (size_t w = 0; w < max_wgs * 16; ++w)
             if (d[w * 8]) { t_min = std::min(t_min, d[w * 8]); t_max = std::max(t_max, std::max(d[w * 8 + 2], d[w * 8 + 1])); ++waves; }
-        std::vector<double> starts, ends, comp, units, fastu;
+        std::vector<double> starts, ends, comp;
         std::map<unsigned, double> simd_end, simd_start, simd_busy;   // key: xcc, se, sh, cu, simd
         for (size_t w = 0; w < max_wgs * 16; ++w) {
             if (!d[w * 8]) continue;
             const double s0 = (d[w * 8] - t_min) * 0.01, c1 = (d[w * 8 + 1] - t_min) * 0.01, e2 = (std::max(d[w * 8 + 2], d[w * 8 + 1]) - t_min) * 0.01;
             starts.push_back(s0); ends.push_back(e2); comp.push_back(c1 - s0);
             const unsigned hw = (unsigned)(d[w * 8 + 3] & 0xFFFFFFFFu), xcc = (unsigned)((d[w * 8 + 3] >> 32) & 15u);
-            units.push_back((double)((d[w * 8 + 3] >> 40) & 255u)); fastu.push_back((double)(d[w * 8 + 3] >> 48));
+            
             const unsigned key = (xcc << 16) | (((hw >> 13) & 7u) << 12) | (((hw >> 12) & 1u) << 11) | (((hw >> 8) & 15u) << 4) | ((hw >> 4) & 3u);
             simd_end[key] = std::max(simd_end[key], e2);
             if (!simd_start.count(key)) simd_start[key] = s0; else simd_start[key] = std::min(simd_start[key], s0);
-            simd_busy[key] += (v.small == 3 ? e2 - s0 : c1 - s0);
+            simd_busy[key] += c1 - s0;
         }
         std::vector<double> clk;
         std::map<unsigned, int> simd_waves;
@@ -100,8 +96,7 @@ int main(int argc, char **argv) {
         std::printf("\n== %s: %d x %d x %d; %zu waves stamped, span %.2f us (first start -> last end)\n", v.name.c_str(), V, P, T, waves, (t_max - t_min) * 0.01);
         std::printf("   wave starts  us: p0 %.2f p10 %.2f p50 %.2f p90 %.2f p100 %.2f\n", pct(starts, 0), pct(starts, .1), pct(starts, .5), pct(starts, .9), pct(starts, 1));
         std::printf("   wave ends    us: p0 %.2f p10 %.2f p50 %.2f p90 %.2f p100 %.2f\n", pct(ends, 0), pct(ends, .1), pct(ends, .5), pct(ends, .9), pct(ends, 1));
-        std::printf("   start->compute done per wave us: p0 %.2f p50 %.2f p100 %.2f;  units per wave: p0 %.0f p50 %.0f p100 %.0f\n", pct(comp, 0), pct(comp, .5), pct(comp, 1), pct(units, 0), pct(units, .5), pct(units, 1));
-        std::printf("   units a wave took with the fast path known at claim time: p0 %.0f p50 %.0f p100 %.0f\n", pct(fastu, 0), pct(fastu, .5), pct(fastu, 1));
+        std::printf("   start->compute done per wave us: p0 %.2f p50 %.2f p100 %.2f;\n", pct(comp, 0), pct(comp, .5), pct(comp, 1));
         std::printf("   %zu SIMDs seen; a SIMD's first wave starts: p0 %.2f p50 %.2f p100 %.2f; its last wave ends: p0 %.2f p10 %.2f p50 %.2f p90 %.2f p100 %.2f\n", se.size(),
                     pct(ss, 0), pct(ss, .5), pct(ss, 1), pct(se, 0), pct(se, .1), pct(se, .5), pct(se, .9), pct(se, 1));
         std::printf("   shader clock seen by the waves (s_memtime / s_memrealtime) GHz: p0 %.2f p50 %.2f p100 %.2f; waves stamped per SIMD: p0 %.0f p50 %.0f p100 %.0f\n",
