@@ -678,6 +678,8 @@ __global__ void __launch_bounds__(64 * NW) bank_short_kernel(BankArgs a, uint32_
     __shared__ float sm[NW][64];
     __shared__ unsigned long long zshared;
     const uint32_t clog = a.log2_p - a.chunk_log2, nchunks = 1u << clog;
+    // (an XCD-aware order like bank_kernel's -- a contiguous (voice, tile, chunk) range per XCD -- measured the same within
+    //  noise: 8 x 4096 x 4800 21.7 -> 21.3 us, 16 x 4096 36.8 -> 36.9; profiles/r03_fewvoices.txt)
     const uint32_t chunk = blockIdx.x & (nchunks - 1u);   // the chunks of one (voice, tile) are neighbours in the grid
     const uint32_t vt = blockIdx.x >> clog;
     const uint32_t voice = vt / tiles, tile = vt - voice * tiles;
