@@ -253,17 +253,24 @@ fr_status fr_fill_buffer_device(fr_renderer *r, float *d_out, uint32_t n_slots, 
 /* Block streaming, for a host that renders short blocks back to back in real time.  Through fr_fill_buffer every block pays
  * for a kernel launch -- ~12 us from enqueue to first wave on this stack, 22 us host to host for a 64-frame block whose
  * arithmetic takes 1.3 us.  fr_stream_begin launches ONE kernel that stays resident; fr_stream_block then hands it a block
- * of 1..64 frames through a doorbell in mapped memory and returns when the rows have arrived in `out` ([n_slots, n_times],
- * row-major): same bits as fr_fill_buffer(out, n_slots, n_times, idx, row, {0, row_len}, 1) renders for these frames.
- * Served: plans that are one bank of balanced template voices, one voice per output row, at most 256 workgroups' worth
- * (FR_ERR_UNSUPPORTED otherwise -- render such graphs with fr_fill_buffer).  `row` is the block's input row for slot 0
- * (shorter than n_times: padded with its last value, reference.rs:72-73); such plans read no other input and no history.
+ * of 1..64 frames through a doorbell in mapped memory and returns when the rows have arrived in `out`, which must hold
+ * [n_slots of fr_stream_begin, n_times] floats, row-major.
+ * Served: plans that are one bank of balanced template voices, one voice per output row, at most one workgroup per compute
+ * unit of the device (256 on a whole MI355X; FR_ERR_UNSUPPORTED otherwise -- render such graphs with fr_fill_buffer).
+ * `row` is the block's input row for slot 0; such plans read no other input and no history.  A row shorter than n_times is
+ * padded as fill_buffer pads it (reference.rs:72-73) with the slot's last stored value: the row's own last value, or -- an
+ * empty row -- the last value of the previous block when `idx` continues it (idx == previous idx + previous n_times); the
+ * first block of a stream, and a block that does not continue the previous one, find nothing stored (as after a seek) and
+ * pad with 0.  Results are the bits fr_fill_buffer renders for the same sequence of calls begun with a seek.
  * ANY other call on the renderer (an edit, fr_fill_buffer, fr_stream_end) first retires the resident launch; the frames
- * streamed in between were not stored, so the call after that is a seek (reference.rs:52-58).  The kernel ends itself
- * if no block arrives for a few seconds (fr_stream_block then returns FR_ERR_DEVICE: begin again).
- * The resident launch holds every compute unit's register file (256 workgroups x 16 waves x 120 VGPRs): while a stream is
- * open NOTHING ELSE runs on the device -- other kernels, of this process or any other, queue up behind it until the stream is
- * closed or ends itself.  It is meant for a host that owns the GPU for audio. */
+ * streamed in between were not stored, so the call after that is a seek (reference.rs:52-58).
+ * Bounds: the kernel ends itself when no block has arrived for FR_STREAM_IDLE_MS = 2000 ms of wall clock (the environment
+ * variable of that name overrides it at fr_renderer_create; fr_stream_block then returns FR_ERR_DEVICE: begin again), and
+ * fr_stream_block gives up with FR_ERR_DEVICE when a block is not answered within 250 ms (the launch is not fully
+ * resident: something else holds compute units).
+ * The resident launch keeps one compute unit per (voice, chunk) workgroup -- a whole MI355X for 64 voices of 4096
+ * partials, 40 of its 256 units for 5 voices of 1024 -- and nothing else runs on THOSE units until the stream is closed
+ * or ends itself; other kernels, of this process or any other, run on the units it leaves. */
 fr_status fr_stream_begin(fr_renderer *r, uint32_t n_slots);
 fr_status fr_stream_block(fr_renderer *r, float *out, uint64_t n_times, uint64_t idx, const float *row, uint64_t row_len);
 fr_status fr_stream_end(fr_renderer *r);

@@ -276,6 +276,9 @@ class Renderer:
         n = len(row)
         if out is None:
             out = np.empty((self._stream_slots, n), dtype=np.float32)
+        # (the C call takes no slot count: it writes stream_slots rows of n floats, so the buffer is checked here)
+        if out.dtype != np.float32 or not out.flags["C_CONTIGUOUS"] or out.shape != (self._stream_slots, n):
+            raise ValueError(f"stream_block: out must be a C-contiguous float32 array of shape ({self._stream_slots}, {n}), got {out.dtype} {out.shape}")
         self._check(self.L.fr_stream_block(self.h, out.ctypes.data, n, start, row.ctypes.data, n))
         return out
 

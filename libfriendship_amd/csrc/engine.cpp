@@ -336,15 +336,33 @@ struct fr_renderer {
     double stream_trace_us[2] = {0, 0};
     uint64_t stream_trace_n = 0;
     uint32_t stream_seq = 0, stream_slots = 0;
-    uint64_t stream_head = 0;
+    uint64_t stream_head = 0;            // first frame after the last streamed block
+    float stream_last = 0.0f;            // that block's last (padded) input value: what a short row continuing it is padded with
+    bool stream_have_last = false;
+    uint32_t stream_idle_ms = BANK_STREAM_IDLE_MS;   // FR_STREAM_IDLE_MS (tests shorten it)
+    int device_cus = 0;
+    // The in-launch combine's arrival counters (d_tickets) and the row-completion counters (d_row_done) are "all zero
+    // between launches": every launch that uses them leaves them so.  A launch that ended abnormally may not have: whatever
+    // can leave them dirty sets this, and the next user clears them before its launch.
+    bool counters_dirty = false;
+    void clean_counters(hipStream_t st) {
+        if (!counters_dirty) return;
+        if (d_tickets.p) HIP_CHECK(hipMemsetAsync(d_tickets.p, 0, d_tickets.bytes, st));
+        if (d_row_done.p) HIP_CHECK(hipMemsetAsync(d_row_done.p, 0, d_row_done.bytes, st));
+        counters_dirty = false;
+    }
     PinnedBuf h_stream_ctl, h_stream_out;
     DevBuf d_stream_dev;
-    void end_stream() {
+    // `clean`: the launch was answering when the stop was rung (every block it took was finished).  Otherwise some chunks of
+    // a voice may have taken their ticket and others never run: the counters are cleared before anyone uses them again.
+    void end_stream(bool clean = true) {
         if (!streaming) return;
         BankStreamCtl *ctl = (BankStreamCtl *)h_stream_ctl.p;
         for (int i = 0; i < 64; ++i) __atomic_store_n(&ctl->row[i], (unsigned long long)BANK_STREAM_STOP << 32, __ATOMIC_RELEASE);
-        (void)hipStreamSynchronize(stream);      // the kernel sees the stop within a poll, or ends itself after its bound
+        if (hipStreamSynchronize(stream) != hipSuccess) { (void)hipGetLastError(); clean = false; }   // the kernel sees the stop within a poll, or ends itself after its bound
         streaming = false;
+        stream_have_last = false;
+        if (!clean) counters_dirty = true;
         head = UINT64_MAX;                       // the streamed frames were not stored: whatever comes next is a seek
     }
     bool allow_jit = true;               // FR_JIT=0: no hipRTC specialisation (those voices run as programs / pull)
@@ -353,6 +371,7 @@ struct fr_renderer {
     int stage_jit_mode = 1;              // FR_STAGE_JIT=0: programs always interpreted; 1: compiled when >= 4 programs share
                                          // a skeleton on average; 2 ("force"): compiled whenever they fit one kernel
     JitCache jit_cache;
+    bool jit_async_configured = true;    // fr_config: hipRTC on the worker thread unless FR_CONFIG_SYNC_COMPILE
     Lowering lowering;                   // lowered graph, kept up to date across edits
     std::unique_ptr<BankMatcher> matcher;   // voice recognition memo over lowering's graph (same generation)
     uint64_t matcher_gen = 0;
@@ -548,6 +567,7 @@ struct fr_renderer {
     void rollback_store(const StoreSnapshot &sn) {
         deferred.clear();
         plan.stage_valid = false;   // rings may hold part of the failed call's window
+        counters_dirty = true;      // a launch of the failed call may have stopped half-way through its tickets / row counts
         if (sn.seeked) {
             for (InSlot &s : slots) { s.base = sn.idx; s.len = sn.idx; }
             return;
@@ -698,6 +718,12 @@ struct fr_renderer {
             } catch (const Error &e) {   // hipRTC unavailable or the generated source did not compile: plan without it
                 jit_error = e.what();
                 without = true;
+                // ... unless the plan must be the SAME on every rank (partial-block sharding: the list of split voices is the
+                // exchange's schedule): a rank that re-planned on its own would send ranges its peers do not expect, and the
+                // job would hang in the transport.  There the failure is the call's.  (FR_ERR_UNSUPPORTED = no run-time compiler in
+                // this build at all -- the same on every rank of it, so planning without is still planning alike.)
+                if (sharded() && shard.mode == FR_SHARD_PARTIALS && e.code != FR_ERR_UNSUPPORTED)
+                    throw Error(FR_ERR_DEVICE, std::string("a kernel of the sharded plan could not be compiled on this rank (every rank must plan alike): ") + e.what());
             }
             if (without) {
                 p.sp = plan_stages(fg, true, true, 20, false, true, nullptr, shard_spec);
@@ -960,6 +986,7 @@ struct fr_renderer {
                 a.ws = d_bank_ws.as<float>();
                 if (a.small_call == 2) {   // arrival counters of the in-launch combine: zero between launches (the kernel resets them)
                     const size_t need = (size_t)a.n_voices * ((blen + 63) / 64) * BANK_TICKET_STRIDE * sizeof(uint32_t);
+                    clean_counters(st);
                     if (need > d_tickets.bytes) {
                         d_tickets.ensure(need * 2);
                         HIP_CHECK(hipMemsetAsync(d_tickets.p, 0, d_tickets.bytes, st));
@@ -1152,7 +1179,8 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     if (!r) return FR_ERR_OUT_OF_MEMORY;
     r->device = dev;
     r->mode = mode;
-    r->jit_cache.set_async(!(cfg && (cfg->flags & FR_CONFIG_SYNC_COMPILE)));
+    r->jit_async_configured = !(cfg && (cfg->flags & FR_CONFIG_SYNC_COMPILE));
+    r->jit_cache.set_async(r->jit_async_configured);
     r->jit_cache.set_sparkle(cfg && cfg->semantics == FR_SEMANTICS_SPARKLE);
     r->mirror.sparkle = cfg && cfg->semantics == FR_SEMANTICS_SPARKLE;
     r->semantics = cfg ? cfg->semantics : FR_SEMANTICS_REFERENCE;
@@ -1171,6 +1199,8 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
         r->host_rows_mapped = (m & 2) != 0;
     }
     if (const char *sv = std::getenv("FR_STAGE_JIT")) r->stage_jit_mode = sv[0] == '0' ? 0 : (sv[0] == '1' ? 1 : 2);
+    if (const char *iv = std::getenv("FR_STREAM_IDLE_MS")) r->stream_idle_ms = (uint32_t)std::min(60000, std::max(1, std::atoi(iv)));
+    r->device_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {
         delete r;
         return FR_ERR_DEVICE;
@@ -1259,6 +1289,7 @@ fr_status fr_fill_buffer(fr_renderer *r, float *out, uint32_t n_slots, uint64_t 
                 std::memset(r->h_row_flags.p, 0, r->h_row_flags.bytes);
                 r->host_seq = 0;
             }
+            r->clean_counters(st);
             if ((size_t)n_slots * sizeof(uint32_t) > r->d_row_done.bytes) {
                 r->d_row_done.ensure((size_t)n_slots * 2 * sizeof(uint32_t));
                 HIP_CHECK(hipMemsetAsync(r->d_row_done.p, 0, r->d_row_done.bytes, st));
@@ -1434,14 +1465,19 @@ fr_status fr_stream_begin(fr_renderer *r, uint32_t n_slots) {
         a.small_call = 2;
         a.waves_per_group = 16;
         a.frames_per_lane = 1;
-        uint32_t c = a.log2_p;                    // chunks of >= 128 partials (a wave needs a group of 8) until the 256 workgroups are used
-        while (c > 7 && ((uint64_t)n_slots << (a.log2_p - c + 1)) <= BANK_STREAM_WGS && a.log2_p - c < 8) --c;
+        // Every workgroup of the launch must be resident at once (a workgroup that never starts never counts its voice in), one
+        // per CU: as many as the device has CUs (a partitioned gfx950 has fewer than 256), and no more than the kernel's limit.
+        const uint64_t max_wgs = std::min<uint64_t>(BANK_STREAM_WGS, (uint64_t)std::max(r->device_cus, 1));
+        uint32_t c = a.log2_p;                    // chunks of >= 128 partials (a wave needs a group of 8) until the CUs are used
+        while (c > 7 && ((uint64_t)n_slots << (a.log2_p - c + 1)) <= max_wgs && a.log2_p - c < 8) --c;
         a.chunk_log2 = c;
-        if (((uint64_t)n_slots << (a.log2_p - c)) > BANK_STREAM_WGS) throw Error(FR_ERR_UNSUPPORTED, "block streaming serves at most 256 voices");
+        if (((uint64_t)n_slots << (a.log2_p - c)) > max_wgs)
+            throw Error(FR_ERR_UNSUPPORTED, "block streaming serves at most one voice per CU (" + std::to_string(max_wgs) + " here)");
         if (c != a.log2_p) {
             r->d_bank_ws.ensure(((size_t)n_slots << (a.log2_p - c)) * 64 * sizeof(float));
             a.ws = r->d_bank_ws.as<float>();
             const size_t need = (size_t)n_slots * BANK_TICKET_STRIDE * sizeof(uint32_t);
+            r->clean_counters(r->stream);
             if (need > r->d_tickets.bytes) {
                 r->d_tickets.ensure(need * 2);
                 HIP_CHECK(hipMemsetAsync(r->d_tickets.p, 0, r->d_tickets.bytes, r->stream));
@@ -1455,10 +1491,11 @@ fr_status fr_stream_begin(fr_renderer *r, uint32_t n_slots) {
         HIP_CHECK(hipMemsetAsync(r->d_stream_dev.p, 0, sizeof(BankStreamDev), r->stream));
         a.out = r->h_stream_out.as_dev<float>();
         a.out_stride = 64;
-        HIP_CHECK(launch_bank_stream(a, r->h_stream_ctl.as_dev<BankStreamCtl>(), r->d_stream_dev.as<BankStreamDev>(), r->stream));
+        HIP_CHECK(launch_bank_stream(a, r->h_stream_ctl.as_dev<BankStreamCtl>(), r->d_stream_dev.as<BankStreamDev>(), r->stream_idle_ms, r->stream));
         r->streaming = true;
         r->stream_seq = 0;
         r->stream_slots = n_slots;
+        r->stream_have_last = false;
         r->last_pending = false;
     });
 }
@@ -1467,16 +1504,19 @@ fr_status fr_stream_block(fr_renderer *r, float *out, uint64_t n_times, uint64_t
     return guarded(r, [&] {
         if (!r->streaming) throw Error(FR_ERR_INVALID_ARG, "no stream is open (fr_stream_begin; any other call on the renderer closes it)");
         if (!out || n_times == 0 || n_times > 64 || row_len > n_times || (row_len && !row)) throw Error(FR_ERR_INVALID_ARG, "a streamed block is 1..64 frames");
-        (void)idx;   // (a plan served here reads nothing but this block's row: the position does not enter the result)
+        // (a plan served here reads nothing but this block's row: `idx` enters only through the padding rule)
         BankStreamCtl *ctl = (BankStreamCtl *)r->h_stream_ctl.p;
         const auto t_in = std::chrono::steady_clock::now();
-        // the row, padded with its last value like a short row of fill_buffer (reference.rs:72-73; no row: zeros), every
-        // word tagged with the block's number and length: the words are the doorbell (kernels.hpp BankStreamCtl)
+        // the row, padded like a short row of fill_buffer (reference.rs:72-73) with the slot's last stored value: its own last
+        // value, or -- an empty row -- the last value of the block it continues (idx == where that block ended); the first
+        // block of a stream and a block that does not continue the previous one are what a seek leaves: nothing stored, pad 0.
+        // Every word is tagged with the block's number and length: the words are the doorbell (kernels.hpp BankStreamCtl)
+        const float pad = row_len ? row[row_len - 1] : ((r->stream_have_last && idx == r->stream_head) ? r->stream_last : 0.0f);
         r->stream_seq = (r->stream_seq + 1u) & 0xFFFFFFu;
         if (r->stream_seq == 0 || r->stream_seq == 0xFFFFFFu) r->stream_seq = 1;
         const uint32_t seq = r->stream_seq << 8 | (uint32_t)n_times;
         for (uint64_t i = 0; i < 64; ++i) {
-            const float v = i < row_len ? row[i] : (row_len && i < n_times ? row[row_len - 1] : 0.0f);
+            const float v = i < row_len ? row[i] : (i < n_times ? pad : 0.0f);
             uint32_t bits;
             std::memcpy(&bits, &v, 4);
             __atomic_store_n(&ctl->row[i], (unsigned long long)seq << 32 | bits, __ATOMIC_RELAXED);
@@ -1488,17 +1528,24 @@ fr_status fr_stream_block(fr_renderer *r, float *out, uint64_t n_times, uint64_t
             if (hipStreamQuery(r->stream) != hipErrorNotReady) {   // the launch is gone (its own bound, or a fault)
                 (void)hipStreamSynchronize(r->stream);
                 r->streaming = false;
+                r->stream_have_last = false;
+                r->counters_dirty = true;                          // (it may have ended between two chunks of a voice)
                 r->head = UINT64_MAX;
                 throw Error(FR_ERR_DEVICE, "the resident launch ended before the block was rendered");
             }
-            if (std::chrono::steady_clock::now() - t_ring > std::chrono::seconds(10)) {   // (not all of it resident? something else holds CUs)
-                r->end_stream();
-                throw Error(FR_ERR_DEVICE, "the resident launch did not answer within 10 s");
+            // a resident launch answers in tens of microseconds; a quarter of a second without an answer means it is not all
+            // resident (something else holds CUs) or the device is in trouble: give the audio thread back
+            if (std::chrono::steady_clock::now() - t_ring > std::chrono::milliseconds(250)) {
+                r->end_stream(false);
+                throw Error(FR_ERR_DEVICE, "the resident launch did not answer within 250 ms");
             }
         }
         const auto t_done = std::chrono::steady_clock::now();
         const float *res = r->h_stream_out.as<float>();
         for (uint32_t v = 0; v < r->stream_slots; ++v) std::memcpy(out + (size_t)v * n_times, res + (size_t)v * 64, n_times * sizeof(float));
+        r->stream_last = n_times <= row_len ? row[n_times - 1] : pad;
+        r->stream_head = idx + n_times;
+        r->stream_have_last = true;
         if (r->host_trace) {   // FR_HOST_TRACE=1: inside the call, without the caller's wrapper
             r->stream_trace_us[0] += std::chrono::duration<double, std::micro>(t_done - t_in).count();
             r->stream_trace_us[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_done).count();
@@ -1573,7 +1620,8 @@ fr_status fr_set_shard(fr_renderer *r, const fr_shard *sh) {
         // Partial-block sharding needs every rank to arrive at the SAME plan (the same list of split voices) on the same
         // call; a kernel that finishes compiling at different moments on different ranks would break that, so compile in
         // the call from here on.
-        if (spec.mode == FR_SHARD_PARTIALS) r->jit_cache.set_async(false);
+        // (and back to the configured behaviour when the renderer leaves that mode)
+        r->jit_cache.set_async(spec.mode == FR_SHARD_PARTIALS ? false : r->jit_async_configured);
         r->shard = spec;
         r->shard_flags = flags;
         r->rccl = std::move(transport);

@@ -3,8 +3,12 @@
 
 #include <hip/hiprtc.h>
 
+#include <hip/hip_version.h>
+
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -157,7 +161,6 @@ struct JitCache::Impl {
         std::string fn_name, error;
         std::vector<char> code;
         std::shared_ptr<JitKernel> kernel;
-        std::thread worker;
         double ms = 0;
     };
     std::mutex mu;
@@ -166,12 +169,43 @@ struct JitCache::Impl {
     size_t compiled = 0;
     size_t disk_hits = 0;   // of them, code objects that came from FR_JIT_CACHE instead of the compiler
     double compile_ms = 0;
+    // ONE worker thread for the whole cache, fed through a queue: a burst of N new voice shapes compiles one after the
+    // other beside the audio thread, not N hipRTC compilers at once (each takes a core for ~0.1 s).
+    std::thread worker;
+    std::deque<std::function<void()>> jobs;
+    std::condition_variable cv;
+    bool stop = false;
+    void enqueue(std::function<void()> job) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            jobs.push_back(std::move(job));
+            if (!worker.joinable())
+                worker = std::thread([this] {
+                    for (;;) {
+                        std::function<void()> j;
+                        {
+                            std::unique_lock<std::mutex> lk(mu);
+                            cv.wait(lk, [this] { return stop || !jobs.empty(); });
+                            if (stop) return;            // (entries still COMPILING are never looked at again: the cache is going away)
+                            j = std::move(jobs.front());
+                            jobs.pop_front();
+                        }
+                        j();
+                    }
+                });
+        }
+        cv.notify_one();
+    }
 };
 
 JitCache::JitCache() : impl_(new Impl) {}
 JitCache::~JitCache() {
-    for (auto &kv : impl_->cache)
-        if (kv.second->worker.joinable()) kv.second->worker.join();
+    {
+        std::lock_guard<std::mutex> g(impl_->mu);
+        impl_->stop = true;
+    }
+    impl_->cv.notify_all();
+    if (impl_->worker.joinable()) impl_->worker.join();   // (waits for the compile in progress, not for the queue)
     delete impl_;
 }
 uint64_t JitCache::epoch() const { return impl_->epoch.load(); }
@@ -190,15 +224,33 @@ std::shared_ptr<JitKernel> JitCache::get(const LeafShape &shape, const std::vect
 // ---- code objects kept on disk (FR_JIT_CACHE=<directory>; off when unset) --------------------------------------------
 // A host that renders the same patches day after day compiles each distinct kernel once per toolchain, not once per
 // process (~0.1 s each).  One file per kernel, named by a hash of everything the code object depends on -- architecture,
-// hipRTC version, options, source text -- and carrying that text itself: a file is used only if its text equals the
-// request's (a hash collision or a stale file is a miss, never a wrong kernel).  Written to a temporary name and
-// renamed, so a reader never sees half a file; any I/O failure just means compiling as if there were no cache.
+// the toolchain's identity (hipRTC version, the HIP version and build this library was compiled against, the runtime
+// and driver versions it runs on: results depend on backend code generation down to the sign of a zero),
+// this engine's generator tag, options, source text -- and carrying that text itself: a file is used only if its text
+// equals the request's (a hash collision or a stale file is a miss, never a wrong kernel) AND the checksum stored with
+// the code bytes matches them (a truncated or bit-rotten file is a miss).  The checksum is no defence against someone
+// who can write the directory -- they can write matching checksums too: FR_JIT_CACHE must name a directory only its
+// owner can write.  Written to a temporary name and renamed, so a reader never sees half a file; any
+// I/O failure just means compiling as if there were no cache.
 static const char *kJitOptions[] = {"-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
                                     "-fno-slp-vectorize", "-mllvm", "-simplifycfg-sink-common=false"};
+#ifndef HIP_VERSION_GITHASH
+#define HIP_VERSION_GITHASH "?"
+#endif
+static uint64_t fnv1a(const void *p, size_t n, uint64_t h = 1469598103934665603ull) {
+    const unsigned char *c = (const unsigned char *)p;
+    for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+    return h;
+}
 static std::string disk_key_text(const std::string &src, const std::string &arch) {
-    int major = 0, minor = 0;
+    int major = 0, minor = 0, rt = 0, drv = 0;
     (void)hiprtcVersion(&major, &minor);
-    std::string key = "fr-jit-1|" + arch + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) + "|";
+    if (hipRuntimeGetVersion(&rt) != hipSuccess) { (void)hipGetLastError(); rt = 0; }
+    if (hipDriverGetVersion(&drv) != hipSuccess) { (void)hipGetLastError(); drv = 0; }
+    // "fr-jit-2": bumped whenever this engine's code generators change what they print for the same request
+    std::string key = "fr-jit-2|" + arch + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) + "|hip " +
+                      std::to_string(HIP_VERSION_MAJOR) + "." + std::to_string(HIP_VERSION_MINOR) + "." + std::to_string(HIP_VERSION_PATCH) + " " +
+                      HIP_VERSION_GITHASH + "|runtime " + std::to_string(rt) + "|driver " + std::to_string(drv) + "|";
     for (const char *o : kJitOptions) { key += o; key += ' '; }
     key += "|\n";
     key += src;
@@ -207,8 +259,7 @@ static std::string disk_key_text(const std::string &src, const std::string &arch
 static std::string disk_path(const std::string &key_text) {
     const char *dir = std::getenv("FR_JIT_CACHE");
     if (!dir || !dir[0]) return "";
-    uint64_t h = 1469598103934665603ull;   // FNV-1a
-    for (unsigned char c : key_text) { h ^= c; h *= 1099511628211ull; }
+    const uint64_t h = fnv1a(key_text.data(), key_text.size());
     char name[40];
     std::snprintf(name, sizeof name, "/fr_%016llx.jitbin", (unsigned long long)h);
     return std::string(dir) + name;
@@ -217,11 +268,12 @@ static bool disk_load(const std::string &path, const std::string &key_text, std:
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
     bool ok = false;
-    uint64_t hdr[3] = {0, 0, 0};   // magic, key length, code length
-    if (std::fread(hdr, sizeof hdr, 1, f) == 1 && hdr[0] == 0x314E49424A5246ull && hdr[1] == key_text.size() && hdr[2] > 0 && hdr[2] < (1ull << 30)) {
+    uint64_t hdr[4] = {0, 0, 0, 0};   // magic, key length, code length, FNV-1a of the code bytes
+    if (std::fread(hdr, sizeof hdr, 1, f) == 1 && hdr[0] == 0x324E49424A5246ull && hdr[1] == key_text.size() && hdr[2] > 0 && hdr[2] < (1ull << 30)) {
         std::string k(hdr[1], '\0');
         code.resize(hdr[2]);
-        ok = std::fread(&k[0], 1, k.size(), f) == k.size() && k == key_text && std::fread(code.data(), 1, code.size(), f) == code.size();
+        ok = std::fread(&k[0], 1, k.size(), f) == k.size() && k == key_text && std::fread(code.data(), 1, code.size(), f) == code.size() &&
+             fnv1a(code.data(), code.size()) == hdr[3];
     }
     std::fclose(f);
     if (!ok) code.clear();
@@ -231,7 +283,7 @@ static void disk_store(const std::string &path, const std::string &key_text, con
     const std::string tmp = path + ".tmp" + std::to_string((unsigned long long)std::hash<std::thread::id>{}(std::this_thread::get_id()));
     FILE *f = std::fopen(tmp.c_str(), "wb");
     if (!f) return;
-    const uint64_t hdr[3] = {0x314E49424A5246ull, key_text.size(), code.size()};
+    const uint64_t hdr[4] = {0x324E49424A5246ull, key_text.size(), code.size(), fnv1a(code.data(), code.size())};
     const bool ok = std::fwrite(hdr, sizeof hdr, 1, f) == 1 && std::fwrite(key_text.data(), 1, key_text.size(), f) == key_text.size() &&
                     std::fwrite(code.data(), 1, code.size(), f) == code.size();
     if (std::fclose(f) != 0 || !ok || std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
@@ -301,7 +353,8 @@ std::shared_ptr<JitKernel> JitCache::get_source(const std::string &src, const ch
             impl->epoch.fetch_add(1);
         };
         if (async_) {
-            e->worker = std::thread(job);
+            lock.unlock();
+            impl_->enqueue(job);
             return nullptr;
         }
         lock.unlock();
@@ -312,7 +365,6 @@ std::shared_ptr<JitKernel> JitCache::get_source(const std::string &src, const ch
     if (e->state == Impl::Entry::COMPILING) return nullptr;
     if (e->state == Impl::Entry::FAILED) throw Error(FR_ERR_DEVICE, e->error);
     if (e->state == Impl::Entry::CODE_READY) {   // load on this thread: it has the device current
-        if (e->worker.joinable()) e->worker.join();
         auto jk = std::make_shared<JitKernel>();
         const bool ok = hipModuleLoadData(&jk->module, e->code.data()) == hipSuccess &&
                         hipModuleGetFunction(&jk->fn, jk->module, e->fn_name.c_str()) == hipSuccess;

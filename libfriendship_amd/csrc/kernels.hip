@@ -786,7 +786,7 @@ static hipError_t launch_bank_short(const BankArgs &a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------
 // Block streaming: the short-call kernel as ONE resident launch (kernels.hpp, BankStreamCtl).
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) bank_stream_kernel(BankArgs a, BankStreamCtl *ctl, BankStreamDev *dev) {
+__global__ void __launch_bounds__(1024) bank_stream_kernel(BankArgs a, BankStreamCtl *ctl, BankStreamDev *dev, uint32_t idle_ms) {
     constexpr int NW = 16;
     __shared__ float sm[NW][64];
     __shared__ unsigned long long zshared;
@@ -800,7 +800,10 @@ __global__ void __launch_bounds__(1024) bank_stream_kernel(BankArgs a, BankStrea
     const uint32_t Pw = Pc / NW, ngroups = Pw >> 3;
     uint32_t levels = 0;
     while ((1u << levels) < ngroups) ++levels;
-    const bool working = voice < a.n_voices;                 // (spare workgroups only follow the doorbell, to end with the rest)
+    const bool working = voice < a.n_voices;                 // (the grid is exactly n_voices * nchunks workgroups: always true)
+    // Every polling loop below is bounded on the 100 MHz wall clock (s_memrealtime): with no block for `idle_ms` the launch
+    // ends itself (friendship_render.h: FR_STREAM_IDLE_MS), whatever a look across PCIe happens to cost.
+    const unsigned long long idle_ticks = (unsigned long long)idle_ms * 100000ull;
     const float *mine = (const float *)(a.params + ((size_t)(working ? voice : 0u) << a.log2_p) + (size_t)chunk * Pc + (size_t)wave * Pw);
     const size_t vstride = (size_t)a.n_voices * 64u;
     uint32_t seen = 0;
@@ -812,13 +815,14 @@ __global__ void __launch_bounds__(1024) bank_stream_kernel(BankArgs a, BankStrea
                 uint32_t tag = seen;
                 float v = 0.0f;
                 bool fresh = false;
-                for (uint32_t spin = 0; spin < (1u << 21); ++spin) {         // ~1 us per look across PCIe: about a second in all
+                const unsigned long long wait_from = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
                     const unsigned long long word = __hip_atomic_load(&ctl->row[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     tag = (uint32_t)(word >> 32);
                     v = __uint_as_float((uint32_t)word);
                     fresh = __all(tag != seen) && (uint32_t)__builtin_amdgcn_readfirstlane(tag) == tag;   // every lane holds the same new tag
                     fresh = __all(fresh);
-                    if (fresh) break;
+                    if (fresh || __builtin_amdgcn_s_memrealtime() - wait_from > idle_ticks) break;
                 }
                 const uint32_t seq = fresh ? __builtin_amdgcn_readfirstlane(tag) : BANK_STREAM_STOP;   // nobody rang: end
                 uint32_t T = 0;
@@ -838,9 +842,10 @@ __global__ void __launch_bounds__(1024) bank_stream_kernel(BankArgs a, BankStrea
             }
         } else if (threadIdx.x == 0) {
             uint32_t seq = seen;
-            for (uint32_t spin = 0; spin < (1u << 27); ++spin) {             // (device memory: ~0.3 us per look; outlasts workgroup 0's bound)
+            const unsigned long long wait_from = __builtin_amdgcn_s_memrealtime();
+            for (;;) {                                                       // (outlasts workgroup 0's bound, which ends in a STOP for everybody)
                 seq = __hip_atomic_load(&dev->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (seq != seen) break;
+                if (seq != seen || __builtin_amdgcn_s_memrealtime() - wait_from > 2ull * idle_ticks + 10000000ull) break;
                 __builtin_amdgcn_s_sleep(4);
             }
             if (seq == seen) seq = BANK_STREAM_STOP;
@@ -942,13 +947,15 @@ __global__ void __launch_bounds__(1024) bank_stream_kernel(BankArgs a, BankStrea
     if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&ctl->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-hipError_t launch_bank_stream(const BankArgs &a, BankStreamCtl *ctl_dev, BankStreamDev *dev, hipStream_t s) {
+hipError_t launch_bank_stream(const BankArgs &a, BankStreamCtl *ctl_dev, BankStreamDev *dev, uint32_t idle_ms, hipStream_t s) {
     if (a.chunk_log2 < 7 || a.chunk_log2 > 13 || a.chunk_log2 > a.log2_p || a.log2_p - a.chunk_log2 > 8) return hipErrorInvalidValue;
     if (((uint64_t)a.n_voices << (a.log2_p - a.chunk_log2)) > BANK_STREAM_WGS || a.n_voices == 0) return hipErrorInvalidValue;
     if ((1u << a.chunk_log2) / 16u < 8u) return hipErrorInvalidValue;          // a wave needs a whole group of 8 partials
     if (a.chunk_log2 != a.log2_p && (!a.ws || !a.tickets)) return hipErrorInvalidValue;
     if (a.leaf_variant != 1 || !a.out || !a.rows || !ctl_dev || !dev) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(bank_stream_kernel, dim3(BANK_STREAM_WGS), dim3(1024), 0, s, a, ctl_dev, dev);
+    // exactly the workgroups that render: a small patch leaves the other CUs to whatever else wants the device
+    const uint32_t wgs = a.n_voices << (a.log2_p - a.chunk_log2);
+    hipLaunchKernelGGL(bank_stream_kernel, dim3(wgs), dim3(1024), 0, s, a, ctl_dev, dev, idle_ms ? idle_ms : BANK_STREAM_IDLE_MS);
     return hipGetLastError();
 }
 

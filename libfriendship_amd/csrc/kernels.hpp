@@ -93,8 +93,9 @@ constexpr uint32_t BANK_TICKET_STRIDE = 32;
 // device memory and releases the other workgroups; each renders its (voice, chunk) exactly as bank_short_kernel does, the
 // chunk sums meet through the same tickets, finished rows go straight to mapped host memory and the workgroup that
 // completes the last voice writes the block's sequence number back.  No workgroup ever waits for another one's result
-// (tickets: the last arriver does the work), and every polling loop is bounded: without a doorbell for ~1 s the kernel
-// ends itself, so a host that dies leaves no spinning GPU behind.
+// (tickets: the last arriver does the work), and every polling loop is bounded on the wall clock: without a doorbell for
+// BANK_STREAM_IDLE_MS (the one number, quoted in friendship_render.h as FR_STREAM_IDLE_MS) the kernel ends itself, so a
+// host that dies leaves no spinning GPU behind.
 struct BankStreamCtl {        // mapped pinned host memory
     // host -> device.  The doorbell IS the block's input row: word i = row[i] (low half) | tag (high half), tag = the block's
     // sequence number << 8 | frames in the block (1..64; 0xFFFFFFFF = stop), written with one 8-byte store each.  Lane i of
@@ -113,10 +114,12 @@ struct BankStreamDev {        // device memory
     float row[64];
 };
 constexpr uint32_t BANK_STREAM_STOP = 0xFFFFFFFFu;
-constexpr uint32_t BANK_STREAM_WGS = 256;      // one per CU; all resident (the same shape bank_short_kernel launches)
-// `a`: as for the short-call kernel (small_call == 2, 16 waves, chunk_log2 chosen so that voices * chunks <= BANK_STREAM_WGS),
+constexpr uint32_t BANK_STREAM_WGS = 256;      // most workgroups a stream may use (the caller also checks the device's CU count: all must be resident)
+constexpr uint32_t BANK_STREAM_IDLE_MS = 2000; // the resident launch ends itself after this long without a block
+// `a`: as for the short-call kernel (small_call == 2, 16 waves, chunk_log2 chosen so that voices * chunks <= the CUs of the device),
 // out = device pointer of the mapped [n_voices][64] host result (out_stride = 64), ws / tickets allocated for 64 frames.
-hipError_t launch_bank_stream(const BankArgs &a, BankStreamCtl *ctl_dev, BankStreamDev *dev, hipStream_t s);
+// Launches exactly n_voices * chunks workgroups.  idle_ms: 0 = BANK_STREAM_IDLE_MS.
+hipError_t launch_bank_stream(const BankArgs &a, BankStreamCtl *ctl_dev, BankStreamDev *dev, uint32_t idle_ms, hipStream_t s);
 void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane,
                 uint32_t &waves_per_group, uint32_t &small_call, uint32_t &voices_per_wave);
 uint64_t bank_blocks(const BankArgs &a);

@@ -627,6 +627,7 @@ class PluginRenderer : public Renderer {
 protected:
     void *dl_ = nullptr;
     fr_renderer *h_ = nullptr;
+    size_t stream_slots_ = 0;            // rows of the stream that is open (fr_stream_block takes no slot count)
     struct Api {
         decltype(&fr_renderer_create) create;
         decltype(&fr_renderer_destroy) destroy;
@@ -743,9 +744,13 @@ public:
         fr_status s = api_.stream_begin(h_, n_slots);
         if (s == FR_ERR_UNSUPPORTED) return false;
         check(s);
+        stream_slots_ = n_slots;
         return true;
     }
     void stream_block(Array2 &buff, uint64_t idx, const std::vector<float> &row) {
+        // (the C call takes no slot count: it writes the stream's rows, so the buffer is checked here)
+        if (buff.rows != stream_slots_ || buff.data.size() != (size_t)buff.rows * buff.cols)
+            throw std::invalid_argument("stream_block: the buffer must have the " + std::to_string(stream_slots_) + " rows the stream was begun with");
         check(api_.stream_block(h_, buff.data.data(), buff.cols, idx, row.data(), row.size()));
     }
     void stream_end() { check(api_.stream_end(h_)); }

@@ -104,7 +104,7 @@ void bank_shape(uint32_t log2_p, uint32_t, uint64_t, uint32_t &chunk_log2, uint3
 uint64_t bank_blocks(const BankArgs &a) { return ((a.n_times + 63) / 64) * a.n_voices; }
 bool bank_publishes_rows(const BankArgs &a) { return a.host_flags && !a.small_call && !a.voices_per_wave && a.leaf_variant == 1 && a.chunk_log2 == a.log2_p; }
 
-hipError_t launch_bank_stream(const BankArgs &, BankStreamCtl *, BankStreamDev *, hipStream_t) { return hipErrorNotSupported; }   // (no resident launches on the simulator)
+hipError_t launch_bank_stream(const BankArgs &, BankStreamCtl *, BankStreamDev *, uint32_t, hipStream_t) { return hipErrorNotSupported; }   // (no resident launches on the simulator)
 hipError_t launch_bank(const BankArgs &a, hipStream_t) {
     ++fr_sim_launches[C_BANK];
     const size_t P = (size_t)1 << a.log2_p;
@@ -225,10 +225,10 @@ size_t JitCache::compiled() const { return 0; }
 double JitCache::compile_ms() const { return 0; }
 size_t JitCache::disk_hits() const { return 0; }
 std::shared_ptr<JitKernel> JitCache::get(const LeafShape &, const std::vector<bool> &, const std::vector<uint32_t> &, const std::vector<uint32_t> &) {
-    throw Error(FR_ERR_DEVICE, "jit: not available in the host-logic simulator");
+    throw Error(FR_ERR_UNSUPPORTED, "jit: not available in the host-logic simulator");
 }
 std::shared_ptr<JitKernel> JitCache::get_source(const std::string &, const char *) {
-    throw Error(FR_ERR_DEVICE, "jit: not available in the host-logic simulator");
+    throw Error(FR_ERR_UNSUPPORTED, "jit: not available in the host-logic simulator");
 }
 hipError_t launch_jit_bank(const JitKernel &, const JitBankArgs &, hipStream_t) { return hipErrorInvalidValue; }
 hipError_t launch_jit_stage(const JitKernel &, const JitStageArgs &, uint32_t, hipStream_t) { return hipErrorInvalidValue; }

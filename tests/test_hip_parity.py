@@ -1675,11 +1675,14 @@ def test_block_streaming_refuses_what_it_cannot_serve(hip_lib):
 
 
 @pytest.mark.gpu
-def test_block_streaming_launch_ends_itself_without_a_host(hip_lib, oracle_lib):
-    """Nobody rings for a few seconds: the resident launch reaches the bound of its polling loop and ends (a host that
-    died leaves no spinning GPU behind); the next block is refused with FR_ERR_DEVICE, a new stream renders on."""
+def test_block_streaming_launch_ends_itself_without_a_host(hip_lib, oracle_lib, monkeypatch):
+    """Nobody rings for FR_STREAM_IDLE_MS of wall clock (2000 ms by default; 300 here): the resident launch ends itself -- a
+    host that died leaves no spinning GPU behind; the next block is refused with FR_ERR_DEVICE, a new stream renders on.
+    The launch may have ended between two chunks of a voice, so the arrival counters the short-call kernel shares with it
+    are cleared before their next use: a short fill_buffer call right after the failure equals the oracle."""
     import time
-    V, P = 2, 256
+    monkeypatch.setenv("FR_STREAM_IDLE_MS", "300")      # (read when the renderer is created)
+    V, P = 3, 4096                                      # 3 voices x 64 chunks of 64 partials: chunked, tickets in use
     tree = synth.additive_tree(V, P)
     with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
         synth.install(hip, tree)
@@ -1687,15 +1690,48 @@ def test_block_streaming_launch_ends_itself_without_a_host(hip_lib, oracle_lib):
         hip.stream_begin(V)
         row = synth.time_ramp(0, 64)
         assert same_bits(hip.stream_block(0, row), ref.fill_buffer(V, 0, 64, [row]))
-        status = None
-        for pause in (8.0, 20.0, 45.0):   # (the bound is a number of polls, ~3 s at the ~1.5 us a look across PCIe takes here)
-            time.sleep(pause)
-            try:
-                hip.stream_block(64, synth.time_ramp(64, 128))
-            except RenderError as e:
-                status = e.status
-                break
-        assert status == 7   # FR_ERR_DEVICE: the launch had ended
+        t0 = time.monotonic()
+        time.sleep(1.0)
+        with pytest.raises(RenderError) as ei:
+            hip.stream_block(64, synth.time_ramp(64, 128))
+        assert ei.value.status == 7                     # FR_ERR_DEVICE: the launch had ended
+        assert time.monotonic() - t0 < 3.0
+        for k, T in enumerate((64, 200, 17)):           # short calls through the chunked kernel and its tickets
+            row = synth.time_ramp(1000 * k, 1000 * k + T)
+            got, exp = hip.fill_buffer(V, 1000 * k, 1000 * k + T, [row]), ref.fill_buffer(V, 1000 * k, 1000 * k + T, [row])
+            assert same_bits(got, exp), f"call {k} after the failed stream: " + first_diff(got, exp)
         hip.stream_begin(V)
         row = synth.time_ramp(64, 128)
         assert same_bits(hip.stream_block(64, row), ref.fill_buffer(V, 64, 128, [row]))
+
+
+@pytest.mark.gpu
+def test_block_streaming_short_rows_and_buffer_checks(hip_lib, oracle_lib):
+    """A block whose row is shorter than the block, or empty, is padded as fill_buffer pads it (reference.rs:72-73): with its
+    own last value, or with the last value of the block it continues; the first block of a stream and one that does not
+    continue the previous block pad with 0 (nothing stored, as after a seek).  The Python wrapper refuses an `out` of the
+    wrong shape (the C call takes no slot count)."""
+    V, P = 4, 512
+    tree = synth.additive_tree(V, P)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        hip.stream_begin(V)
+
+        def block(idx, n, row):
+            out = np.empty((V, n), np.float32)
+            row = np.ascontiguousarray(row, np.float32)
+            hip._check(hip.L.fr_stream_block(hip.h, out.ctypes.data, n, idx, row.ctypes.data if len(row) else None, len(row)))
+            return out
+
+        # the oracle makes the same calls, begun with a seek (idx 5000 != head 0)
+        seq = [(5000, 40, synth.time_ramp(5000, 5040)), (5040, 64, synth.time_ramp(5040, 5050)), (5104, 32, np.zeros(0, np.float32)),
+               (5136, 64, synth.time_ramp(5136, 5200)), (9000, 16, np.zeros(0, np.float32)), (9016, 8, synth.time_ramp(9016, 9019))]
+        for k, (idx, n, row) in enumerate(seq):
+            got, exp = block(idx, n, row), ref.fill_buffer(V, idx, idx + n, [row])
+            assert same_bits(got, exp), f"block {k}: " + first_diff(got, exp)
+        with pytest.raises(ValueError):
+            hip.stream_block(9024, synth.time_ramp(9024, 9032), out=np.empty((V - 1, 8), np.float32))
+        with pytest.raises(ValueError):
+            hip.stream_block(9024, synth.time_ramp(9024, 9032), out=np.empty((V, 9), np.float32))
+        hip.stream_end()
