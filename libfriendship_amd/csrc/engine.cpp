@@ -368,6 +368,7 @@ struct fr_renderer {
     bool allow_jit = true;               // FR_JIT=0: no hipRTC specialisation (those voices run as programs / pull)
     bool allow_template = true;          // FR_BANK_TEMPLATE=0: template voices go through the JIT path literally
     bool allow_multi = true;             // FR_BANK_MULTI=0: never the whole-voices-per-wave kernel for small voices
+    bool fused_strided_ok = true;        // FR_STAGE_STRIDED=0: a long steady call of the fused form as one launch per sub-window (A/B)
     int stage_jit_mode = 1;              // FR_STAGE_JIT=0: programs always interpreted; 1: compiled when >= 4 programs share
                                          // a skeleton on average; 2 ("force"): compiled whenever they fit one kernel
     JitCache jit_cache;
@@ -819,7 +820,7 @@ struct fr_renderer {
                << ",\"param_bytes\":" << g.params.size() * sizeof(float) << "}";
         }
         js << "],\"stage_programs\":" << (p.sp.progs.size() - p.sp.fused_count) << ",\"stage_instrs\":" << p.sp.instrs.size()
-           << ",\"fused_programs\":" << p.sp.fused_count << ",\"fused_max_frames\":" << p.sp.fused_max_frames
+           << ",\"fused_programs\":" << p.sp.fused_count << ",\"fused_max_frames\":" << p.sp.fused_max_frames << ",\"fused_stride\":" << p.sp.fused_stride
            << ",\"stage_levels\":" << (p.sp.level_first.empty() ? 0 : p.sp.level_first.size() - 1)
            << ",\"stage_jit\":" << (p.stage_jit ? "true" : "false") << ",\"stage_shapes\":" << p.stage_shapes
            << ",\"rings\":" << p.sp.n_rings << ",\"max_lookback\":" << p.sp.lmax
@@ -1016,6 +1017,14 @@ struct fr_renderer {
             const uint64_t fused_step = std::max<uint64_t>(sp.fused_max_frames, 1);
             const uint64_t n_sub = sp.fused_count ? (n_times - 1) / fused_step + 1 : 0;   // (n_times > 0 here; no overflow)
             const bool fused = sp.fused_count != 0 && w0 == idx && plan.stage_valid && n_sub < n_levels;
+            // ... or ONE launch whose threads stride through the sub-windows themselves, when every delayed read of a program ring
+            // reaches back a multiple of fused_stride frames into a ring its own program stores (the delay chains of an effects
+            // patch: 2400, 4800, 7200 ...): a thread then reads only what it stored itself.  Worth it for a handful of strides
+            // (each one is a dependent round trip to memory inside the launch; a launch boundary costs ~5 us at this size).
+            const uint64_t strided_sub = sp.fused_stride ? (n_times - 1) / sp.fused_stride + 1 : 0;
+            const bool strided = sp.fused_count != 0 && w0 == idx && plan.stage_valid && sp.fused_stride >= 256 && strided_sub >= 2 &&
+                                 strided_sub <= 8 && fused_strided_ok;
+            uint64_t launch_stride = 0;
             auto launch_range = [&](uint32_t first, uint32_t count, uint64_t s0, uint64_t slen) {
                 for (uint32_t off = 0; off < count && plan.stage_jit; off += 65535u) {   // grid.y limit
                     JitStageArgs a{};
@@ -1031,6 +1040,7 @@ struct fr_renderer {
                     a.idx = idx;
                     a.w0 = s0;
                     a.w_len = slen;
+                    a.stride = launch_stride;
                     Scope sc(this, &t_stage, st);
                     HIP_CHECK(launch_jit_stage(*plan.stage_jit, a, std::min<uint32_t>(count - off, 65535u), st));
                     sc.done();
@@ -1050,13 +1060,18 @@ struct fr_renderer {
                     a.idx = idx;
                     a.w0 = s0;
                     a.w_len = slen;
+                    a.stride = launch_stride;
                     a.sparkle = mirror.sparkle ? 1u : 0u;
                     Scope sc(this, &t_stage, st);
                     HIP_CHECK(launch_stage(a, st));
                     sc.done();
                 }
             };
-            if (fused) {
+            if (strided) {
+                launch_stride = sp.fused_stride;
+                launch_range(sp.fused_first, sp.fused_count, idx, n_times);
+                launch_stride = 0;
+            } else if (fused) {
                 for (uint64_t done = 0; done < n_times;) {   // by frames still to do: no sum that could wrap
                     const uint64_t len = std::min<uint64_t>(fused_step, n_times - done);
                     launch_range(sp.fused_first, sp.fused_count, idx + done, len);
@@ -1199,6 +1214,7 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
         r->host_rows_mapped = (m & 2) != 0;
     }
     if (const char *sv = std::getenv("FR_STAGE_JIT")) r->stage_jit_mode = sv[0] == '0' ? 0 : (sv[0] == '1' ? 1 : 2);
+    if (const char *fv = std::getenv("FR_STAGE_STRIDED")) r->fused_strided_ok = fv[0] != '0';
     if (const char *iv = std::getenv("FR_STREAM_IDLE_MS")) r->stream_idle_ms = (uint32_t)std::min(60000, std::max(1, std::atoi(iv)));
     r->device_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {

@@ -395,7 +395,8 @@ hipError_t launch_jit_stage(const JitKernel &k, const JitStageArgs &a, uint32_t 
     if (n_progs == 0 || a.w_len == 0) return hipSuccess;
     JitStageArgs copy = a;
     void *args[] = {&copy};
-    return hipModuleLaunchKernel(k.fn, (uint32_t)((a.w_len + 255) / 256), n_progs, 1, 256, 1, 1, 0, s, args, nullptr);
+    const unsigned long long span = a.stride ? std::min(a.stride, a.w_len) : a.w_len;   // (stride: one launch walks the window in strides)
+    return hipModuleLaunchKernel(k.fn, (uint32_t)((span + 255) / 256), n_progs, 1, 256, 1, 1, 0, s, args, nullptr);
 }
 
 }  // namespace fr

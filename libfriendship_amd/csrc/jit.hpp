@@ -68,6 +68,7 @@ FR_JIT_ARGS_TEXT
         unsigned int n_inputs;                                                                                 \
         float *out;                     /* [n_slots][n_times] of the call */                                   \
         unsigned long long n_times, idx, w0, w_len;                                                            \
+        unsigned long long stride;      /* 0: thread wi computes frame w0 + wi; else frames w0 + wi + k * stride < w0 + w_len */ \
     };
 FR_JIT_STAGE_ARGS_TEXT
 static_assert(sizeof(JitInput) == sizeof(DevInput), "JitInput mirrors DevInput");

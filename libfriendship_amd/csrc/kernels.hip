@@ -1479,13 +1479,18 @@ __device__ __forceinline__ float stage_load(const StageArgs &a, const StageInstr
 
 __global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
     __shared__ float tmp[STAGE_REGS][256];
-    const uint64_t wi = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (wi >= a.w_len) return;
-    const uint64_t t = a.w0 + wi;
+    const uint64_t wi0 = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    // one frame per thread, or (stride != 0) the frames wi0, wi0 + stride, ... of the window in order: the planner's
+    // fused_stride divides every delay with which this launch reads a ring it also writes, so a thread reads only what it
+    // stored itself earlier in this loop, or an earlier launch did
+    const uint64_t span = a.stride ? a.stride : a.w_len;
+    if (wi0 >= span) return;
     const StageProg pg = a.progs[blockIdx.y];
     const uint32_t tid = threadIdx.x;
     const StageInstr *gins = a.instrs + pg.first_instr;
     auto fetch = [&](uint32_t i) -> StageInstr { return gins[i]; };
+    for (uint64_t wi = wi0; wi < a.w_len; wi += span) {
+    const uint64_t t = a.w0 + wi;
     // 1. the program's loads (ring reads at t - d, inputs, constants), all in flight together
     {
         float ld[STAGE_MAX_HOISTED];
@@ -1524,12 +1529,14 @@ __global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
     const float r = tmp[pg.result_reg][tid];
     if (pg.dst_ring != 0xFFFFFFFFu) a.rings[(size_t)pg.dst_ring * (a.ring_mask + 1) + (t & a.ring_mask)] = r;
     if (pg.out_row >= 0 && t >= a.idx) a.out[(size_t)pg.out_row * a.n_times + (t - a.idx)] = r;
+    if (a.stride) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stride's ring stores are in memory before the next one reads them
+    }
 }
 
 hipError_t launch_stage(const StageArgs &a, hipStream_t s) {
     if (a.n_progs == 0 || a.w_len == 0) return hipSuccess;
     if (a.n_progs > 65535u) return hipErrorInvalidValue;
-    uint64_t bx = (a.w_len + 255) / 256;
+    uint64_t bx = ((a.stride ? std::min(a.stride, a.w_len) : a.w_len) + 255) / 256;
     if (bx > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(stage_kernel, dim3((uint32_t)bx, a.n_progs), dim3(256), 0, s, a);
     return hipGetLastError();

@@ -176,6 +176,8 @@ struct StageArgs {
     uint64_t idx;              // first frame of the call
     uint64_t w0;               // first frame of the window computed now (<= idx)
     uint64_t w_len;            // window length
+    uint64_t stride;           // 0: thread wi computes frame w0 + wi; else the frames w0 + wi + k * stride inside the window, in order
+                               // (StagedPlan::fused_stride: a long steady call of the fused form in ONE launch)
     uint32_t sparkle;          // FR_SEMANTICS_SPARKLE
 };
 hipError_t launch_stage(const StageArgs &a, hipStream_t s);

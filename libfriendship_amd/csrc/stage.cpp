@@ -243,7 +243,7 @@ struct ProgBuild {
 //                most that many frames, in steady state).
 bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unordered_map<uint32_t, uint32_t> &dense_input,
                    std::vector<uint32_t> &input_slots, ProgBuild &out, bool fuse = false,
-                   const std::unordered_set<uint32_t> *stored = nullptr, uint64_t *min_delay = nullptr) {
+                   const std::unordered_set<uint32_t> *stored = nullptr, uint64_t *min_delay = nullptr, uint64_t *gcd_delay = nullptr) {
     auto is_boundary = [&](uint32_t n) {
         if (n == m) return false;
         if (P.bank_of.count(n)) return true;
@@ -331,6 +331,7 @@ bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unorde
             else {
                 in.op = S_READ; in.buf = x.a; out.reads.push_back({x.a, d});
                 if (min_delay && !P.bank_of.count(x.a)) *min_delay = std::min(*min_delay, d);
+                if (gcd_delay && !P.bank_of.count(x.a)) { uint64_t a_ = *gcd_delay, b_ = d; while (b_) { const uint64_t r_ = a_ % b_; a_ = b_; b_ = r_; } *gcd_delay = a_; }
             }
         } else {
             switch (x.op) {
@@ -662,7 +663,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         for (auto &kv : built)
             for (auto &rd : kv.second.reads)
                 if ((rd.second == 0 || kv.second.dynamic_reads.count(rd.first)) && !P.bank_of.count(rd.first)) same_frame_used.insert(rd.first);
-        uint64_t min_delay = ~0ull;
+        uint64_t min_delay = ~0ull, gcd_delay = 0;
         bool fits = true;
         std::vector<StageInstr> finstrs;
         std::vector<StageProg> fprogs;
@@ -687,7 +688,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
             // a non-sink with output rows still needs those rows written: compute it as its own (fused) program too
             if (!sink && ro == my_rows_of.end()) continue;
             ProgBuild pb;
-            if (!build_program(g, P, m, dense_input, sp.input_slots, pb, true, &needs_ring, &min_delay)) { fits = false; break; }
+            if (!build_program(g, P, m, dense_input, sp.input_slots, pb, true, &needs_ring, &min_delay, &gcd_delay)) { fits = false; break; }
             emit(pb, needs_ring.count(m) ? ring_of[m] : NO_RING, ro != my_rows_of.end() ? (int32_t)ro->second[0] : -1);
             if (ro != my_rows_of.end())
                 for (size_t i = 1; i < ro->second.size(); ++i) emit(pb, NO_RING, (int32_t)ro->second[i]);   // extra rows: recompute
@@ -707,6 +708,23 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
             sp.fused_count = (uint32_t)fprogs.size();
             // no delayed read of a program ring at all (min_delay untouched): a steady call of any length is one launch
             sp.fused_max_frames = std::min<uint64_t>(min_delay, FUSED_UNBOUNDED);
+            // every delayed read of a program's ring reaches back a multiple of `fused_stride` frames: a thread that walks the
+            // frames wi, wi + stride, wi + 2 stride ... of a longer call only ever reads what IT stored (or an earlier call did)
+            sp.fused_stride = min_delay == ~0ull ? 0 : gcd_delay;
+            // ... provided the ring is one the reading program stores itself (its own chain: x1 = x0 + g * Delay(x0)); a ring that
+            // ANOTHER fused program stores would be another thread's, with no order between the two inside one launch
+            std::unordered_set<uint32_t> bank_rings;   // (complete before any program runs: reading them is always safe)
+            for (auto &kv : P.bank_of) { auto it = ring_of.find(kv.first); if (it != ring_of.end()) bank_rings.insert(it->second); }
+            for (const StageProg &pg : fprogs) {
+                std::unordered_set<uint32_t> mine;
+                if (pg.dst_ring != NO_RING) mine.insert(pg.dst_ring);
+                const size_t f0 = pg.first_instr - sp.instrs.size();
+                for (uint32_t i = 0; i < pg.n_instr; ++i) if (finstrs[f0 + i].op == S_STORE) mine.insert(finstrs[f0 + i].buf);
+                for (uint32_t i = 0; i < pg.n_instr && sp.fused_stride; ++i) {
+                    const StageInstr &in = finstrs[f0 + i];
+                    if (in.op == S_READ && !bank_rings.count(in.buf) && !mine.count(in.buf)) sp.fused_stride = 0;
+                }
+            }
             sp.instrs.insert(sp.instrs.end(), finstrs.begin(), finstrs.end());
             sp.progs.insert(sp.progs.end(), fprogs.begin(), fprogs.end());
         }

@@ -71,6 +71,9 @@ struct StagedPlan {
     // one launch; valid when the rings are current and the call is at most fused_max_frames long
     uint32_t fused_first = 0, fused_count = 0;
     uint64_t fused_max_frames = 0;
+    // gcd of the delays of the fused form's reads of program rings (0: there are none).  A call longer than
+    // fused_max_frames is still ONE launch when its threads stride by this many frames (engine.cpp execute()).
+    uint64_t fused_stride = 0;
     uint32_t n_rings = 0;
     uint64_t lmax = 0;                     // deepest look-back any ring must serve
     // How far back in the INPUT history the staged part can read when it computes frame t (ring look-backs + the delays

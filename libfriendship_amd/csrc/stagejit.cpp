@@ -86,17 +86,26 @@ SHAPE_FUNCTIONS
 
 extern "C" __global__ void __launch_bounds__(256) jit_stage(JitStageArgs a) {
     const u64 wi = (u64)blockIdx.x * 256u + threadIdx.x;
-    if (wi >= a.w_len) return;
-    const u64 t = a.w0 + wi;
+    // One frame per thread -- or, stride != 0, the frames wi, wi + stride, ... of the window in this order: every delayed
+    // read of a ring that this launch writes reaches back a multiple of `stride` frames (the planner's fused_stride), so a
+    // thread reads only what it stored itself earlier in this loop (same-thread program order) or an earlier launch did.
+    const u64 span = a.stride ? a.stride : a.w_len;
+    if (wi >= span) return;
     const JitStageProg pg = a.progs[blockIdx.y];
     cu32 P = (cu32)(a.ptab + pg.param_off);
-    float r;
-    switch (pg.shape) {
+    for (u64 off = wi; off < a.w_len; off += span) {
+        const u64 t = a.w0 + off;
+        float r;
+        switch (pg.shape) {
 SHAPE_CASES
-    default: r = 0.0f; break;
+        default: r = 0.0f; break;
+        }
+        if (pg.dst_ring != 0xFFFFFFFFu) ring_store(a, pg.dst_ring, t, r);
+        if (pg.out_row >= 0 && t >= a.idx) a.out[(size_t)pg.out_row * a.n_times + (t - a.idx)] = r;
+#if defined(__AMDGCN__)
+        if (a.stride) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stride's ring stores are in memory before the next one reads them
+#endif
     }
-    if (pg.dst_ring != 0xFFFFFFFFu) ring_store(a, pg.dst_ring, t, r);
-    if (pg.out_row >= 0 && t >= a.idx) a.out[(size_t)pg.out_row * a.n_times + (t - a.idx)] = r;
 }
 )JIT";
 
@@ -196,7 +205,7 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
             var_of[in.dst] = (int)i;
         }
         fns << "    return v" << var_of[p0.result_reg] << ";\n}\n";
-        cases << "    case " << si << ": r = shape" << si << "(a, P, t); break;\n";
+        cases << "        case " << si << ": r = shape" << si << "(a, P, t); break;\n";
     }
     std::ostringstream src;
     src << "#pragma clang fp contract(off)\n#define FR_SPARKLE " << (sparkle ? 1 : 0) << "\n" << FR_STR(FR_JIT_STAGE_ARGS_TEXT) << "\n";

@@ -189,7 +189,7 @@ struct StagedSim {
     std::vector<std::map<uint64_t, float>> rings;
     bool valid = false;
     uint64_t end = 0;
-    uint64_t fused_launches = 0;
+    uint64_t fused_launches = 0, strided_launches = 0;
     explicit StagedSim(const StagedPlan &p) : sp(p), rings(p.n_rings) {}
 
     void run_progs(uint32_t first, uint32_t count, uint64_t w0, uint64_t wlen, uint64_t idx, uint64_t T, const Inputs &in, std::vector<float> &out) {
@@ -257,7 +257,18 @@ struct StagedSim {
         uint64_t n_sub = sp.fused_count ? (T - 1) / fstep + 1 : 0;
         bool fused = !force_levels && sp.fused_count && w0 == idx && valid && n_sub < n_levels;
         if (used_fused) *used_fused = fused;
-        if (fused) {
+        // the engine's ONE strided launch (engine.cpp execute()): frames wi, wi + stride, ... per thread.  Emulated in the
+        // order least friendly to a wrong plan: programs last to first, threads last to first -- a read of a ring that another
+        // program (or another thread) stores inside this launch finds nothing there yet.
+        const uint64_t ssub = sp.fused_stride ? (T - 1) / sp.fused_stride + 1 : 0;
+        if (!force_levels && sp.fused_count && w0 == idx && valid && sp.fused_stride >= 16 && ssub >= 2 && ssub <= 8) {
+            if (used_fused) *used_fused = true;
+            for (uint32_t pi = sp.fused_count; pi-- > 0;)
+                for (uint64_t wi = std::min<uint64_t>(sp.fused_stride, T); wi-- > 0;)
+                    for (uint64_t off = wi; off < T; off += sp.fused_stride) run_progs(sp.fused_first + pi, 1, idx + off, 1, idx, T, in, out);
+            ++fused_launches;
+            ++strided_launches;
+        } else if (fused) {
             for (uint64_t done = 0; done < T;) {
                 const uint64_t len = std::min<uint64_t>(fstep, T - done);
                 run_progs(sp.fused_first, sp.fused_count, idx + done, len, idx, T, in, out);
@@ -275,6 +286,7 @@ struct StagedSim {
 static bool same_bits(float a, float b) { return f32_to_bits(a) == f32_to_bits(b) || (a != a && b != b); }
 
 // Renders the same calls on the oracle and through (lower -> plan -> simulators); compares everything.
+static uint64_t g_last_strided_launches = 0;   // of the last check_graph's fused simulator
 static void check_graph(const Build &b, uint32_t n_slots, uint64_t T, int calls, bool allow_banks, const char *what,
                         std::function<void(const FlatGraph &, const StagedPlan &)> inspect = nullptr) {
     Mirror m;
@@ -320,6 +332,7 @@ static void check_graph(const Build &b, uint32_t n_slots, uint64_t T, int calls,
     }
     oracle().destroy(ref);
     (void)any_fused;
+    g_last_strided_launches = sim_fused.strided_launches;
 }
 
 // ---- tests ---------------------------------------------------------------------------------------------------
@@ -454,9 +467,30 @@ static void effects_chain_is_staged() {
         CHECK(sp.lmax == 70 + 140 + 210);
         CHECK(sp.n_rings == 2 * 4);                 // per voice: the bank's mix + x0, x1, x2
         CHECK(sp.fused_count > 0 && sp.fused_max_frames == 70);
+        CHECK(sp.fused_stride == 70);               // the taps' delays 70, 140, 210 read rings their own program stores
         CHECK(sp.level_first.size() - 1 >= 5);
     });
+    CHECK(g_last_strided_launches == 4);            // calls of 100 frames > 70: the steady ones are ONE strided launch each
     check_graph(b, 3, 33, 7, true, "effects chain, short calls");
+    CHECK(g_last_strided_launches == 0);
+    check_graph(b, 3, 500, 3, true, "effects chain, 8 strides per call");
+    CHECK(g_last_strided_launches == 2);
+    {   // a tap of another row's chain: row 1 reads x0 of row 0's voice 70 frames back -- a ring ANOTHER fused program stores.
+        // No stride is valid for that (two threads, no order inside one launch): sub-window launches as before.
+        Build c;
+        std::mt19937 rng2(10);
+        uint32_t x = c.op(FR_PRIM_MULTIPLY, N(voice(c, 32, 110.0f, rng2)), N(c.op(FR_PRIM_DIVIDE, In(0), Cf(50.0f))));
+        uint32_t d0 = c.op(FR_PRIM_DELAY, N(x), Cf(70.0f));
+        c.out(N(c.op(FR_PRIM_SUM2, N(x), N(c.op(FR_PRIM_MULTIPLY, Cf(0.5f), N(d0))))), 0);
+        uint32_t z = c.op(FR_PRIM_MULTIPLY, N(voice(c, 32, 220.0f, rng2)), Cf(0.25f));
+        uint32_t d1 = c.op(FR_PRIM_DELAY, N(x), Cf(140.0f));
+        c.out(N(c.op(FR_PRIM_SUM2, N(z), N(d1))), 1);
+        check_graph(c, 2, 100, 5, true, "tap of another row's chain", [](const FlatGraph &, const StagedPlan &sp) {
+            CHECK(sp.pull_rows.empty());
+            if (sp.fused_count) CHECK(sp.fused_stride == 0);
+        });
+        CHECK(g_last_strided_launches == 0);
+    }
 }
 
 // A non-bank root wired to two output rows with no delayed read of a program ring: the fused form has no frame limit

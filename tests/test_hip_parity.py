@@ -309,47 +309,69 @@ def test_chunked_calls_equal_one_call(hip_lib):
         assert a.plan()["banks"][0]["partials"] == P
 
 
+def _oracle_with_history(ref, tree, rows_by_call):
+    """The oracle holding `tree` and the input history of the given calls WITHOUT having rendered anything: the graph goes in
+    without its output edges (an unconnected slot is 0.0, reference.rs:164), the calls store their rows, then the output
+    edges are added.  The evaluator is a pure function of (graph, history, t) (reference.rs:90-96,178-266), so
+    oracle_tools.eval_samples then answers any (slot, frame) of the full graph -- random access instead of minutes of CPU."""
+    e = tree["edges"]
+    synth.install(ref, dict(tree, edges=e[e[:, 1] != 0]))
+    for start, row in rows_by_call:
+        assert not ref.fill_buffer(1, start, start + len(row), [row]).any()
+    ref.on_add_edges(e[e[:, 1] == 0])
+
+
+def _sampled_parity(ref, got_by_call, slots, frames, what):
+    """got_by_call: [(first frame, [V, T] array)]; compares every (slot, frame) of slots x frames bit for bit."""
+    slots, frames = np.asarray(slots, np.uint32), np.asarray(frames, np.uint64)
+    exp = oracle_tools.eval_samples(ref, np.repeat(slots, len(frames)), np.tile(frames, len(slots))).reshape(len(slots), len(frames))
+    got = np.empty_like(exp)
+    for j, f in enumerate(frames):
+        start, arr = next((st, a) for st, a in got_by_call if st <= f < st + a.shape[1])
+        got[:, j] = arr[slots, int(f) - start]
+    assert same_bits(got, exp), what + ": " + first_diff(got, exp)
+    return got
+
+
 def test_config_c_full_size_sampled_against_oracle(hip_lib, oracle_lib):
-    """BASELINE config C (4096 partials x 64 voices): the real oracle, random-access, on sampled frames of
-    every voice; the graph is the same 3.1 M-node primitive graph on both sides."""
+    """BASELINE config C (4096 partials x 64 voices) at full size: EVERY voice at 64 random frames of two consecutive
+    4800-frame calls plus the first / last / call-boundary frames, against the real oracle (random access,
+    reference.rs:90-96) on the same 3.1 M-node primitive graph."""
     V, P, T = 64, 4096, 4800
     tree = synth.additive_tree(V, P)
-    t = synth.time_ramp(0, T)
+    rows = [(0, synth.time_ramp(0, T)), (T, synth.time_ramp(T, 2 * T))]
     with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
         synth.install(hip, tree)
-        synth.install(ref, tree)
-        got = hip.fill_buffer(V, 0, T, [t])
+        got = [(st, hip.fill_buffer(V, st, st + T, [row])) for st, row in rows]
+        _oracle_with_history(ref, tree, rows)
         rng = np.random.default_rng(0)
-        cols = np.unique(np.concatenate([[0, 1, T - 1], rng.integers(0, T, 5)]))
-        for c in cols:   # one oracle call per sampled frame (a seek each; this graph has no Delay)
-            exp = ref.fill_buffer(V, int(c), int(c) + 1, [t[c:c + 1]])
-            assert same_bits(got[:, c:c + 1], exp), f"frame {c}: " + first_diff(got[:, c:c + 1], exp)
+        frames = np.unique(np.concatenate([[0, 1, 63, 64, T - 1, T, T + 1, 2 * T - 1], rng.integers(0, 2 * T, 64)]))
+        _sampled_parity(ref, got, np.arange(V), frames, "config C")
 
 
 def test_config_e_full_size_sampled_against_oracle(hip_lib, oracle_lib):
     """BASELINE configs[4] in its named size, 16384 partials x 256 voices (4.2 M partials, a 50 M-node primitive graph),
-    on one GPU: sampled frames of sampled voices against the oracle.  Voices are independent (reference.rs:78-82), so
-    the oracle gets the sub-tree of just those voices.  With the survey's f0 = 55 * 2^(v/12) every voice above v ~ 150
-    is identically zero (every t*w >= 2^23): those take the kernel's zero-sign path for every frame, so some of them are
-    sampled too, signs of zero included."""
+    on one GPU: 32 voices x 32 frames against the oracle.  Voices are independent (reference.rs:78-82), so the oracle gets
+    the sub-tree of just those voices.  With the survey's f0 = 55 * 2^(v/12) every voice above v ~ 150 is identically
+    zero (every t*w >= 2^23): those take the kernel's zero-sign path for every frame, so a dozen of them are sampled
+    too, signs of zero included."""
     V, P, T = 256, 16384, 4800
-    picks = [0, 37, 101, 149, 150, 151, 160, 200, 255]
+    picks = [0, 1, 7, 19, 37, 52, 64, 77, 90, 101, 113, 126, 133, 140, 145, 148, 149, 150, 151, 152, 155, 160, 171, 183, 196, 200, 214, 229, 240, 247, 254, 255]
     tree = synth.additive_tree(V, P)
     sub = synth.additive_tree(V, P, voices=picks)
     t = synth.time_ramp(0, T)
     with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
         synth.install(hip, tree)
         del tree
-        synth.install(ref, sub)
         got = hip.fill_buffer(V, 0, T, [t])
         plan = hip.plan()
         assert plan["pull_rows"] == 0 and [(b["voices"], b["partials"]) for b in plan["banks"]] == [(V, P)], plan
+        _oracle_with_history(ref, sub, [(0, t)])
         rng = np.random.default_rng(0)
-        cols = np.unique(np.concatenate([[0, 1, 63, 64, T - 1], rng.integers(0, T, 3)]))
-        for c in cols:   # one oracle call per sampled frame (a seek each; this graph has no Delay)
-            exp = ref.fill_buffer(len(picks), int(c), int(c) + 1, [t[c:c + 1]])
-            assert same_bits(got[picks, c:c + 1], exp), f"frame {c}: " + first_diff(got[picks, c:c + 1], exp)
-        assert np.abs(got[:100]).max() > 0.1 and (got == 0).any()
+        frames = np.unique(np.concatenate([[0, 1, 63, 64, 65, T - 1], rng.integers(0, T, 27)]))[:32]
+        assert len(picks) == 32 and len(frames) >= 30
+        _sampled_parity(ref, [(0, got[picks])], np.arange(len(picks)), frames, "config E")
+        assert np.abs(got[:100]).max() > 0.1 and (got == 0).any() and not got[200].any()
 
 
 @pytest.mark.parametrize("V,P,detune", [(4, 1024, True), (64, 256, False)])
@@ -1067,30 +1089,29 @@ def test_graph_edit_rebuilds_delay_state(hip_lib, oracle_lib):
 
 
 def test_config_d_full_size_sampled_against_oracle(hip_lib, oracle_lib):
-    """BASELINE config D (1024 partials x 128 voices, detune + ADSR + 4-tap delay chain reaching back 24000
-    frames).  The oracle cannot render it in full (the pull model costs 2^4 upstream evaluations per sample), so:
-    both sides first take in 28800 frames of input with NO outputs connected (cheap), then the output edges are
-    added (a graph edit: the engine must rebuild its delay state from the input history) and a few frames of a few
-    voices are compared bit for bit."""
-    V, P = 128, 1024
+    """BASELINE config D (1024 partials x 128 voices, detune + ADSR + 4-tap delay chain reaching back 24000 frames) at full
+    size, rendered as seven contiguous 4800-frame calls from frame 0 -- the first call rebuilds nothing, the later ones
+    run on the rings, the seventh crosses the rings' wrap (capacity 32768) -- and compared on 32 voices x 40 frames: the
+    envelope's break points, every tap's first live frame and its neighbours, call boundaries, the wrap, random frames.
+    The oracle cannot render it (the pull model costs 2^4 upstream evaluations per sample) but answers single samples from
+    the stored input history (reference.rs:197-216: a Delay re-evaluates its source at t - d)."""
+    V, P, T, calls = 128, 1024, 4800, 7
     tree = synth.effects_tree(V, P)
-    out_edges = tree["edges"][tree["edges"][:, 1] == 0]
-    body = dict(tree, edges=tree["edges"][tree["edges"][:, 1] != 0])
-    H = 28800
-    t = synth.time_ramp(0, H + 8)
+    rows = [(k * T, synth.time_ramp(k * T, (k + 1) * T)) for k in range(calls)]
     with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
-        synth.install(hip, body)
-        synth.install(ref, body)
-        assert not hip.fill_buffer(4, 0, H, [t[:H]]).any() and not ref.fill_buffer(4, 0, H, [t[:H]]).any()
-        hip.on_add_edges(out_edges)
-        ref.on_add_edges(out_edges)
-        got = hip.fill_buffer(V, H, H + 8, [t[H:]])
+        synth.install(hip, tree)
+        got = [(st, hip.fill_buffer(V, st, st + T, [row])) for st, row in rows]
         plan = hip.plan()
         # per voice: the bank's mix (read by the envelope stage) + x0..x3 (each read back by the next tap)
         assert plan["pull_rows"] == 0 and plan["rings"] == V * 5 and plan["max_lookback"] == 24000, plan
-        exp = ref.fill_buffer(4, H, H + 2, [t[H:H + 2]])     # 4 voices x 2 frames on the CPU
-        assert same_bits(got[:4, :2], exp), first_diff(got[:4, :2], exp)
-        assert np.abs(got).max() > 0.01
+        _oracle_with_history(ref, tree, rows)
+        rng = np.random.default_rng(4)
+        voices = np.unique(np.concatenate([[0, 1, 63, 127], rng.integers(0, V, 40)]))[:32]
+        frames = np.unique(np.concatenate([[0, 1, 479, 480, 481, 2399, 2400, 2401, 2879, 2880, 2881, T - 1, T, 7199, 7200, 9600, 11999, 12000, 14400,
+                                            23999, 24000, 24001, 28800, 32767, 32768, 32769, calls * T - 1], rng.integers(0, calls * T, 13)]))
+        assert len(voices) == 32 and len(frames) >= 36
+        g = _sampled_parity(ref, got, voices, frames, "config D")
+        assert np.abs(g).max() > 0.01
 
 
 def test_bank_from_composite_effect_instances(hip_lib, oracle_lib):
