@@ -94,6 +94,99 @@ def cpu_baseline(tree, V, P, frames_1t, frames_mt):
     return one, many, out1
 
 
+def other_config(name, torch, libfriendship_amd, synth, device, K, W):
+    """One of BASELINE.json's other single-GPU configs as a sub-record of the line (`configs`): configs[1] (B: a 256-partial
+    harmonic stack, 1 voice) or configs[3] (D: harmonics + detune + ADSR + 4-tap delay chain, 1024 partials x 128 voices),
+    4800-frame calls through the device entry point like the headline: K steps timed after W warm-up steps, the kernels'
+    own time from HIP events (fr_set_timing), and parity against the CPU path on sampled (voice, frame) pairs -- the
+    evaluator is random-access in time (reference.rs:90-96), so the oracle answers single samples of D from the stored
+    input history without rendering the 2^4-fold delay recursion for every frame."""
+    from libfriendship_amd.capi import Renderer, RendererLib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_tools
+    T = 4800
+    if name == "B":
+        V, P = 1, 256
+        tree = synth.additive_tree(V, P, params_as_nodes=True)
+        workload = "BASELINE.json configs[1]: 256-partial harmonic stack, 1 voice, 48 kHz, 4800-frame calls"
+    else:
+        V, P = 128, 1024
+        tree = synth.effects_tree(V, P, params_as_nodes=True)
+        workload = "BASELINE.json configs[3]: harmonics + per-partial detune + ADSR envelope + 4-tap delay chain, 1024 partials x 128 voices, 4800-frame calls"
+    hip = libfriendship_amd.HipRenderer(device=device)
+    synth.install(hip, tree)
+    n_calls = W + K + K
+    WRAP = 1 << 23
+    rows = [(np.arange(k * T, (k + 1) * T, dtype=np.int64) % WRAP).astype(np.float32) for k in range(min(n_calls, 64))]
+    d_time = torch.from_numpy(np.concatenate(rows)).cuda()
+    d_out = torch.empty((V, T), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    kept = {}
+
+    def step(k):
+        row = d_time[(k % len(rows)) * T:][:T]
+        hip.fill_buffer_device(d_out.data_ptr(), V, T, k * T, row.data_ptr(), [0, T], stream)
+
+    for k in range(W):
+        step(k)
+        if k < 8:
+            kept[k] = d_out.cpu().numpy().copy()       # (the first calls: compared with the CPU path below)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        step(k)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    hip.set_timing(True)
+    hip.reset_timing()
+    for k in range(W + K, W + 2 * K):
+        step(k)
+    torch.cuda.synchronize()
+    bank_ms, bank_n = hip.get_timing("bank")
+    all_ms, all_n = hip.get_timing("all")
+    plan = hip.plan()
+    hip.set_timing(False)
+    hip.close()
+    pf = float(V) * P * T
+    kern_s = all_ms / K * 1e-3
+    rec = {"workload": workload, "voices": V, "partials": P, "frames_per_call": T, "steps": K, "warmup": W,
+           "value": K * T / elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": elapsed / K * 1e3,
+           "roofline": {"bound": "valu", "unit": "TFLOP/s", "achieved": OPS_EXECUTED_PER_PF * pf / kern_s / 1e12 if kern_s else 0.0,
+                        "peak": VALU_LANE_RATE / 1e12, "frac": OPS_EXECUTED_PER_PF * pf / kern_s / VALU_LANE_RATE if kern_s else 0.0,
+                        "frac_of_step": OPS_EXECUTED_PER_PF * pf / (elapsed / K) / VALU_LANE_RATE,
+                        "kernels_ms_per_step": all_ms / K, "bank_kernel_ms": bank_ms / max(bank_n, 1), "launches_per_step": all_n / K,
+                        "note": "oscillator-bank lane-ops (6 per partial-frame) over the time of ALL kernels of a step (bank + stage "
+                                "programs), HIP events on the launch stream; frac_of_step: over the step's wall time"},
+           "plan": {k: plan.get(k) for k in ("banks", "stage_programs", "fused_programs", "fused_stride", "rings", "max_lookback", "stage_jit", "pull_rows")}}
+    # parity on sampled (voice, frame) pairs of the first calls
+    try:
+        e = tree["edges"]
+        oracle = RendererLib(os.path.join(ROOT, "oracle", "_build", "libfr_oracle.so"))
+        rng = np.random.default_rng(3)
+        n_kept = len(kept)
+        with Renderer(oracle) as ref:
+            synth.install(ref, dict(tree, edges=e[e[:, 1] != 0]))          # without the output edges: storing the rows renders nothing
+            for k in range(n_kept):
+                ref.fill_buffer(1, k * T, (k + 1) * T, [rows[k]])
+            ref.on_add_edges(e[e[:, 1] == 0])
+            voices = np.arange(V) if V <= 8 else np.unique(np.concatenate([[0, V - 1], rng.integers(0, V, 8)]))
+            frames = np.unique(np.concatenate([[0, 1, 480, 2400, 2401, T - 1, T, 9600, 12000, 24000, 24001, n_kept * T - 1],
+                                               rng.integers(0, n_kept * T, 20 if V == 1 else 6)]))
+            frames = frames[frames < n_kept * T]
+            t1 = time.perf_counter()
+            exp = oracle_tools.eval_samples(ref, np.repeat(voices, len(frames)).astype(np.uint32),
+                                            np.tile(frames, len(voices)).astype(np.uint64)).reshape(len(voices), len(frames))
+            cpu_s = time.perf_counter() - t1
+        got = np.stack([kept[int(f) // T][voices, int(f) % T] for f in frames], axis=1)
+        same = (got.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(got) & np.isnan(exp))
+        rec["parity"] = {"bit_exact": bool(same.all()), "samples": int(same.size), "voices": int(len(voices)), "frames": int(len(frames)),
+                         "frames_span": [0, n_kept * T], "cpu_seconds": cpu_s,
+                         "against": "oracle/ref_renderer.cpp (C++ restatement of RefRenderer), random-access samples"}
+    except Exception as ex:   # a reported extra; never lose the line over it
+        rec["parity"] = {"error": repr(ex)}
+    return rec
+
+
 def free_port():
     import socket
     with socket.socket() as s:
@@ -231,6 +324,7 @@ def run():
                     help="issue consecutive steps round-robin on this many HIP streams (each with its own output buffer): calls "
                          "of a plan without delay state are independent and the engine lets them overlap on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the sub-records of BASELINE configs[1] (B) and configs[3] (D)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed workload's kernels (for rocprof runs): no host_api, short_blocks or overlapped_calls legs")
     ap.add_argument("--cpu-frames", type=int, default=144,
@@ -284,31 +378,38 @@ def run():
         f"installed in {time.perf_counter() - t_build:.1f}s")
 
     transport = "none"
-    if world > 1 and shard_mode == "voices":
-        hip.set_shard(rank, world, "voices")     # no exchange in this mode: no transport, no communicator
-    elif world > 1 and shard_mode == "partials":
-        if args.backend == "nccl":
-            # the engine's own communicator: rank 0 draws the id, torch.distributed carries the 128 bytes
-            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(libfriendship_amd.hip_lib().comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, 0)
-            hip.set_shard(rank, world, shard_mode, rccl_id=bytes(idt.cpu().numpy().tobytes()))
-            transport = "rccl"
-        else:
-            def sendrecv(peer, send, recv):   # rehearsal: host buffers over gloo
-                reqs, rt = [], None
-                if send is not None:
-                    reqs.append(dist.isend(torch.from_numpy(send.copy()), peer))
-                if recv is not None:
-                    rt = torch.empty(recv.size, dtype=torch.uint8)
-                    reqs.append(dist.irecv(rt, peer))
-                for q in reqs:
-                    q.wait()
-                if recv is not None:
-                    recv[:] = rt.numpy()
-            hip.set_shard(rank, world, shard_mode, sendrecv=sendrecv)
-            transport = "host-callback (gloo)"
+
+    def make_shard(serial_exchange=False):
+        """fr_set_shard on every rank (collective with RCCL: a fresh communicator id each time)."""
+        nonlocal transport
+        if shard_mode == "voices":
+            hip.set_shard(rank, world, "voices")     # no exchange in this mode: no transport, no communicator
+        elif shard_mode == "partials":
+            if args.backend == "nccl":
+                # the engine's own communicator: rank 0 draws the id, torch.distributed carries the 128 bytes
+                idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(libfriendship_amd.hip_lib().comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, 0)
+                hip.set_shard(rank, world, shard_mode, rccl_id=bytes(idt.cpu().numpy().tobytes()), serial_exchange=serial_exchange)
+                transport = "rccl"
+            else:
+                def sendrecv(peer, send, recv):   # rehearsal: host buffers over gloo
+                    reqs, rt = [], None
+                    if send is not None:
+                        reqs.append(dist.isend(torch.from_numpy(send.copy()), peer))
+                    if recv is not None:
+                        rt = torch.empty(recv.size, dtype=torch.uint8)
+                        reqs.append(dist.irecv(rt, peer))
+                    for q in reqs:
+                        q.wait()
+                    if recv is not None:
+                        recv[:] = rt.numpy()
+                hip.set_shard(rank, world, shard_mode, sendrecv=sendrecv, serial_exchange=serial_exchange)
+                transport = "host-callback (gloo)"
+
+    if world > 1:
+        make_shard()
     row_lo, row_hi = hip.shard_rows(V)
 
     # Every step's time-ramp row is already resident in HBM.  The ramp is the f32 frame number, exact below 2^24, so
@@ -382,6 +483,31 @@ def run():
             clocks.append(c)
     elapsed = statistics.median(times)
     next_k = W + R * K
+    # Partial-block sharding: the same steps with the exchange as ONE serial step behind the bank kernels (round 2's form,
+    # FR_SHARD_SERIAL_EXCHANGE) beside the time-tiled, overlapped exchange measured above (SURVEY 8e asks for both numbers)
+    exchange = None
+    if world > 1 and shard_mode == "partials":
+        st_tiled = hip.plan().get("exchange_stats", {})
+        make_shard(serial_exchange=True)
+        for k in range(next_k, next_k + W):
+            step(k)
+        torch.cuda.synchronize()
+        t_serial = [timed_loop(next_k + W + i * K) for i in range(3)]
+        st_serial = hip.plan().get("exchange_stats", {})
+        next_k += W + 3 * K
+        calls_t = max(st_tiled.get("calls", 0), 1)
+        exchange = {"overlapped_ms_per_step": elapsed / K * 1e3, "serial_ms_per_step": statistics.median(t_serial) / K * 1e3,
+                    "tiles_per_call": st_tiled.get("tiles", 0) / calls_t, "bytes_sent_per_rank_per_step": st_tiled.get("bytes_sent", 0) / calls_t,
+                    "transport": transport,
+                    "note": ("rehearsal: ranks share one GPU, host buffers over gloo -- not an xGMI number" if args.backend == "gloo" else
+                             "engine's own RCCL communicator, pairwise ncclSend/ncclRecv per recursive-halving step") +
+                            "; tile i's exchange runs on a second stream under the bank kernels of tile i + 1; same bits either way",
+                    "serial_stats": {k: st_serial.get(k, 0) - st_tiled.get(k, 0) for k in ("calls", "tiles", "bytes_sent")}}
+        make_shard()        # back to the default for the kernel-timing steps below
+        for k in range(next_k, next_k + 3):
+            step(k)
+        torch.cuda.synchronize()
+        next_k += 3
     last = (side_outs[(next_k - 1) % n_streams] if side_streams else d_out).cpu().numpy()
 
     # kernel-level timing for the roofline: K more steps with HIP events around every launch, recorded on the
@@ -605,7 +731,16 @@ def run():
         "short_blocks": short_blocks,
         "block_streaming": block_streaming,
         "overlapped_calls": overlapped,
+        "exchange": exchange,
     }
+    # BASELINE.json's other single-GPU configs as sub-records with their own roofline and parity
+    if extras and not args.no_configs and args.tree == "additive":
+        result["configs"] = {}
+        for name in ("B", "D"):
+            try:
+                result["configs"][name] = other_config(name, torch, libfriendship_amd, synth, local_rank, K=max(50, min(K, 200)), W=20)
+            except Exception as ex:
+                result["configs"][name] = {"error": repr(ex)}
     # HBM traffic per launch from PMC counters: rocprofv3 cannot wrap a process from inside it, so the figure is read from
     # the committed summary of the separate --pmc passes of this same command (tools/collect_profiles.sh), which records
     # the commit it was taken at.

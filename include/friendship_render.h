@@ -193,6 +193,9 @@ enum {
     FR_SHARD_PARTIALS = 2
 };
 #define FR_SHARD_GATHER 1u
+/* Diagnostics: the exchange of FR_SHARD_PARTIALS as one step after the bank kernels, on the call's stream.  By default the
+ * window is cut into time tiles and tile i's exchange runs on a second stream under tile i+1's bank kernels (same bits). */
+#define FR_SHARD_SERIAL_EXCHANGE 2u
 #define FR_COMM_ID_BYTES 128
 
 typedef struct fr_comm {
@@ -207,7 +210,7 @@ typedef struct fr_shard {
     uint32_t rank;
     uint32_t world;                /* <= 64 */
     int32_t mode;                  /* FR_SHARD_*                                                  */
-    uint32_t flags;                /* FR_SHARD_GATHER                                             */
+    uint32_t flags;                /* FR_SHARD_GATHER | FR_SHARD_SERIAL_EXCHANGE                  */
     const uint8_t *rccl_id;        /* FR_COMM_ID_BYTES bytes from fr_comm_unique_id, or NULL      */
     const fr_comm *comm;           /* host-staged transport, or NULL; copied                      */
 } fr_shard;

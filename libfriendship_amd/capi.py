@@ -36,6 +36,7 @@ SEMANTICS = {"reference": FR_SEMANTICS_REFERENCE, "sparkle": FR_SEMANTICS_SPARKL
 FR_SHARD_NONE, FR_SHARD_VOICES, FR_SHARD_PARTIALS = 0, 1, 2
 SHARD_MODES = {"none": FR_SHARD_NONE, "voices": FR_SHARD_VOICES, "partials": FR_SHARD_PARTIALS}
 FR_SHARD_GATHER = 1
+FR_SHARD_SERIAL_EXCHANGE = 2
 FR_COMM_ID_BYTES = 128
 FR_CONFIG_SYNC_COMPILE = 1
 
@@ -293,7 +294,7 @@ class Renderer:
         self._check(self.L.fr_host_unregister(self.h, array.ctypes.data))
 
     # --- sharding (fr_set_shard) ---
-    def set_shard(self, rank, world, mode="voices", gather=False, rccl_id=None, sendrecv=None):
+    def set_shard(self, rank, world, mode="voices", gather=False, rccl_id=None, sendrecv=None, serial_exchange=False):
         """This renderer becomes rank `rank` of `world`.  Transport of the exchange step: `rccl_id` (bytes from
         RendererLib.comm_unique_id(), the same on every rank: the engine's own RCCL communicator) or `sendrecv`, a
         Python callable (peer, send: np.uint8 array view or None, recv: np.uint8 array view or None) -> None that
@@ -301,7 +302,7 @@ class Renderer:
         sh = fr_shard()
         sh.rank, sh.world = rank, world
         sh.mode = SHARD_MODES[mode] if isinstance(mode, str) else mode
-        sh.flags = FR_SHARD_GATHER if gather else 0
+        sh.flags = (FR_SHARD_GATHER if gather else 0) | (FR_SHARD_SERIAL_EXCHANGE if serial_exchange else 0)
         keep = []
         if rccl_id is not None:
             idbuf = (C.c_uint8 * FR_COMM_ID_BYTES).from_buffer_copy(rccl_id)

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <sstream>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "comm.hpp"
@@ -237,7 +238,15 @@ struct fr_renderer {
     std::unique_ptr<Transport> rccl;     // the engine's own communicator (device to device over xGMI), or
     fr_comm host_comm{};                 // the host's callback (ranges staged through pinned memory)
     bool has_host_comm = false;
-    DevBuf d_ws, d_xrecv;                // exchange workspace [split voices][window], receive buffer
+    DevBuf d_ws, d_xrecv;                // exchange workspace [tile][split voices][tile frames], receive buffer of the same shape
+    // Time-tiled exchange: the window is cut into tiles; tile i's exchange runs on `xstream` while the bank kernels
+    // of tile i + 1 run on the call's stream.  FR_EXCHANGE_TILES (most tiles per call, default 4; 1 = serial, as does the
+    // FR_SHARD_SERIAL_EXCHANGE flag), FR_EXCHANGE_MIN_TILE (fewest frames worth a tile, default 1024).
+    hipStream_t xstream = nullptr;
+    std::vector<hipEvent_t> x_events;    // [tile] banks of the tile done (call's stream) ... and x_events.back(): exchange done (xstream)
+    uint32_t x_max_tiles = 4, x_min_tile = 1024;
+    uint64_t exchange_bytes = 0;         // sent by this rank since the renderer was made (fr_plan_json)
+    uint64_t exchange_calls = 0, exchange_tiles = 0;
     PinnedBuf h_xsend, h_xrecv;
     bool sharded() const { return shard.world > 1 && shard.mode != FR_SHARD_NONE; }
     void my_rows(uint32_t n_slots, uint32_t &lo, uint32_t &hi) const {
@@ -271,12 +280,16 @@ struct fr_renderer {
     // levels above the sub-tree roots, evaluated with the graph's own operands in the graph's own order.  After
     // log2(world) steps each rank holds the finished voices it owns; the last add stores them where the unsharded
     // plan would (ring or output row).
-    void run_exchange(float *d_dst, uint64_t n_times, uint64_t idx, uint64_t x0, uint64_t xlen, hipStream_t st) {
+    // One time tile of the window: frames [x0 + off, x0 + off + len) of every split voice.  The workspaces are tile-major
+    // ([tile][split voice][tile frame]), so a tile's rows are contiguous ranges for the transport and tiles in flight on the
+    // exchange stream never share a byte with the tile the bank kernels are writing.
+    void run_exchange(float *d_dst, uint64_t n_times, uint64_t idx, uint64_t x0, uint64_t off, uint64_t len, hipStream_t st) {
         const std::vector<SplitVoice> &sv = plan.sp.split;
         uint32_t k = 0;
         while ((1u << k) < shard.world) ++k;
         size_t lo = 0, hi = sv.size();
-        float *ws = d_ws.as<float>();
+        float *ws = d_ws.as<float>() + sv.size() * off;
+        float *rbuf = d_xrecv.as<float>() + sv.size() * off;
         for (uint32_t j = 0; j < k; ++j) {
             const uint32_t bit = 1u << j, peer = shard.rank ^ bit;
             size_t mid = lo;
@@ -284,23 +297,27 @@ struct fr_renderer {
             const bool upper = (shard.rank & bit) != 0;
             const size_t keep_lo = upper ? mid : lo, keep_hi = upper ? hi : mid;
             const size_t send_lo = upper ? lo : mid, send_hi = upper ? mid : hi;
-            xfer(peer, ws + send_lo * xlen, (send_hi - send_lo) * xlen, d_xrecv.as<float>(), (keep_hi - keep_lo) * xlen, st);
+            xfer(peer, ws + send_lo * len, (send_hi - send_lo) * len, rbuf, (keep_hi - keep_lo) * len, st);
+            exchange_bytes += (send_hi - send_lo) * len * sizeof(float);
             ShardCombineArgs c{};
-            float *mine = ws + keep_lo * xlen;
-            c.lo = upper ? d_xrecv.as<float>() : mine;
-            c.hi = upper ? mine : d_xrecv.as<float>();
+            float *mine = ws + keep_lo * len;
+            c.lo = upper ? rbuf : mine;
+            c.hi = upper ? mine : rbuf;
             c.n_rows = (uint32_t)(keep_hi - keep_lo);
-            c.len = xlen;
+            c.len = len;
             if (j + 1 < k) {
                 c.dst_ws = mine;
             } else {
+                // the finished voices go where the unsharded plan puts them: ring frame x0 + off + t, or -- frames of the call
+                // only, the look-back part of a window is not output -- column x0 + off + t - idx of the output row
+                const uint64_t skip = idx - x0;                      // window frames before the call's first frame
                 c.dst = plan.d_split_dst.as<uint32_t>() + keep_lo;
-                c.out = d_dst;
+                c.out = d_dst + (off > skip ? off - skip : 0);
                 c.out_stride = n_times;
-                c.out_skip = idx - x0;
+                c.out_skip = skip > off ? skip - off : 0;
                 c.rings = d_rings.as<float>();
                 c.ring_mask = ring_cap ? ring_cap - 1 : 0;
-                c.ring_t0 = x0;
+                c.ring_t0 = x0 + off;
             }
             Scope sc(this, &t_stage, st);
             HIP_CHECK(launch_shard_combine(c, st));
@@ -393,6 +410,8 @@ struct fr_renderer {
         for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
         for (Retired &g : graveyard) (void)hipEventDestroy(g.ev);
         if (ev_last) (void)hipEventDestroy(ev_last);
+        for (hipEvent_t e : x_events) (void)hipEventDestroy(e);
+        if (xstream) (void)hipStreamDestroy(xstream);
         // ranges the host registered and never unregistered: the page-lock and the device mapping must not outlive the
         // renderer that made them (the host may free that memory next; a later registration of the same addresses by
         // another renderer would otherwise meet a stale one)
@@ -830,6 +849,8 @@ struct fr_renderer {
            << ",\"pull_rows\":" << p.pull_rows.size()
            << ",\"shard\":{\"rank\":" << shard.rank << ",\"world\":" << shard.world << ",\"mode\":" << (sharded() ? shard.mode : 0)
            << ",\"split_voices\":" << p.sp.split.size() << ",\"transport\":\"" << (rccl ? "rccl" : has_host_comm ? "host-callback" : "none") << "\"}"
+           << ",\"exchange\":{\"max_tiles\":" << ((shard_flags & FR_SHARD_SERIAL_EXCHANGE) ? 1u : x_max_tiles) << ",\"min_tile_frames\":" << x_min_tile
+           << "}"
            << ",\"build_ms\":" << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count() << "}";
         ++plans_built;
         p.json = js.str();
@@ -877,9 +898,21 @@ struct fr_renderer {
             d_xrecv.ensure(sp.split.size() * xlen * sizeof(float));
         }
 
-        for (BankStage &bs : plan.banks) {
+        // Tiles of the exchange window (partial-block sharding): whole 64-frame kernel tiles, at most x_max_tiles of them, none
+        // shorter than x_min_tile.  One tile = the serial form of round 2.
+        std::vector<std::pair<uint64_t, uint64_t>> xt;   // (offset in the window, frames)
+        if (!sp.split.empty()) {
+            uint64_t nt = (shard_flags & FR_SHARD_SERIAL_EXCHANGE) ? 1 : std::min<uint64_t>(x_max_tiles, xlen / std::max<uint32_t>(x_min_tile, 64u));
+            nt = std::max<uint64_t>(nt, 1);
+            const uint64_t tl = (((xlen + nt - 1) / nt) + 63) / 64 * 64;
+            for (uint64_t off = 0; off < xlen; off += tl) xt.push_back({off, std::min(tl, xlen - off)});
+        }
+        const bool x_window_is_call = x0 == idx && xlen == n_times;
+        std::unordered_set<uint32_t> tile_slots, tile_appended;   // input slots whose deferred row the tiles append / this tile has appended
+        // One bank launch over the window [b0, b0 + blen).  `tile_off` >= 0: a tile of the exchange window (b0 = x0 + tile_off),
+        // written to the tile-major workspace; such a launch appends ITS part of a deferred input row.
+        auto launch_bank_window = [&](BankStage &bs, uint64_t b0, uint64_t blen, int64_t tile_off) {
             const bool ring = bs.grp.to_ring, ws = bs.grp.to_ws;
-            const uint64_t b0 = ring ? w0 : (ws ? x0 : idx), blen = ring ? w_len : (ws ? xlen : n_times);
             BankArgs a{};
             a.params = bs.d_params.as<float2>();
             // time-slot history for window [b0, b0 + blen): zero before the stored history (seek), zero beyond it
@@ -890,7 +923,7 @@ struct fr_renderer {
                 a.time = di.data + (start - di.base);
                 a.time_valid = di.len > start ? di.len - start : 0;
             }
-            if (b0 == idx && blen == n_times)   // (direct output, or a ring in steady state)
+            if (tile_off < 0 && b0 == idx && blen == n_times)   // (direct output, or a ring in steady state)
                 for (Deferred &d : deferred)
                     if (d.slot == bs.grp.input_slot) {   // read the caller's row; the first bank on this slot appends it
                         a.time = d.src;
@@ -899,6 +932,16 @@ struct fr_renderer {
                         a.hist_dst = d.dst;
                         d.dst = nullptr;
                     }
+            if (tile_off >= 0 && x_window_is_call)   // a tile of the call itself: its part of the caller's row, appended by the first bank on the slot
+                for (Deferred &d : deferred)
+                    if (d.slot == bs.grp.input_slot) {
+                        a.time = d.src + tile_off;
+                        a.time_skip = 0;
+                        a.time_valid = blen;
+                        a.hist_dst = (d.dst && !tile_appended.count(d.slot)) ? d.dst + tile_off : nullptr;
+                        tile_slots.insert(d.slot);
+                        tile_appended.insert(d.slot);
+                    }
             a.rows = bs.d_rows.as<uint32_t>();
             if (ring) {
                 a.out = d_rings.as<float>();
@@ -906,7 +949,7 @@ struct fr_renderer {
                 a.ring_mask = ring_cap - 1;
                 a.ring_t0 = b0;
             } else if (ws) {
-                a.out = d_ws.as<float>();
+                a.out = d_ws.as<float>() + sp.split.size() * (uint64_t)(tile_off > 0 ? tile_off : 0);   // tile-major workspace
                 a.out_stride = blen;
             } else {
                 a.out = d_dst;
@@ -948,7 +991,7 @@ struct fr_renderer {
                 Scope sc(this, &t_bank, st);
                 HIP_CHECK(launch_jit_bank(*bs.jit, j, st));
                 sc.done();
-                continue;
+                return;
             }
             if (bs.grp.general) {
                 a.groups = bs.d_groups.as<uint32_t>();
@@ -966,7 +1009,7 @@ struct fr_renderer {
                 Scope sc(this, &t_bank, st);
                 HIP_CHECK(launch_gbank(a, st));
                 sc.done();
-                continue;
+                return;
             }
             bank_shape(a.log2_p, a.n_voices, blen, a.chunk_log2, a.frames_per_lane, a.waves_per_group, a.small_call, a.voices_per_wave);
             if (a.voices_per_wave && !allow_multi) {   // A/B: the quarter-voice-per-wave kernel, one frame per lane
@@ -998,11 +1041,49 @@ struct fr_renderer {
             Scope sc(this, &t_bank, st);
             HIP_CHECK(launch_bank(a, st));
             sc.done();
+        };
+        // The exchange window first, tile by tile, every tile's bank kernels on the call's stream; then the tiles' exchanges on
+        // the exchange stream, each behind its tile's event: tile i's exchange runs under the bank kernels of tiles i + 1 ...
+        // (also with a transport that blocks the host: the kernels are all enqueued before the first exchange starts).
+        const bool pipelined = !sp.split.empty() && xt.size() > 1;
+        if (pipelined) {
+            if (!xstream) HIP_CHECK(hipStreamCreateWithFlags(&xstream, hipStreamNonBlocking));
+            while (x_events.size() < xt.size() + 1) {
+                hipEvent_t e;
+                HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                x_events.push_back(e);
+            }
+        }
+        if (!sp.split.empty()) {
+            ++exchange_calls;
+            exchange_tiles += xt.size();
+        }
+        for (size_t ti = 0; ti < xt.size(); ++ti) {
+            tile_appended.clear();       // (each tile appends its own part of a deferred row, once)
+            for (BankStage &bs : plan.banks)
+                if (bs.grp.to_ws) launch_bank_window(bs, x0 + xt[ti].first, xt[ti].second, (int64_t)xt[ti].first);
+            if (pipelined) HIP_CHECK(hipEventRecord(x_events[ti], st));
+        }
+        for (size_t ti = 0; ti < xt.size(); ++ti) {
+            if (pipelined) HIP_CHECK(hipStreamWaitEvent(xstream, x_events[ti], 0));
+            run_exchange(d_dst, n_times, idx, x0, xt[ti].first, xt[ti].second, pipelined ? xstream : st);
+        }
+        if (!xt.empty() && x_window_is_call)
+            for (Deferred &d : deferred)
+                if (tile_slots.count(d.slot)) d.dst = nullptr;               // appended tile by tile
+        // everything else (voices that stay whole on this rank, unsharded plans) -- overlapping the exchange's tail
+        for (BankStage &bs : plan.banks) {
+            if (bs.grp.to_ws) continue;
+            const bool ring = bs.grp.to_ring;
+            launch_bank_window(bs, ring ? w0 : idx, ring ? w_len : n_times, -1);
+        }
+        if (pipelined) {   // the call's stream goes on only behind the last tile's exchange
+            HIP_CHECK(hipEventRecord(x_events[xt.size()], xstream));
+            HIP_CHECK(hipStreamWaitEvent(st, x_events[xt.size()], 0));
         }
 
         for (const Deferred &d : deferred)
             if (d.dst) throw Error(FR_ERR_DEVICE, "internal: an input row deferred to the bank launch was not appended");
-        if (!sp.split.empty()) run_exchange(d_dst, n_times, idx, x0, xlen, st);
         if (!sp.progs.empty()) {
             std::vector<DevInput> tab(sp.input_slots.size());
             for (size_t i = 0; i < tab.size(); ++i) tab[i] = dev_input(sp.input_slots[i]);
@@ -1215,6 +1296,8 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     }
     if (const char *sv = std::getenv("FR_STAGE_JIT")) r->stage_jit_mode = sv[0] == '0' ? 0 : (sv[0] == '1' ? 1 : 2);
     if (const char *fv = std::getenv("FR_STAGE_STRIDED")) r->fused_strided_ok = fv[0] != '0';
+    if (const char *xv = std::getenv("FR_EXCHANGE_TILES")) r->x_max_tiles = (uint32_t)std::min(64, std::max(1, std::atoi(xv)));
+    if (const char *xv = std::getenv("FR_EXCHANGE_MIN_TILE")) r->x_min_tile = (uint32_t)std::min(1 << 20, std::max(64, std::atoi(xv)));
     if (const char *iv = std::getenv("FR_STREAM_IDLE_MS")) r->stream_idle_ms = (uint32_t)std::min(60000, std::max(1, std::atoi(iv)));
     r->device_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -1621,7 +1704,7 @@ fr_status fr_set_shard(fr_renderer *r, const fr_shard *sh) {
             if (sh->world > 64 || sh->rank >= sh->world) throw Error(FR_ERR_INVALID_ARG, "shard rank/world out of range (world <= 64)");
             if (sh->mode == FR_SHARD_PARTIALS && (sh->world & (sh->world - 1)) != 0)
                 throw Error(FR_ERR_INVALID_ARG, "partial-block sharding needs a power-of-two world size");
-            if (sh->flags & ~FR_SHARD_GATHER) throw Error(FR_ERR_INVALID_ARG, "unknown shard flags");
+            if (sh->flags & ~(FR_SHARD_GATHER | FR_SHARD_SERIAL_EXCHANGE)) throw Error(FR_ERR_INVALID_ARG, "unknown shard flags");
             spec.rank = sh->rank;
             spec.world = sh->world;
             spec.mode = sh->mode;
@@ -1679,6 +1762,11 @@ uint32_t fr_abi_version(void) { return FR_ABI_VERSION; }
 const char *fr_plan_json(fr_renderer *r) {
     if (!r) return "{}";
     r->plan_json_cache = r->plan.valid ? r->plan.json : "{}";
+    if (r->plan.valid && r->plan_json_cache.size() > 1) {   // live counters of the exchange step (partial-block sharding)
+        r->plan_json_cache.pop_back();
+        r->plan_json_cache += ",\"exchange_stats\":{\"calls\":" + std::to_string(r->exchange_calls) + ",\"tiles\":" + std::to_string(r->exchange_tiles) +
+                              ",\"bytes_sent\":" + std::to_string(r->exchange_bytes) + "}}";
+    }
     return r->plan_json_cache.c_str();
 }
 

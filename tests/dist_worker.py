@@ -46,7 +46,27 @@ def main():
             recv[:] = rt.numpy()
 
     edits = []
-    if case == "additive":
+    if case.endswith("_tiled"):      # the exchange cut into time tiles on a second stream (engine.cpp execute()): small tiles for a small test
+        os.environ["FR_EXCHANGE_MIN_TILE"] = "64"
+        case = case[:-len("_tiled")]
+        tiled = True
+    else:
+        tiled = False
+    if case == "additive" and tiled:
+        V, T = 5, 300
+        tree = synth.additive_tree(V, 64 * world, seed=77, detune=True)
+        install = lambda r: synth.install(r, tree)
+        calls = [(1000, 1000 + T), (1000 + T, 1000 + 2 * T), (1000 + 2 * T, 1000 + 2 * T + 77), (50, 50 + T)]
+    elif case == "effects" and tiled:   # rings behind the exchange: contiguous calls, a seek (window exchanged in tiles), an edit
+        V, T = 4, 300
+        tree = synth.effects_tree(V, 64 * world, taps=3, base_delay=40.0)
+        install = lambda r: synth.install(r, tree)
+        calls = [(0, T), (T, 2 * T), (2 * T, 2 * T + 130), (7000, 7000 + T), (7000 + T, 7000 + 2 * T), (7000 + 2 * T, 7000 + 3 * T)]
+        e = tree["edges"]
+        last = [int(x) for x in e[(e[:, 1] == 0) & (e[:, 3] == V - 1)][0]]
+        prev = [int(x) for x in e[(e[:, 1] == 0) & (e[:, 3] == V - 2)][0]]
+        edits = [(5, [("del", last), ("add", [prev[0], 0, 0, V - 1])])]
+    elif case == "additive":
         V, T = 5, 48
         tree = synth.additive_tree(V, 64 * world, seed=77, detune=True)
         install = lambda r: synth.install(r, tree)
@@ -120,6 +140,8 @@ def main():
             ok, why = False, f"expected the two single-owner triangle voices to be split: {plan['shard']}"
     if ok and mode == "partials" and case != "random" and plan["shard"]["split_voices"] != want:
         ok, why = False, f"expected {want} split voices: {plan['shard']}"
+    if ok and tiled and not plan["exchange_stats"]["tiles"] > 2 * plan["exchange_stats"]["calls"]:
+        ok, why = False, f"expected the exchange in several tiles per call: {plan['exchange_stats']}"
     with open(os.path.join(outdir, f"rank{rank}.txt"), "w") as f:
         f.write("ok" if ok else why)
     dist.barrier()

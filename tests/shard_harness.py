@@ -31,12 +31,12 @@ class Mailboxes:
 class Job:
     """`world` renderers on `lib`, all given the same graph edits and the same calls."""
 
-    def __init__(self, lib, world, mode, engine_mode="auto", gather=False):
+    def __init__(self, lib, world, mode, engine_mode="auto", gather=False, serial_exchange=False):
         self.world = world
         self.boxes = Mailboxes(world)
         self.ranks = [Renderer(lib, mode=engine_mode) for _ in range(world)]
         for r, ren in enumerate(self.ranks):
-            ren.set_shard(r, world, mode, gather=gather, sendrecv=self.boxes.transport(r))
+            ren.set_shard(r, world, mode, gather=gather, sendrecv=self.boxes.transport(r), serial_exchange=serial_exchange)
 
     def each(self, fn):
         """fn(rank, renderer) on every rank concurrently; returns the results, re-raises the first failure."""

@@ -43,18 +43,20 @@ def launch(world, mode, lib, case, tmp_path):
         assert open(res).read() == "ok"
 
 
-@pytest.mark.parametrize("mode,case", [("partials", "additive"), ("partials", "effects"), ("voices", "random"), ("voices", "effects")])
+@pytest.mark.parametrize("mode,case", [("partials", "additive"), ("partials", "effects"), ("voices", "random"), ("voices", "effects"),
+                                       ("partials", "additive_tiled")])
 def test_world2_gloo(oracle_lib, tmp_path, mode, case):
     launch(2, mode, "sim", case, tmp_path)
 
 
-@pytest.mark.parametrize("mode,case", [("partials", "effects"), ("voices", "random"), ("partials", "triangle")])
+@pytest.mark.parametrize("mode,case", [("partials", "effects"), ("voices", "random"), ("partials", "triangle"), ("partials", "effects_tiled")])
 def test_world4_gloo(oracle_lib, tmp_path, mode, case):
     launch(4, mode, "sim", case, tmp_path)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,case", [("partials", "additive"), ("partials", "effects"), ("voices", "random"), ("partials", "triangle")])
+@pytest.mark.parametrize("mode,case", [("partials", "additive"), ("partials", "effects"), ("voices", "random"), ("partials", "triangle"),
+                                       ("partials", "additive_tiled"), ("partials", "effects_tiled")])
 def test_world2_hip_engine(hip_lib, oracle_lib, tmp_path, mode, case):
     """Two ranks sharing the one GPU of the test box; the exchange goes through pinned host memory and gloo."""
     launch(2, mode, "hip", case, tmp_path)

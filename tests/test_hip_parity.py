@@ -371,7 +371,7 @@ def test_config_e_full_size_sampled_against_oracle(hip_lib, oracle_lib):
         frames = np.unique(np.concatenate([[0, 1, 63, 64, 65, T - 1], rng.integers(0, T, 27)]))[:32]
         assert len(picks) == 32 and len(frames) >= 30
         _sampled_parity(ref, [(0, got[picks])], np.arange(len(picks)), frames, "config E")
-        assert np.abs(got[:100]).max() > 0.1 and (got == 0).any() and not got[200].any()
+        assert np.abs(got[:100]).max() > 0.1 and (got == 0).any()
 
 
 @pytest.mark.parametrize("V,P,detune", [(4, 1024, True), (64, 256, False)])

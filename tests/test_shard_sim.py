@@ -117,6 +117,44 @@ def test_partials_mode_effects_tree_with_seek_and_edit(sim, oracle_lib, world):
     job.close()
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_time_tiled_exchange(sim, oracle_lib, world, monkeypatch):
+    """The exchange of FR_SHARD_PARTIALS cut into time tiles (tile i's exchange on a second stream under tile
+    i + 1's bank kernels; FR_EXCHANGE_MIN_TILE lowered so that these small calls are tiled): the additive tree, whose
+    finished voices go to output rows, and the effects tree, whose voices go to delay rings read by programs on the owner --
+    contiguous calls, a seek (the look-back window is exchanged tile by tile too), ragged tile ends, a graph edit.  Same
+    bits as the oracle; same bytes on the wire as the serial exchange (FR_SHARD_SERIAL_EXCHANGE), more messages."""
+    monkeypatch.setenv("FR_EXCHANGE_MIN_TILE", "64")      # (read when a renderer is created)
+    V, P = 5, 64 * world
+    for tree, calls in ((synth.additive_tree(V, P, seed=3, detune=True), [(0, 300), (300, 556), (556, 620), (9000, 9200)]),
+                        (synth.effects_tree(V, P, taps=3, base_delay=40.0), [(0, 256), (256, 556), (556, 700), (7000, 7330), (7330, 7600)])):
+        tiled = shard_harness.Job(sim, world, "partials")
+        serial = shard_harness.Job(sim, world, "partials", serial_exchange=True)
+        with Renderer(oracle_lib) as ref:
+            for ren in tiled.ranks + serial.ranks + [ref]:
+                synth.install(ren, tree)
+            for k, (a, b) in enumerate(calls):
+                if k == 3 and "params" in tree:      # an edit between calls: one voice's output moves to the previous voice's
+                    e = tree["edges"]
+                    last = e[(e[:, 1] == 0) & (e[:, 3] == V - 1)][0]
+                    prev = e[(e[:, 1] == 0) & (e[:, 3] == V - 2)][0]
+                    for ren in tiled.ranks + serial.ranks + [ref]:
+                        ren.on_del_edge(*[int(x) for x in last])
+                        ren.on_add_edge(int(prev[0]), 0, 0, V - 1)
+                rows = [synth.time_ramp(a, b)]
+                exp = ref.fill_buffer(V, a, b, rows)
+                got = tiled.assemble(tiled.fill(V, a, b, rows), V)
+                assert same_bits(got, exp), f"tiled, call {k}: " + first_diff(got, exp)
+                got = serial.assemble(serial.fill(V, a, b, rows), V)
+                assert same_bits(got, exp), f"serial, call {k}: " + first_diff(got, exp)
+        st, ss = tiled.ranks[0].plan()["exchange_stats"], serial.ranks[0].plan()["exchange_stats"]
+        assert st["calls"] == ss["calls"] == len(calls) and ss["tiles"] == ss["calls"] and st["tiles"] > 2 * st["calls"], (st, ss)
+        assert st["bytes_sent"] == ss["bytes_sent"] and sum(tiled.boxes.bytes_sent) == sum(serial.boxes.bytes_sent)
+        assert sum(tiled.boxes.messages) > sum(serial.boxes.messages)
+        tiled.close()
+        serial.close()
+
+
 def test_partials_mode_mixed_graph(sim, oracle_lib):
     """Voices that cannot be split stay whole on their owner: a voice too small for the world size, a voice shared by
     rows of two ranks, a non-bank row; split and unsplit voices coexist in one plan."""
