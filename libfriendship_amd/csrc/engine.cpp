@@ -716,7 +716,8 @@ struct fr_renderer {
         // rank's rows are that rank's to report); partial-block sharding analyses the whole graph on every rank
         uint32_t lower_lo = 0, lower_hi = UINT32_MAX;
         if (sharded() && shard.mode == FR_SHARD_VOICES) my_rows(n_slots, lower_lo, lower_hi);
-        const FlatGraph &fg = lowering.update(mirror, n_slots, lower_lo, lower_hi);
+        // (partial-block sharding: every rank must arrive at the same node ids -- the exchange is ordered by them)
+        const FlatGraph &fg = lowering.update(mirror, n_slots, lower_lo, lower_hi, sharded() && shard.mode == FR_SHARD_PARTIALS);
         const double lower_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
         p.max_depth = fg.max_depth;
         bool use_jit = allow_jit && mode == FR_MODE_AUTO;

@@ -1,8 +1,11 @@
 // graph.cpp -- mirror maintenance (GraphWatcher side) and lowering to a flat primitive DAG.
 #include "graph.hpp"
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 namespace fr {
 
@@ -237,6 +240,80 @@ uint32_t FlatGraph::make(FlatOp op, uint32_t a, uint32_t b) {
     uint32_t id = push(op, a, b, d);
     e = (uint64_t)id + 1;
     return id;
+}
+
+// ---- concurrent construction -------------------------------------------------------------------------
+bool FlatGraph::par_begin(size_t max_new_nodes, size_t const_budget) {
+    if (!nodes.mapped() || nodes.capacity() < nodes.size() + max_new_nodes + const_budget + 64) return false;
+    cse_bin_.reserve(cse_bin_.size() + max_new_nodes);
+    cse_[OP_CONST].reserve(cse_[OP_CONST].size() + const_budget + 1024);   // (+ the few a thread may add between its check and the others')
+    cse_[OP_INPUT].reserve(cse_[OP_INPUT].size() + 4096);
+    if (!cse_bin_.concurrent_ready(max_new_nodes) || !cse_[OP_CONST].concurrent_ready(const_budget) || !cse_[OP_INPUT].concurrent_ready(4096)) return false;
+    par_next_ = (uint32_t)nodes.size();
+    return true;
+}
+
+uint32_t FlatGraph::par_push(FlatOp op, uint32_t a, uint32_t b, uint32_t depth, ParCounters &c) {
+    const uint32_t above = (op == OP_CONST || op == OP_INPUT) ? 0u : std::max(a, b);   // operands must have smaller ids
+    if (c.id_next == c.id_end || c.id_next <= above) {
+        c.id_next = __atomic_fetch_add(&par_next_, PAR_ID_BLOCK, __ATOMIC_RELAXED);
+        c.id_end = c.id_next + PAR_ID_BLOCK;
+        if (c.id_end >= 0x3FFFFFFFu) throw Error(FR_ERR_UNSUPPORTED, "lowered graph exceeds 2^30 nodes");
+    }
+    const uint32_t id = c.id_next++;
+    nodes.data()[id] = FlatNode{op, a, b, depth};   // (published by whoever hands the id on: release store of the table entry / memo)
+    return id;
+}
+
+uint32_t FlatGraph::par_konst(uint32_t bits, ParCounters &c) {
+    if (c.new_const >= c.const_budget) throw ParBudget{};   // this thread's share of what the constants' table was sized for
+    return (uint32_t)(cse_[OP_CONST].concurrent_get(bits, [&] { return (uint64_t)par_push(OP_CONST, bits, 0, 0, c) + 1; }, &c.new_const) - 1);
+}
+
+uint32_t FlatGraph::par_input(uint32_t slot, ParCounters &c) {
+    if (c.new_input >= 4000) throw Error(FR_ERR_UNSUPPORTED, "too many distinct input slots for one parallel lowering");   // (caught: the row is lowered sequentially)
+    const uint32_t id = (uint32_t)(cse_[OP_INPUT].concurrent_get(slot, [&] { return (uint64_t)par_push(OP_INPUT, slot, 0, 0, c) + 1; }, &c.new_input) - 1);
+    if (!c.has_input || slot > c.max_input_slot) c.max_input_slot = slot;
+    c.has_input = true;
+    return id;
+}
+
+uint32_t FlatGraph::par_make(FlatOp op, uint32_t a, uint32_t b, ParCounters &c) {   // make(), on the concurrent tables
+    const FlatNode *nd = nodes.data();
+    auto kconst = [&](uint32_t id) { return nd[id].op == OP_CONST; };
+    if (op == OP_DELAY) {
+        if (kconst(a) && nd[a].a == f32_to_bits(0.0f)) return a;
+        if (kconst(b)) {
+            const float d = f32_from_bits(nd[b].a);
+            if (d >= 18446744073709551616.0f) return par_konst(0, c);
+            if (sparkle && !(d >= 0.0f)) return par_konst(0, c);
+            const uint64_t di = (d < 0.0f || d != d) ? 0 : (uint64_t)d;
+            if (di == 0) return a;
+        }
+    } else {
+        if (kconst(a) && kconst(b)) return par_konst(f32_to_bits(host_binop(op, f32_from_bits(nd[a].a), f32_from_bits(nd[b].a), sparkle)), c);
+        if ((op == OP_SUM2 || op == OP_MUL) && a > b) std::swap(a, b);
+    }
+    const uint64_t key = ((uint64_t)op << 60) | ((uint64_t)a << 30) | b;
+    return (uint32_t)(cse_bin_.concurrent_get(key, [&] {
+        const uint32_t d = 1 + std::max(nd[a].depth, nd[b].depth);
+        if (d > c.max_depth) c.max_depth = d;
+        return (uint64_t)par_push(op, a, b, d, c) + 1;
+    }, &c.new_bin) - 1);
+}
+
+void FlatGraph::par_end(const std::vector<ParCounters> &threads) {
+    size_t nc = 0, ni = 0, nb = 0;
+    for (const ParCounters &c : threads) {
+        nc += c.new_const; ni += c.new_input; nb += c.new_bin;
+        if (c.max_depth > max_depth) max_depth = c.max_depth;
+        if (c.has_input && (!has_input || c.max_input_slot > max_input_slot)) max_input_slot = c.max_input_slot;
+        has_input = has_input || c.has_input;
+    }
+    cse_[OP_CONST].concurrent_added(nc);
+    cse_[OP_INPUT].concurrent_added(ni);
+    cse_bin_.concurrent_added(nb);
+    nodes.set_size(__atomic_load_n(&par_next_, __ATOMIC_ACQUIRE));
 }
 
 // ---- lowering --------------------------------------------------------------------------------------
@@ -481,6 +558,210 @@ struct Lowering::Impl {
         return result;
     }
 
+    // ---- parallel from-scratch lowering ---------------------------------------------------------------------------------
+    // Output rows are independent sub-graphs for the most part (voices), and lowering one is a walk over hash tables that
+    // misses the cache at every step: 0.25 us per node, 0.94 s for config C's 3.7 M nodes on one thread, inside the first
+    // fill_buffer call.  Here the rows are dealt to threads; the shared structures take concurrent use as follows:
+    //   * the flat graph: FlatGraph::par_* (ids from an atomic counter, lock-free insert-if-absent in the hash-consing maps);
+    //   * memo (top-level table, pre-sized): 0 = untouched, id + 2 = final (release store), PAR_BUSY | thread = being lowered.
+    //     A thread claims a node with a compare-and-swap; a thread that meets another thread's claim waits for the final value
+    //     -- claims are held only along one root-to-leaf path, so two threads can wait for each other only around a real
+    //     cycle, and a wait that lasts is handed to the sequential pass (as is a claim of one's own: a cycle);
+    //   * readers lists: cells from an atomic counter, pushed with a compare-and-swap on the list head;
+    //   * anything inside a composite instance (contexts, their hash-mapped tables) is NOT shared: a row that reaches a
+    //     composite, or fails, is left to the sequential pass after the threads have joined -- which also reports errors in
+    //     row order exactly as before.  What the threads leave behind is only ever final values of correctly lowered nodes.
+    // Incremental updates (a few nodes per edit) stay sequential.
+    static constexpr uint64_t PAR_BUSY = 1ull << 40;
+    struct NeedsSequential {};
+    struct ParThread {
+        FlatGraph::ParCounters cnt;
+        uint64_t relowered = 0, visited = 0, me = 0;
+        uint32_t cell_next = 0, cell_end = 0;   // this thread's block of reader cells (one contended add per 4096)
+        std::vector<Frame> stack;
+    };
+    uint32_t par_cells_next = 0;
+    bool allow_parallel = true;   // (ids then depend on thread timing; Lowering::update's `deterministic` turns it off)
+
+    void par_add_reader(ParThread &ts, uint64_t of, uint64_t reader) {
+        if (reader == NOBODY) return;
+        uint64_t *head = &readers_head.top[(uint32_t)of];
+        uint64_t old = __atomic_load_n(head, __ATOMIC_ACQUIRE);
+        if (old && cells.data()[old - 1].user == reader) return;   // both operands the same node
+        if (ts.cell_next == ts.cell_end) {
+            ts.cell_next = __atomic_fetch_add(&par_cells_next, 4096u, __ATOMIC_RELAXED);
+            ts.cell_end = ts.cell_next + 4096u;
+            if (ts.cell_end >= cells.capacity() || ts.cell_end < ts.cell_next) throw NeedsSequential{};
+        }
+        const uint32_t c = ts.cell_next++;
+        do cells.data()[c] = UserCell{reader, (uint32_t)old};
+        while (!__atomic_compare_exchange_n(head, &old, (uint64_t)c + 1, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE));
+    }
+
+    // resolve() for context 0 only; a composite instance ends the parallel attempt at this row
+    bool par_resolve(ParThread &ts, EdgeRef ref, uint32_t &out, Frame &need, uint64_t reader) {
+        if (!ref.present) { out = fg.par_konst(0, ts.cnt); return true; }
+        if (ref.from == 0) { out = fg.par_input(ref.from_slot, ts.cnt); return true; }
+        const MNode *n = m->nodes.find(ref.from);
+        if (!n) throw Error(FR_ERR_NO_SUCH_NODE, "edge reads from unknown node " + std::to_string(ref.from));
+        ++ts.visited;
+        if (n->kind == FR_EFFECT_GRAPH) throw NeedsSequential{};
+        if (n->kind == FR_PRIM_F32CONSTANT) { out = fg.par_konst(ref.from_slot, ts.cnt); return true; }
+        if (ref.from_slot != 0) throw Error(FR_ERR_BAD_SLOT, "primitive node read through a non-zero output slot");
+        const uint64_t k = m->nodes.position(n);
+        par_add_reader(ts, k, reader);
+        uint64_t *mv = &memo.top[(uint32_t)k];
+        uint64_t spins = 0;
+        for (;;) {
+            uint64_t v = __atomic_load_n(mv, __ATOMIC_ACQUIRE);
+            if (v >= 2 && v < PAR_BUSY) { out = (uint32_t)(v - 2); return true; }
+            if (v == 0) {
+                if (__atomic_compare_exchange_n(mv, &v, ts.me, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+                    need = Frame{0, n, 0, {0, 0}};
+                    return false;
+                }
+                continue;
+            }
+            if (v == ts.me) throw NeedsSequential{};            // a cycle: the sequential pass reports it
+            if (++spins > (1u << 22)) throw NeedsSequential{};   // another thread's claim that does not resolve: cycle across threads
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+
+    uint32_t par_eval(ParThread &ts, EdgeRef root) {
+        uint32_t result = 0;
+        Frame need;
+        if (par_resolve(ts, root, result, need, NOBODY)) return result;
+        std::vector<Frame> &stack = ts.stack;
+        stack.clear();
+        stack.push_back(need);
+        try {
+            while (!stack.empty()) {
+                Frame &f = stack.back();
+                if (f.next < 2) {
+                    const MNode *n = f.node;
+                    EdgeRef ref = (size_t)f.next < n->inbound.size() ? n->inbound[f.next] : EdgeRef{};
+                    uint32_t id;
+                    Frame child;
+                    if (par_resolve(ts, ref, id, child, m->nodes.position(n))) f.vals[f.next++] = id;
+                    else stack.push_back(child);   // invalidates f; the loop re-reads the top
+                    continue;
+                }
+                const uint32_t id = fg.par_make(op_of(f.node->kind), f.vals[0], f.vals[1], ts.cnt);
+                __atomic_store_n(&memo.top[m->nodes.position(f.node)], (uint64_t)id + 2, __ATOMIC_RELEASE);
+                ++ts.relowered;
+                stack.pop_back();
+                if (stack.empty()) result = id;
+                else { Frame &p = stack.back(); p.vals[p.next++] = id; }
+            }
+        } catch (...) {   // give the claims back: whoever waits for them goes on, the sequential pass starts from a clean slate
+            for (const Frame &f : stack) __atomic_store_n(&memo.top[m->nodes.position(f.node)], (uint64_t)0, __ATOMIC_RELEASE);
+            stack.clear();
+            throw;
+        }
+        return result;
+    }
+
+    // (read at every from-scratch lowering, which is rare: tests switch them inside one process)
+    static unsigned par_threads() {
+        if (const char *e = std::getenv("FR_LOWER_THREADS")) return (unsigned)std::max(1, std::atoi(e));
+        const unsigned hw = std::thread::hardware_concurrency();
+        return std::min(32u, std::max(1u, hw));
+    }
+    static size_t par_min_nodes() {
+        const char *e = std::getenv("FR_LOWER_PAR_MIN_NODES");
+        return e ? (size_t)std::atoll(e) : (size_t)200000;
+    }
+
+    // Lowers the rows [row_lo, row_hi) of a freshly reset state on several threads; done[s] says which rows came through
+    // (fg.outputs[s] set).  Returns false without touching anything when the parallel form does not apply.
+    bool lower_rows_parallel(const Mirror &mm, uint32_t n_slots, std::vector<char> &done) {
+        const uint32_t lo = std::min(row_lo, n_slots), hi = std::min(row_hi, n_slots);
+        const unsigned nthreads = std::min<unsigned>(par_threads(), hi > lo ? hi - lo : 0);
+        const size_t positions = mm.nodes.capacity_positions();
+        if (nthreads < 2 || mm.nodes.size() < par_min_nodes() || positions >= (1ull << 31)) return false;
+        const size_t const_budget = mm.nodes.size() / 8 + 65536;   // distinct constants the table is sized for (more: the rest sequentially)
+        if (!cells.mapped() || !memo.top.mapped() || !readers_head.top.mapped() || !fg.par_begin(mm.nodes.size() + 16, const_budget)) return false;
+        memo.top.resize(positions, 0);
+        readers_head.top.resize(positions, 0);
+        par_cells_next = (uint32_t)cells.size();
+        std::vector<ParThread> ts(nthreads);
+        std::atomic<uint32_t> next_row{lo};
+        std::atomic<bool> stop{false};
+        // Pass 1 -- every constant and input the top-level nodes read, made before any other node: leaves have no operands, so
+        // their ids may come from any block, and with all of them below every block pass 2 draws, a node made from a constant
+        // some OTHER thread made first never has to abandon its id block for "operands precede users" (the waveform's constants
+        // and the amplitudes 1/(k+1) are shared by every voice: without this pass the graph came out 7x its size in abandoned
+        // ids).  A scan of the node table in position order, split evenly: memory-bound, a few tens of milliseconds.
+        std::atomic<size_t> next_chunk{0};
+        auto leaves = [&](unsigned t) {
+            ParThread &me = ts[t];
+            me.cnt.const_budget = const_budget / nthreads;
+            uint32_t const_handle = 0;   // the last handle seen to be an F32Constant node (usually there is exactly one)
+            try {
+                for (;;) {
+                    const size_t c0 = next_chunk.fetch_add(1 << 14);
+                    if (c0 >= positions || stop.load(std::memory_order_relaxed)) return;
+                    const size_t c1 = std::min(positions, c0 + (1u << 14));
+                    for (size_t p = c0; p < c1; ++p) {
+                        const MNode &n = mm.nodes.by_position(p);
+                        if (n.kind == FR_EFFECT_GRAPH || n.kind == FR_PRIM_F32CONSTANT) continue;
+                        for (size_t i = 0; i < n.inbound.size() && i < 2; ++i) {
+                            const EdgeRef ref = n.inbound[i];
+                            if (!ref.present) continue;
+                            if (ref.from == 0) { fg.par_input(ref.from_slot, me.cnt); continue; }
+                            if (ref.from != const_handle) {
+                                const MNode *src = mm.nodes.find(ref.from);
+                                if (!src || src->kind != FR_PRIM_F32CONSTANT) continue;
+                                const_handle = ref.from;
+                            }
+                            fg.par_konst(ref.from_slot, me.cnt);
+                        }
+                    }
+                }
+            } catch (...) {   // budget, too many input slots: no harm done, the rest goes the sequential way
+                stop.store(true);
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            th.reserve(nthreads - 1);
+            for (unsigned t = 1; t < nthreads; ++t) th.emplace_back(leaves, t);
+            leaves(0);
+            for (std::thread &x : th) x.join();
+        }
+        for (ParThread &x : ts) { x.cnt.id_next = x.cnt.id_end = 0; }   // pass 2 starts on fresh blocks, above every leaf
+        auto work = [&](unsigned t) {
+            ParThread &me = ts[t];
+            me.me = PAR_BUSY | (uint64_t)(t + 1);
+            for (;;) {
+                if (stop.load(std::memory_order_relaxed)) return;
+                const uint32_t s = next_row.fetch_add(1);
+                if (s >= hi) return;
+                try {
+                    const EdgeRef ref = s < mm.outputs.size() ? mm.outputs[s] : EdgeRef{};
+                    fg.outputs[s] = par_eval(me, ref);
+                    done[s] = 1;
+                } catch (const FlatGraph::ParBudget &) {   // the constants' table is as full as it was sized for: the rest sequentially
+                    stop.store(true);
+                } catch (...) {   // composite, error, suspected cycle: the sequential pass lowers this row (and reports)
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        th.reserve(nthreads - 1);
+        for (unsigned t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+        work(0);
+        for (std::thread &x : th) x.join();
+        std::vector<FlatGraph::ParCounters> cnts;
+        for (ParThread &x : ts) { cnts.push_back(x.cnt); relowered += x.relowered; fg.n_mirror_nodes_visited += x.visited; }
+        fg.par_end(cnts);
+        cells.set_size(par_cells_next);
+        return true;
+    }
+
     // journal == nullptr: from scratch
     const FlatGraph &update(const Mirror &mm, uint32_t n_slots, const std::vector<uint32_t> *journal) {
         // superseded nodes cost memory only (32 B each with their hash-table entry), a rebuild costs a stall: be generous
@@ -501,7 +782,10 @@ struct Lowering::Impl {
         }
         valid = true;   // from here on the state matches the mirror even if an output fails to lower
         fg.outputs.assign(n_slots, 0);
+        std::vector<char> done(n_slots, 0);
+        if (full && allow_parallel) lower_rows_parallel(mm, n_slots, done);   // big graphs: rows on several threads; what is left follows here
         for (uint32_t s = 0; s < n_slots; ++s) {
+            if (done[s]) continue;
             if (s < row_lo || s >= row_hi) { fg.outputs[s] = fg.konst(0); continue; }   // another rank's row
             EdgeRef ref = s < mm.outputs.size() ? mm.outputs[s] : EdgeRef{};  // reference.rs:158-161
             fg.outputs[s] = eval(0, ref);
@@ -513,7 +797,8 @@ struct Lowering::Impl {
 
 Lowering::Lowering() : impl_(new Impl) {}
 Lowering::~Lowering() = default;
-const FlatGraph &Lowering::update(Mirror &m, uint32_t n_slots, uint32_t row_lo, uint32_t row_hi) {
+const FlatGraph &Lowering::update(Mirror &m, uint32_t n_slots, uint32_t row_lo, uint32_t row_hi, bool deterministic) {
+    impl_->allow_parallel = !deterministic;
     std::vector<uint32_t> journal;
     journal.swap(m.journal);
     bool usable = m.journal_on && !m.journal_overflow;

@@ -160,6 +160,42 @@ public:
         slots_ = old_ = nullptr;
         cap_ = mask_ = n_ = old_cap_ = old_pos_ = 0;
     }
+
+    // ---- lock-free insert-if-absent, for the parallel from-scratch lowering (graph.cpp Lowering::Impl::update_parallel) ----
+    // The table never grows here: it must have been sized for everything that can arrive (reserve(), which also finishes
+    // any migration; concurrent_ready() says so).  make() runs exactly once per new key, in the thread that claimed the slot,
+    // and returns a NON-ZERO value; a thread that finds the key claimed but unpublished waits for the value (the claimer is a
+    // few instructions from publishing it and takes no lock and no other slot meanwhile).  Afterwards the owner calls
+    // concurrent_added(n) with the number of keys the threads inserted, and the map is an ordinary one again.
+    bool concurrent_ready(size_t extra) const { return cap_ && !old_ && (n_ + extra) * 4 <= cap_ * 3; }
+    template <class F>
+    uint64_t concurrent_get(uint64_t k, F &&make, size_t *inserted) {
+        size_t i = hash(k) & mask_;
+        for (;;) {
+            uint64_t cur = __atomic_load_n(&slots_[i].key1, __ATOMIC_ACQUIRE);
+            if (cur == 0) {
+                uint64_t expect = 0;
+                if (__atomic_compare_exchange_n(&slots_[i].key1, &expect, k + 1, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+                    const uint64_t v = make();
+                    __atomic_store_n(&slots_[i].val, v, __ATOMIC_RELEASE);
+                    ++*inserted;
+                    return v;
+                }
+                cur = expect;
+            }
+            if (cur == k + 1) {
+                uint64_t v;
+                while (!(v = __atomic_load_n(&slots_[i].val, __ATOMIC_ACQUIRE))) {
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                }
+                return v;
+            }
+            i = (i + 1) & mask_;
+        }
+    }
+    void concurrent_added(size_t n) { n_ += n; }
 };
 
 // Growable array for the engine's multi-million-element tables (lowered nodes, memo tables, reader lists) that never
@@ -218,6 +254,11 @@ public:
         n_ = n;
     }
     void clear();                                 // gives the pages back
+    // Concurrent appends (parallel lowering): with the address range mapped the threads write elements at indices they drew
+    // from their own atomic counter -- nothing moves, pages appear as they are touched -- and the owner sets the size after.
+    bool mapped() { if (!p_ && !mapped_) map_once(); return mapped_; }
+    size_t capacity() const { return cap_; }
+    void set_size(size_t n) { n_ = n; }
 };
 
 struct Error : std::runtime_error {
@@ -330,6 +371,7 @@ public:
         // position of a node inside the table (a dense id for per-node side tables)
         uint32_t position(const MNode *n) const { return n->pos; }
         size_t capacity_positions() const { return store_.size(); }
+        const MNode &by_position(size_t pos) const { return store_[pos]; }   // (a recycled position holds an empty node)
     };
     NodeTable nodes;
     std::vector<EdgeRef> outputs;
@@ -388,7 +430,30 @@ struct FlatGraph {
     float const_val(uint32_t id) const;
     void reserve_nodes(size_t n) { nodes.reserve(n); cse_bin_.reserve(n); }   // one allocation instead of repeated regrowth
 
+    // ---- concurrent construction (the parallel from-scratch lowering; graph.cpp) ----------------------------------------
+    // Between par_begin() and par_end() several threads may call the par_* forms of konst / input / make at once: node ids
+    // come in per-thread blocks drawn from one atomic counter (one contended add per 4096 nodes instead of per node); a
+    // thread whose next id is not above both operands of the node it is making -- an operand another thread made from a later
+    // block: shared sub-expressions -- abandons the rest of its block for a fresh one, which lies above every id handed out so
+    // far, so operands still precede users.  Unused ids are all-zero nodes (the constant +0.0): garbage like the nodes an
+    // incremental update supersedes.  The hash-consing tables take lock-free insert-if-absent.
+    struct ParCounters {
+        size_t new_const = 0, new_input = 0, new_bin = 0, const_budget = 0;
+        uint32_t max_depth = 0, max_input_slot = 0;
+        uint32_t id_next = 0, id_end = 0;      // this thread's block of node ids
+        bool has_input = false;
+    };
+    static constexpr uint32_t PAR_ID_BLOCK = 4096;
+    struct ParBudget {};   // thrown by par_konst when the constants' table has taken what it was sized for: lower the rest sequentially
+    bool par_begin(size_t max_new_nodes, size_t const_budget);   // false: this graph cannot (the node array is not a mapped range)
+    uint32_t par_konst(uint32_t bits, ParCounters &c);
+    uint32_t par_input(uint32_t slot, ParCounters &c);
+    uint32_t par_make(FlatOp op, uint32_t a, uint32_t b, ParCounters &c);
+    void par_end(const std::vector<ParCounters> &threads);
+
 private:
+    uint32_t par_next_ = 0;        // next unassigned block of node ids while a concurrent construction is open (atomic builtins)
+    uint32_t par_push(FlatOp op, uint32_t a, uint32_t b, uint32_t depth, ParCounters &c);
     FlatMap64 cse_[2];   // OP_CONST: bits -> node id + 1; OP_INPUT: slot -> node id + 1
     FlatMap64 cse_bin_;  // (op << 60 | a << 30 | b) -> node id + 1   (ids < 2^30)
     uint32_t push(FlatOp op, uint32_t a, uint32_t b, uint32_t depth);
@@ -415,7 +480,9 @@ public:
     // graph is fixed.  The returned reference is stable for the life of this object.
     // [row_lo, row_hi): only these output slots are lowered (a rank of a voice-sharded job needs nothing else); the
     // others read as the constant 0 and are never planned.  A different range than last time lowers from scratch.
-    const FlatGraph &update(Mirror &m, uint32_t n_slots, uint32_t row_lo = 0, uint32_t row_hi = 0xFFFFFFFFu);
+    // `deterministic`: node ids must come out the same for the same mirror wherever this runs (the ranks of a partial-block
+    // sharded job order their exchange by them): a from-scratch lowering then stays on one thread.
+    const FlatGraph &update(Mirror &m, uint32_t n_slots, uint32_t row_lo = 0, uint32_t row_hi = 0xFFFFFFFFu, bool deterministic = false);
     uint64_t generation() const;        // bumped by every from-scratch rebuild: ids of different generations are unrelated
     bool last_was_full() const;
     uint64_t last_relowered() const;    // nodes lowered by the last update()

@@ -1134,8 +1134,108 @@ static void generated_leaves_equal_the_graph() {
     }
 }
 
+// The parallel from-scratch lowering (rows on several threads, graph.cpp Lowering::Impl::lower_rows_parallel) against the
+// one-thread form on graphs built to make threads meet: many rows, each with a part of its own and a part SHARED with other
+// rows (an LFO-like sub-graph feeding several voices, whole rows that repeat another row's expression), a row that fails,
+// a row through a composite-free cycle.  Same errors; where it lowers, the same values at every sampled time; operands
+// precede users in the flat graph; and a Lowering that started in parallel takes incremental edits like any other.
+static void parallel_lowering_equals_sequential() {
+    std::mt19937 rng(77);
+    for (int round = 0; round < 6; ++round) {
+        Build b;
+        const int rows = 24 + round * 7;
+        std::vector<uint32_t> shared;
+        for (int i = 0; i < 6; ++i) {   // shared sub-graphs over inputs and constants
+            uint32_t x = b.op(FR_PRIM_MULTIPLY, In(i % 2), Cf(0.01f * (i + 1)));
+            uint32_t y = b.op(FR_PRIM_MODULO, N(x), Cf(1.0f));
+            shared.push_back(b.op(FR_PRIM_SUM2, N(y), i ? N(shared[i - 1]) : Cf(0.25f)));
+        }
+        std::vector<uint32_t> roots;
+        for (int r = 0; r < rows; ++r) {
+            uint32_t own = voice(b, 8 + (int)(rng() % 3) * 8, 40.0f + r, rng);
+            uint32_t mix = b.op(FR_PRIM_MULTIPLY, N(own), N(shared[rng() % shared.size()]));
+            if (r % 5 == 0) mix = b.op(FR_PRIM_DELAY, N(mix), Cf((float)(r + 1)));
+            if (r % 7 == 3 && !roots.empty()) mix = b.op(FR_PRIM_SUM2, N(mix), N(roots[rng() % roots.size()]));   // reads another row's root
+            roots.push_back(mix);
+            b.out(N(mix), (uint32_t)r);
+        }
+        if (round % 2) b.out(N(roots[3]), (uint32_t)rows);        // a row that repeats another row's expression
+        const uint32_t n_slots = (uint32_t)rows + (round % 2 ? 1u : 0u);
+        Mirror m;
+        b.apply(m);
+        setenv("FR_LOWER_PAR_MIN_NODES", "0", 1);
+        setenv("FR_LOWER_THREADS", "1", 1);
+        FlatGraph seq = lower(m, n_slots);
+        setenv("FR_LOWER_THREADS", round % 2 ? "3" : "8", 1);
+        FlatGraph par = lower(m, n_slots);
+        CHECK(par.outputs.size() == seq.outputs.size());
+        for (uint32_t id = 0; id < par.nodes.size(); ++id) {
+            const FlatNode &n = par.nodes[id];
+            if (n.op != OP_CONST && n.op != OP_INPUT) CHECK(n.a < id && n.b < id);
+        }
+        Inputs hist(2);
+        for (int t = 0; t < 160; ++t) { hist[0].push_back((float)t); hist[1].push_back(0.37f * (float)t - 3.0f); }
+        for (uint32_t s2 = 0; s2 < n_slots; ++s2)
+            for (uint64_t t : {0ull, 1ull, 17ull, 64ull, 159ull})
+                CHECK(same_bits(flat_eval(seq, seq.outputs[s2], t, hist), flat_eval(par, par.outputs[s2], t, hist)));
+        // a Lowering that began in parallel, then edits (incremental, sequential), against from-scratch on one thread
+        Lowering low;
+        const FlatGraph &f0 = low.update(m, n_slots);
+        CHECK(low.last_was_full());
+        (void)f0;
+        for (int e = 0; e < 20; ++e) {
+            const uint32_t victim = roots[rng() % roots.size()];
+            fr_edge old_e{}, new_e{};
+            bool found = false;
+            for (const fr_edge &x : b.edges) if (x.to == victim && x.to_slot == 1) { old_e = x; found = true; }
+            if (!found) continue;
+            m.del_edge(old_e);
+            new_e = fr_edge{1, victim, f32_to_bits(0.5f + 0.01f * e), 1};
+            m.add_edge(new_e);
+            for (fr_edge &x : b.edges) if (x.to == victim && x.to_slot == 1) x = new_e;
+            const FlatGraph &fi = low.update(m, n_slots);
+            CHECK(!low.last_was_full());
+            setenv("FR_LOWER_THREADS", "1", 1);
+            FlatGraph ref = lower(m, n_slots);
+            setenv("FR_LOWER_THREADS", "8", 1);
+            for (uint32_t s2 = 0; s2 < n_slots; ++s2)
+                for (uint64_t t : {0ull, 33ull, 159ull}) CHECK(same_bits(flat_eval(ref, ref.outputs[s2], t, hist), flat_eval(fi, fi.outputs[s2], t, hist)));
+        }
+        // errors: an edge from a node that does not exist, in the middle of the rows -> the same error as on one thread
+        Mirror bad;
+        b.apply(bad);
+        bad.add_edge(fr_edge{999999, roots[rows / 2], 0, 0});
+        for (const char *threads : {"1", "8"}) {
+            setenv("FR_LOWER_THREADS", threads, 1);
+            bool threw = false;
+            try { (void)lower(bad, n_slots); } catch (const Error &er) { threw = er.code == FR_ERR_NO_SUCH_NODE; }
+            CHECK(threw);
+        }
+        // a cycle between two rows' nodes -> FR_ERR_CYCLE either way (the threads hand it to the sequential pass)
+        Mirror cyc;
+        b.apply(cyc);
+        {
+            // roots[1] = own * shared: rewire its slot 1 to read roots[2], and roots[2]'s slot 1 to read roots[1]
+            fr_edge e1{}, e2{};
+            for (const fr_edge &x : b.edges) { if (x.to == roots[1] && x.to_slot == 1) e1 = x; if (x.to == roots[2] && x.to_slot == 1) e2 = x; }
+            cyc.del_edge(e1); cyc.del_edge(e2);
+            cyc.add_edge(fr_edge{roots[2], roots[1], 0, 1});
+            cyc.add_edge(fr_edge{roots[1], roots[2], 0, 1});
+        }
+        for (const char *threads : {"1", "8"}) {
+            setenv("FR_LOWER_THREADS", threads, 1);
+            bool threw = false;
+            try { (void)lower(cyc, n_slots); } catch (const Error &er) { threw = er.code == FR_ERR_CYCLE; }
+            CHECK(threw);
+        }
+    }
+    unsetenv("FR_LOWER_THREADS");
+    unsetenv("FR_LOWER_PAR_MIN_NODES");
+}
+
 int main(int argc, char **argv) {
     std::vector<std::pair<const char *, std::function<void()>>> tests = {
+        {"parallel_lowering_equals_sequential", parallel_lowering_equals_sequential},
         {"lowering_folds_constants", lowering_folds_constants}, {"lowering_errors", lowering_errors},
         {"random_graphs_lower_correctly", random_graphs_lower_correctly}, {"banks_are_recognised", banks_are_recognised},
         {"effects_chain_is_staged", effects_chain_is_staged}, {"dynamic_delay_goes_to_pull", dynamic_delay_goes_to_pull},

@@ -49,7 +49,7 @@ def test_engine_host_logic_against_oracle(oracle_lib):
     if not os.path.exists(PLAN_BIN) or os.path.getmtime(PLAN_BIN) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(PLAN_BIN), exist_ok=True)
         subprocess.run(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
-                        "-Wno-subobject-linkage", "-o", PLAN_BIN, PLAN_SRC, "-ldl"], check=True)
+                        "-Wno-subobject-linkage", "-pthread", "-o", PLAN_BIN, PLAN_SRC, "-ldl"], check=True)
     env = dict(os.environ, FRIENDSHIP_ORACLE_LIB=oracle_lib.path)
     p = subprocess.run([PLAN_BIN], env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and "14 passed; 0 failed" in p.stdout, p.stdout + p.stderr
+    assert p.returncode == 0 and "15 passed; 0 failed" in p.stdout, p.stdout + p.stderr
