@@ -245,6 +245,7 @@ struct fr_renderer {
     hipStream_t xstream = nullptr;
     std::vector<hipEvent_t> x_events;    // [tile] banks of the tile done (call's stream) ... and x_events.back(): exchange done (xstream)
     uint32_t x_max_tiles = 4, x_min_tile = 1024;
+    bool x_tiles_explicit = false;       // either knob came from the environment: tile whatever the transport
     uint64_t exchange_bytes = 0;         // sent by this rank since the renderer was made (fr_plan_json)
     uint64_t exchange_calls = 0, exchange_tiles = 0;
     PinnedBuf h_xsend, h_xrecv;
@@ -903,7 +904,11 @@ struct fr_renderer {
         // shorter than x_min_tile.  One tile = the serial form of round 2.
         std::vector<std::pair<uint64_t, uint64_t>> xt;   // (offset in the window, frames)
         if (!sp.split.empty()) {
-            uint64_t nt = (shard_flags & FR_SHARD_SERIAL_EXCHANGE) ? 1 : std::min<uint64_t>(x_max_tiles, xlen / std::max<uint32_t>(x_min_tile, 64u));
+            // (the host-callback transport pays a host round trip and a stream synchronisation per message -- 4 tiles over gloo
+            //  measured 0.63 ms per call against 0.28 serial, profiles/r03_exchange_rehearsal.txt: it stays serial unless asked;
+            //  RCCL sends are enqueued like kernels, there tiling hides them)
+            const bool serial = (shard_flags & FR_SHARD_SERIAL_EXCHANGE) || (!rccl && !x_tiles_explicit);
+            uint64_t nt = serial ? 1 : std::min<uint64_t>(x_max_tiles, xlen / std::max<uint32_t>(x_min_tile, 64u));
             nt = std::max<uint64_t>(nt, 1);
             const uint64_t tl = (((xlen + nt - 1) / nt) + 63) / 64 * 64;
             for (uint64_t off = 0; off < xlen; off += tl) xt.push_back({off, std::min(tl, xlen - off)});
@@ -1297,8 +1302,8 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     }
     if (const char *sv = std::getenv("FR_STAGE_JIT")) r->stage_jit_mode = sv[0] == '0' ? 0 : (sv[0] == '1' ? 1 : 2);
     if (const char *fv = std::getenv("FR_STAGE_STRIDED")) r->fused_strided_ok = fv[0] != '0';
-    if (const char *xv = std::getenv("FR_EXCHANGE_TILES")) r->x_max_tiles = (uint32_t)std::min(64, std::max(1, std::atoi(xv)));
-    if (const char *xv = std::getenv("FR_EXCHANGE_MIN_TILE")) r->x_min_tile = (uint32_t)std::min(1 << 20, std::max(64, std::atoi(xv)));
+    if (const char *xv = std::getenv("FR_EXCHANGE_TILES")) { r->x_max_tiles = (uint32_t)std::min(64, std::max(1, std::atoi(xv))); r->x_tiles_explicit = true; }
+    if (const char *xv = std::getenv("FR_EXCHANGE_MIN_TILE")) { r->x_min_tile = (uint32_t)std::min(1 << 20, std::max(64, std::atoi(xv))); r->x_tiles_explicit = true; }
     if (const char *iv = std::getenv("FR_STREAM_IDLE_MS")) r->stream_idle_ms = (uint32_t)std::min(60000, std::max(1, std::atoi(iv)));
     r->device_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <thread>
 
@@ -249,18 +250,44 @@ bool FlatGraph::par_begin(size_t max_new_nodes, size_t const_budget) {
     cse_[OP_CONST].reserve(cse_[OP_CONST].size() + const_budget + 1024);   // (+ the few a thread may add between its check and the others')
     cse_[OP_INPUT].reserve(cse_[OP_INPUT].size() + 4096);
     if (!cse_bin_.concurrent_ready(max_new_nodes) || !cse_[OP_CONST].concurrent_ready(const_budget) || !cse_[OP_INPUT].concurrent_ready(4096)) return false;
-    par_next_ = (uint32_t)nodes.size();
+    par_next_s_.v = (uint32_t)nodes.size();
+    par_input_claimed_ = 0;
+    par_input_budget_ = 4096;
+    return true;
+}
+
+bool FlatGraph::par_begin_in_place(size_t max_new_nodes, size_t const_budget) {
+    // (an incremental update: growing a hash table means rehashing the whole graph's entries -- tens of milliseconds --
+    //  which is what the caller is trying to avoid; the tables normally have a quarter to a half of their slots free)
+    if (!nodes.mapped() || nodes.capacity() < nodes.size() + max_new_nodes + const_budget + 64) return false;
+    // (a small table is rehashed in no time: give it room)
+    if (cse_bin_.size() < (1u << 16)) cse_bin_.reserve(cse_bin_.size() + max_new_nodes);
+    if (cse_[OP_CONST].size() < (1u << 16)) cse_[OP_CONST].reserve(cse_[OP_CONST].size() + const_budget + 1024);
+    if (!cse_bin_.concurrent_ready(max_new_nodes) || !cse_[OP_CONST].concurrent_ready(const_budget + 1024)) return false;
+    par_next_s_.v = (uint32_t)nodes.size();
+    par_input_claimed_ = 0;
+    par_input_budget_ = 0;
+    while (cse_[OP_INPUT].concurrent_ready(par_input_budget_ + 128) && par_input_budget_ < 4096) par_input_budget_ += 128;   // what it has room for
     return true;
 }
 
 uint32_t FlatGraph::par_push(FlatOp op, uint32_t a, uint32_t b, uint32_t depth, ParCounters &c) {
     const uint32_t above = (op == OP_CONST || op == OP_INPUT) ? 0u : std::max(a, b);   // operands must have smaller ids
-    if (c.id_next == c.id_end || c.id_next <= above) {
-        c.id_next = __atomic_fetch_add(&par_next_, PAR_ID_BLOCK, __ATOMIC_RELAXED);
-        c.id_end = c.id_next + PAR_ID_BLOCK;
-        if (c.id_end >= 0x3FFFFFFFu) throw Error(FR_ERR_UNSUPPORTED, "lowered graph exceeds 2^30 nodes");
+    uint32_t id;
+    if (c.id_next != c.id_end && c.id_next <= above) {
+        // an operand another thread made, from a later block (voices an octave apart share every second partial's
+        // sub-expression through hash-consing): this node, and then its users up the tree, take single ids from the counter --
+        // above everything handed out so far -- while the thread's block stays in use for what does not depend on them
+        id = __atomic_fetch_add(&par_next_s_.v, 1u, __ATOMIC_RELAXED);
+        if (id >= 0x3FFFFFFFu) throw Error(FR_ERR_UNSUPPORTED, "lowered graph exceeds 2^30 nodes");
+    } else {
+        if (c.id_next == c.id_end) {
+            c.id_next = __atomic_fetch_add(&par_next_s_.v, PAR_ID_BLOCK, __ATOMIC_RELAXED);
+            c.id_end = c.id_next + PAR_ID_BLOCK;
+            if (c.id_end >= 0x3FFFFFFFu) throw Error(FR_ERR_UNSUPPORTED, "lowered graph exceeds 2^30 nodes");
+        }
+        id = c.id_next++;
     }
-    const uint32_t id = c.id_next++;
     nodes.data()[id] = FlatNode{op, a, b, depth};   // (published by whoever hands the id on: release store of the table entry / memo)
     return id;
 }
@@ -271,8 +298,12 @@ uint32_t FlatGraph::par_konst(uint32_t bits, ParCounters &c) {
 }
 
 uint32_t FlatGraph::par_input(uint32_t slot, ParCounters &c) {
-    if (c.new_input >= 4000) throw Error(FR_ERR_UNSUPPORTED, "too many distinct input slots for one parallel lowering");   // (caught: the row is lowered sequentially)
-    const uint32_t id = (uint32_t)(cse_[OP_INPUT].concurrent_get(slot, [&] { return (uint64_t)par_push(OP_INPUT, slot, 0, 0, c) + 1; }, &c.new_input) - 1);
+    // (new input slots are rare; one shared count against what the table was found to have room for)
+    if (__atomic_load_n(&par_input_claimed_, __ATOMIC_RELAXED) + 64 >= par_input_budget_) throw ParBudget{};
+    const uint32_t id = (uint32_t)(cse_[OP_INPUT].concurrent_get(slot, [&] {
+        __atomic_fetch_add(&par_input_claimed_, (size_t)1, __ATOMIC_RELAXED);
+        return (uint64_t)par_push(OP_INPUT, slot, 0, 0, c) + 1;
+    }, &c.new_input) - 1);
     if (!c.has_input || slot > c.max_input_slot) c.max_input_slot = slot;
     c.has_input = true;
     return id;
@@ -313,7 +344,7 @@ void FlatGraph::par_end(const std::vector<ParCounters> &threads) {
     cse_[OP_CONST].concurrent_added(nc);
     cse_[OP_INPUT].concurrent_added(ni);
     cse_bin_.concurrent_added(nb);
-    nodes.set_size(__atomic_load_n(&par_next_, __ATOMIC_ACQUIRE));
+    nodes.set_size(__atomic_load_n(&par_next_s_.v, __ATOMIC_ACQUIRE));
 }
 
 // ---- lowering --------------------------------------------------------------------------------------
@@ -574,14 +605,16 @@ struct Lowering::Impl {
     // Incremental updates (a few nodes per edit) stay sequential.
     static constexpr uint64_t PAR_BUSY = 1ull << 40;
     struct NeedsSequential {};
-    struct ParThread {
+    struct alignas(128) ParThread {   // (a cache line pair of its own: the counters are written at every node)
         FlatGraph::ParCounters cnt;
         uint64_t relowered = 0, visited = 0, me = 0;
         uint32_t cell_next = 0, cell_end = 0;   // this thread's block of reader cells (one contended add per 4096)
         std::vector<Frame> stack;
     };
-    uint32_t par_cells_next = 0;
+    struct alignas(128) ParCellsNext { uint32_t v = 0; char pad[124]; };
+    ParCellsNext par_cells_next_s;   // (its own cache line, like FlatGraph's id counter)
     bool allow_parallel = true;   // (ids then depend on thread timing; Lowering::update's `deterministic` turns it off)
+    uint64_t par_items = 0;       // sub-trees the last update lowered on threads
 
     void par_add_reader(ParThread &ts, uint64_t of, uint64_t reader) {
         if (reader == NOBODY) return;
@@ -589,7 +622,7 @@ struct Lowering::Impl {
         uint64_t old = __atomic_load_n(head, __ATOMIC_ACQUIRE);
         if (old && cells.data()[old - 1].user == reader) return;   // both operands the same node
         if (ts.cell_next == ts.cell_end) {
-            ts.cell_next = __atomic_fetch_add(&par_cells_next, 4096u, __ATOMIC_RELAXED);
+            ts.cell_next = __atomic_fetch_add(&par_cells_next_s.v, 4096u, __ATOMIC_RELAXED);
             ts.cell_end = ts.cell_next + 4096u;
             if (ts.cell_end >= cells.capacity() || ts.cell_end < ts.cell_next) throw NeedsSequential{};
         }
@@ -668,97 +701,173 @@ struct Lowering::Impl {
     static unsigned par_threads() {
         if (const char *e = std::getenv("FR_LOWER_THREADS")) return (unsigned)std::max(1, std::atoi(e));
         const unsigned hw = std::thread::hardware_concurrency();
-        return std::min(32u, std::max(1u, hw));
+        return std::min(32u, std::max(1u, hw));   // (measured on the 256-thread host of an MI355X box: 16 / 32 / 64 threads 92 / 59 / 113 ms at config C)
     }
     static size_t par_min_nodes() {
         const char *e = std::getenv("FR_LOWER_PAR_MIN_NODES");
         return e ? (size_t)std::atoll(e) : (size_t)200000;
     }
+    static size_t par_min_edit() {   // journalled edits (a new node and its two edges are three) from which an incremental update goes parallel
+        const char *e = std::getenv("FR_LOWER_PAR_MIN_EDIT");
+        return e ? (size_t)std::atoll(e) : (size_t)16384;
+    }
 
-    // Lowers the rows [row_lo, row_hi) of a freshly reset state on several threads; done[s] says which rows came through
-    // (fg.outputs[s] set).  Returns false without touching anything when the parallel form does not apply.
-    bool lower_rows_parallel(const Mirror &mm, uint32_t n_slots, std::vector<char> &done) {
+    // par_eval for a node that is known to be a top-level primitive, not a constant (a sub-tree of the frontier below)
+    void par_eval_node(ParThread &ts, const MNode *n) {
+        uint64_t *mv = &memo.top[m->nodes.position(n)];
+        uint64_t v = 0;
+        if (!__atomic_compare_exchange_n(mv, &v, ts.me, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) return;   // lowered meanwhile, or another thread's
+        std::vector<Frame> &stack = ts.stack;
+        stack.clear();
+        stack.push_back(Frame{0, n, 0, {0, 0}});
+        try {
+            while (!stack.empty()) {
+                Frame &f = stack.back();
+                if (f.next < 2) {
+                    const MNode *nn = f.node;
+                    EdgeRef ref = (size_t)f.next < nn->inbound.size() ? nn->inbound[f.next] : EdgeRef{};
+                    uint32_t id;
+                    Frame child;
+                    if (par_resolve(ts, ref, id, child, m->nodes.position(nn))) f.vals[f.next++] = id;
+                    else stack.push_back(child);
+                    continue;
+                }
+                const uint32_t id = fg.par_make(op_of(f.node->kind), f.vals[0], f.vals[1], ts.cnt);
+                __atomic_store_n(&memo.top[m->nodes.position(f.node)], (uint64_t)id + 2, __ATOMIC_RELEASE);
+                ++ts.relowered;
+                stack.pop_back();
+                if (!stack.empty()) { Frame &p = stack.back(); p.vals[p.next++] = id; }
+            }
+        } catch (...) {
+            for (const Frame &f : stack) __atomic_store_n(&memo.top[m->nodes.position(f.node)], (uint64_t)0, __ATOMIC_RELEASE);
+            stack.clear();
+            throw;
+        }
+    }
+
+    // The parallel part of an update: the sub-trees hanging below the rows that still need lowering, on several threads.
+    // Work items are the nodes of a FRONTIER: starting from those rows' roots, un-lowered top-level primitives are expanded
+    // breadth-first into their operands until there are a few items per thread (64 voices give 128+ sub-trees; ONE new
+    // voice -- a note-on -- gives 64 sub-trees of its Sum2 tree too).  What is above the frontier, rows through composites,
+    // and anything that fails stays for the sequential pass that follows, which then finds the sub-trees in the memo.
+    // `full`: a from-scratch lowering (tables sized here, leaf pre-pass); else an incremental one, taken only if the tables
+    // have room for `expect_new` more entries as they are.  Returns false when the parallel form does not apply.
+    bool lower_parallel(const Mirror &mm, uint32_t n_slots, bool full, size_t expect_new) {
         const uint32_t lo = std::min(row_lo, n_slots), hi = std::min(row_hi, n_slots);
-        const unsigned nthreads = std::min<unsigned>(par_threads(), hi > lo ? hi - lo : 0);
+        const unsigned want_threads = par_threads();
         const size_t positions = mm.nodes.capacity_positions();
-        if (nthreads < 2 || mm.nodes.size() < par_min_nodes() || positions >= (1ull << 31)) return false;
-        const size_t const_budget = mm.nodes.size() / 8 + 65536;   // distinct constants the table is sized for (more: the rest sequentially)
-        if (!cells.mapped() || !memo.top.mapped() || !readers_head.top.mapped() || !fg.par_begin(mm.nodes.size() + 16, const_budget)) return false;
+        if (want_threads < 2 || hi <= lo || expect_new < (full ? par_min_nodes() : par_min_edit()) || positions >= (1ull << 31)) return false;
+        const bool trace = std::getenv("FR_LOWER_TRACE") != nullptr;
+        const auto t_begin = std::chrono::steady_clock::now();
+        auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+        const size_t const_budget = full ? mm.nodes.size() / 8 + 65536 : expect_new / 2 + 4096;
+        if (!cells.mapped() || !memo.top.mapped() || !readers_head.top.mapped()) return false;
+        if (full ? !fg.par_begin(mm.nodes.size() + 16, const_budget) : !fg.par_begin_in_place(expect_new + 16, const_budget)) return false;
         memo.top.resize(positions, 0);
         readers_head.top.resize(positions, 0);
-        par_cells_next = (uint32_t)cells.size();
-        std::vector<ParThread> ts(nthreads);
-        std::atomic<uint32_t> next_row{lo};
-        std::atomic<bool> stop{false};
-        // Pass 1 -- every constant and input the top-level nodes read, made before any other node: leaves have no operands, so
-        // their ids may come from any block, and with all of them below every block pass 2 draws, a node made from a constant
-        // some OTHER thread made first never has to abandon its id block for "operands precede users" (the waveform's constants
-        // and the amplitudes 1/(k+1) are shared by every voice: without this pass the graph came out 7x its size in abandoned
-        // ids).  A scan of the node table in position order, split evenly: memory-bound, a few tens of milliseconds.
-        std::atomic<size_t> next_chunk{0};
-        auto leaves = [&](unsigned t) {
-            ParThread &me = ts[t];
-            me.cnt.const_budget = const_budget / nthreads;
-            uint32_t const_handle = 0;   // the last handle seen to be an F32Constant node (usually there is exactly one)
-            try {
-                for (;;) {
-                    const size_t c0 = next_chunk.fetch_add(1 << 14);
-                    if (c0 >= positions || stop.load(std::memory_order_relaxed)) return;
-                    const size_t c1 = std::min(positions, c0 + (1u << 14));
-                    for (size_t p = c0; p < c1; ++p) {
-                        const MNode &n = mm.nodes.by_position(p);
-                        if (n.kind == FR_EFFECT_GRAPH || n.kind == FR_PRIM_F32CONSTANT) continue;
-                        for (size_t i = 0; i < n.inbound.size() && i < 2; ++i) {
-                            const EdgeRef ref = n.inbound[i];
-                            if (!ref.present) continue;
-                            if (ref.from == 0) { fg.par_input(ref.from_slot, me.cnt); continue; }
-                            if (ref.from != const_handle) {
-                                const MNode *src = mm.nodes.find(ref.from);
-                                if (!src || src->kind != FR_PRIM_F32CONSTANT) continue;
-                                const_handle = ref.from;
-                            }
-                            fg.par_konst(ref.from_slot, me.cnt);
-                        }
-                    }
-                }
-            } catch (...) {   // budget, too many input slots: no harm done, the rest goes the sequential way
-                stop.store(true);
-            }
+        par_cells_next_s.v = (uint32_t)cells.size();
+        // ---- the frontier ----
+        auto unlowered_primitive = [&](EdgeRef ref) -> const MNode * {
+            if (!ref.present || ref.from == 0) return nullptr;
+            const MNode *n = mm.nodes.find(ref.from);
+            if (!n || n->kind == FR_EFFECT_GRAPH || n->kind == FR_PRIM_F32CONSTANT || ref.from_slot != 0) return nullptr;
+            return memo.top[mm.nodes.position(n)] == 0 ? n : nullptr;
         };
+        std::vector<const MNode *> frontier;
         {
+            FlatMap64 seen;
+            for (uint32_t s = lo; s < hi; ++s)
+                if (const MNode *n = unlowered_primitive(s < mm.outputs.size() ? mm.outputs[s] : EdgeRef{})) {
+                    bool fresh = false;
+                    seen.get(mm.nodes.position(n), &fresh);
+                    if (fresh) frontier.push_back(n);
+                }
+            const size_t want = (size_t)want_threads * 4;
+            size_t head = 0;   // frontier[0, head) have been expanded: they stay for the sequential pass, their operands joined the frontier
+            while (head < frontier.size() && frontier.size() - head < want && head < (1u << 16)) {
+                const MNode *n = frontier[head++];
+                for (size_t i = 0; i < 2 && i < n->inbound.size(); ++i)
+                    if (const MNode *c = unlowered_primitive(n->inbound[i])) {
+                        bool fresh = false;
+                        seen.get(mm.nodes.position(c), &fresh);
+                        if (fresh) frontier.push_back(c);
+                    }
+            }
+            frontier.erase(frontier.begin(), frontier.begin() + (ptrdiff_t)head);
+        }
+        const unsigned nthreads = (unsigned)std::min<size_t>(want_threads, frontier.size());
+        if (nthreads < 2) { std::vector<FlatGraph::ParCounters> none; fg.par_end(none); return false; }
+        const double t_setup = since();
+        std::vector<ParThread> ts(nthreads);
+        std::atomic<bool> stop{false};
+        for (unsigned t = 0; t < nthreads; ++t) { ts[t].me = PAR_BUSY | (uint64_t)(t + 1); ts[t].cnt.const_budget = const_budget / nthreads; }
+        auto run_threads = [&](auto &&fn) {
             std::vector<std::thread> th;
             th.reserve(nthreads - 1);
-            for (unsigned t = 1; t < nthreads; ++t) th.emplace_back(leaves, t);
-            leaves(0);
+            for (unsigned t = 1; t < nthreads; ++t) th.emplace_back(fn, t);
+            fn(0);
             for (std::thread &x : th) x.join();
+        };
+        // Pass 1 (from-scratch only) -- every constant and input the top-level nodes read, made before any other node: leaves
+        // have no operands, so their ids may come from any block, and with all of them below every block pass 2 draws, a node
+        // made from a constant some OTHER thread made first keeps its place in its thread's block (the waveform's constants and
+        // the amplitudes 1/(k+1) are shared by every voice).  A scan of the node table in position order: memory-bound.
+        if (full) {
+            std::atomic<size_t> next_chunk{0};
+            run_threads([&](unsigned t) {
+                ParThread &me = ts[t];
+                uint32_t const_handle = 0;   // the last handle seen to be an F32Constant node (usually there is exactly one)
+                try {
+                    for (;;) {
+                        const size_t c0 = next_chunk.fetch_add(1 << 14);
+                        if (c0 >= positions || stop.load(std::memory_order_relaxed)) return;
+                        const size_t c1 = std::min(positions, c0 + (1u << 14));
+                        for (size_t p = c0; p < c1; ++p) {
+                            const MNode &n = mm.nodes.by_position(p);
+                            if (n.kind == FR_EFFECT_GRAPH || n.kind == FR_PRIM_F32CONSTANT) continue;
+                            for (size_t i = 0; i < n.inbound.size() && i < 2; ++i) {
+                                const EdgeRef ref = n.inbound[i];
+                                if (!ref.present) continue;
+                                if (ref.from == 0) { fg.par_input(ref.from_slot, me.cnt); continue; }
+                                if (ref.from != const_handle) {
+                                    const MNode *src = mm.nodes.find(ref.from);
+                                    if (!src || src->kind != FR_PRIM_F32CONSTANT) continue;
+                                    const_handle = ref.from;
+                                }
+                                fg.par_konst(ref.from_slot, me.cnt);
+                            }
+                        }
+                    }
+                } catch (...) {   // budget, too many input slots: no harm done, the rest goes the sequential way
+                    stop.store(true);
+                }
+            });
+            for (ParThread &x : ts) { x.cnt.id_next = x.cnt.id_end = 0; }   // pass 2 starts on fresh blocks, above every leaf
         }
-        for (ParThread &x : ts) { x.cnt.id_next = x.cnt.id_end = 0; }   // pass 2 starts on fresh blocks, above every leaf
-        auto work = [&](unsigned t) {
+        const double t_leaves = since();
+        // Pass 2 -- the sub-trees
+        std::atomic<size_t> next_item{0};
+        run_threads([&](unsigned t) {
             ParThread &me = ts[t];
-            me.me = PAR_BUSY | (uint64_t)(t + 1);
             for (;;) {
                 if (stop.load(std::memory_order_relaxed)) return;
-                const uint32_t s = next_row.fetch_add(1);
-                if (s >= hi) return;
+                const size_t i = next_item.fetch_add(1);
+                if (i >= frontier.size()) return;
                 try {
-                    const EdgeRef ref = s < mm.outputs.size() ? mm.outputs[s] : EdgeRef{};
-                    fg.outputs[s] = par_eval(me, ref);
-                    done[s] = 1;
+                    par_eval_node(me, frontier[i]);
                 } catch (const FlatGraph::ParBudget &) {   // the constants' table is as full as it was sized for: the rest sequentially
                     stop.store(true);
-                } catch (...) {   // composite, error, suspected cycle: the sequential pass lowers this row (and reports)
+                } catch (...) {   // composite, error, suspected cycle: the sequential pass lowers this (and reports)
                 }
             }
-        };
-        std::vector<std::thread> th;
-        th.reserve(nthreads - 1);
-        for (unsigned t = 1; t < nthreads; ++t) th.emplace_back(work, t);
-        work(0);
-        for (std::thread &x : th) x.join();
+        });
         std::vector<FlatGraph::ParCounters> cnts;
         for (ParThread &x : ts) { cnts.push_back(x.cnt); relowered += x.relowered; fg.n_mirror_nodes_visited += x.visited; }
         fg.par_end(cnts);
-        cells.set_size(par_cells_next);
+        cells.set_size(par_cells_next_s.v);
+        par_items = frontier.size();
+        if (trace) std::fprintf(stderr, "parallel lowering (%s), %u threads, %zu sub-trees: tables + frontier %.1f ms, leaves %.1f ms, sub-trees %.1f ms\n",
+                                full ? "from scratch" : "incremental", nthreads, frontier.size(), t_setup, t_leaves - t_setup, since() - t_leaves);
         return true;
     }
 
@@ -769,6 +878,7 @@ struct Lowering::Impl {
                              cells.size() > 8 * base_cells + (1u << 22);
         const bool full = !valid || m != &mm || !journal || garbage;
         relowered = 0;
+        par_items = 0;
         was_full = full;
         if (full) {
             reset(mm);
@@ -782,10 +892,10 @@ struct Lowering::Impl {
         }
         valid = true;   // from here on the state matches the mirror even if an output fails to lower
         fg.outputs.assign(n_slots, 0);
-        std::vector<char> done(n_slots, 0);
-        if (full && allow_parallel) lower_rows_parallel(mm, n_slots, done);   // big graphs: rows on several threads; what is left follows here
+        // big jobs -- a from-scratch lowering, or an edit that brought thousands of new nodes (a note-on) -- first lower the
+        // sub-trees below the rows on several threads; the loop here then finds them in the memo
+        if (allow_parallel) lower_parallel(mm, n_slots, full, full ? mm.nodes.size() : (journal ? journal->size() : 0));
         for (uint32_t s = 0; s < n_slots; ++s) {
-            if (done[s]) continue;
             if (s < row_lo || s >= row_hi) { fg.outputs[s] = fg.konst(0); continue; }   // another rank's row
             EdgeRef ref = s < mm.outputs.size() ? mm.outputs[s] : EdgeRef{};  // reference.rs:158-161
             fg.outputs[s] = eval(0, ref);
@@ -814,6 +924,7 @@ const FlatGraph &Lowering::update(Mirror &m, uint32_t n_slots, uint32_t row_lo, 
 uint64_t Lowering::generation() const { return impl_->generation; }
 bool Lowering::last_was_full() const { return impl_->was_full; }
 uint64_t Lowering::last_relowered() const { return impl_->relowered; }
+uint64_t Lowering::last_parallel_subtrees() const { return impl_->par_items; }
 
 FlatGraph lower(const Mirror &m, uint32_t n_slots) {
     Lowering::Impl one_shot;

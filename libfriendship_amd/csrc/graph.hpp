@@ -48,11 +48,12 @@ class FlatMap64 {
         g ^= g >> 33; g *= 0xff51afd7ed558ccdULL; g ^= g >> 33; g *= 0xc4ceb9fe1a85ec53ULL; g ^= g >> 33;
         return (g << 4) | (k & 15u);
     }
-    static Slot *alloc(size_t cap) {
-        Slot *p = (Slot *)std::calloc(cap, sizeof(Slot));
-        if (!p) throw std::bad_alloc();
-        return p;
-    }
+    // Big tables come from mmap with transparent huge pages asked for: a from-scratch lowering touches every page of them
+    // once, and with 4 KiB pages those first touches -- 74 000 of them at config C, each through the kernel's page-fault path
+    // -- were the part of the parallel lowering that did not get faster with more threads.
+    static constexpr size_t HUGE_BYTES = (size_t)2 << 20;
+    static Slot *alloc(size_t cap);
+    static void dealloc(Slot *p, size_t cap);
     static Slot *probe(Slot *t, size_t mask, uint64_t k) {   // the slot holding k, or the empty slot where it would go
         size_t i = hash(k) & mask;
         while (t[i].key1 != 0 && t[i].key1 != k + 1) i = (i + 1) & mask;
@@ -61,7 +62,7 @@ class FlatMap64 {
     void migrate(size_t steps) {
         while (old_ && steps) {
             if (old_pos_ == old_cap_) {
-                std::free(old_);
+                dealloc(old_, old_cap_);
                 old_ = nullptr;
                 old_cap_ = old_pos_ = 0;
                 return;
@@ -155,8 +156,8 @@ public:
         return s->val;
     }
     void clear() {
-        std::free(slots_);
-        std::free(old_);
+        dealloc(slots_, cap_);
+        dealloc(old_, old_cap_);
         slots_ = old_ = nullptr;
         cap_ = mask_ = n_ = old_cap_ = old_pos_ = 0;
     }
@@ -432,11 +433,11 @@ struct FlatGraph {
 
     // ---- concurrent construction (the parallel from-scratch lowering; graph.cpp) ----------------------------------------
     // Between par_begin() and par_end() several threads may call the par_* forms of konst / input / make at once: node ids
-    // come in per-thread blocks drawn from one atomic counter (one contended add per 4096 nodes instead of per node); a
-    // thread whose next id is not above both operands of the node it is making -- an operand another thread made from a later
-    // block: shared sub-expressions -- abandons the rest of its block for a fresh one, which lies above every id handed out so
-    // far, so operands still precede users.  Unused ids are all-zero nodes (the constant +0.0): garbage like the nodes an
-    // incremental update supersedes.  The hash-consing tables take lock-free insert-if-absent.
+    // come in per-thread blocks drawn from one atomic counter (one contended add per 4096 nodes instead of per node); a node
+    // with an operand another thread made from a later block (shared sub-expressions) takes a single id from the same counter
+    // instead -- above every id handed out so far -- so operands still precede users (the planner orders cut nodes by id).
+    // Ids of a block that were never used are all-zero nodes (the constant +0.0): garbage like the nodes an incremental update
+    // supersedes.  The hash-consing tables take lock-free insert-if-absent.
     struct ParCounters {
         size_t new_const = 0, new_input = 0, new_bin = 0, const_budget = 0;
         uint32_t max_depth = 0, max_input_slot = 0;
@@ -446,13 +447,18 @@ struct FlatGraph {
     static constexpr uint32_t PAR_ID_BLOCK = 4096;
     struct ParBudget {};   // thrown by par_konst when the constants' table has taken what it was sized for: lower the rest sequentially
     bool par_begin(size_t max_new_nodes, size_t const_budget);   // false: this graph cannot (the node array is not a mapped range)
+    bool par_begin_in_place(size_t max_new_nodes, size_t const_budget);   // the same without resizing any table: false if one lacks room
     uint32_t par_konst(uint32_t bits, ParCounters &c);
     uint32_t par_input(uint32_t slot, ParCounters &c);
     uint32_t par_make(FlatOp op, uint32_t a, uint32_t b, ParCounters &c);
     void par_end(const std::vector<ParCounters> &threads);
 
 private:
-    uint32_t par_next_ = 0;        // next unassigned block of node ids while a concurrent construction is open (atomic builtins)
+    // next unassigned node id while a concurrent construction is open (atomic builtins).  On a cache line of its own: the
+    // threads add to it, and every other member of this object is something they all READ at every node.
+    struct alignas(128) ParNext { uint32_t v = 0; char pad[124]; };
+    ParNext par_next_s_;
+    size_t par_input_claimed_ = 0, par_input_budget_ = 0;
     uint32_t par_push(FlatOp op, uint32_t a, uint32_t b, uint32_t depth, ParCounters &c);
     FlatMap64 cse_[2];   // OP_CONST: bits -> node id + 1; OP_INPUT: slot -> node id + 1
     FlatMap64 cse_bin_;  // (op << 60 | a << 30 | b) -> node id + 1   (ids < 2^30)
@@ -486,6 +492,7 @@ public:
     uint64_t generation() const;        // bumped by every from-scratch rebuild: ids of different generations are unrelated
     bool last_was_full() const;
     uint64_t last_relowered() const;    // nodes lowered by the last update()
+    uint64_t last_parallel_subtrees() const;   // sub-trees the last update() lowered on threads (0: it ran on the calling thread alone)
 
 private:
     struct Impl;
@@ -500,10 +507,28 @@ FlatGraph lower(const Mirror &m, uint32_t n_slots);
 }  // namespace fr
 #include <sys/mman.h>
 namespace fr {
+inline FlatMap64::Slot *FlatMap64::alloc(size_t cap) {
+    const size_t bytes = cap * sizeof(Slot);
+    if (bytes >= HUGE_BYTES) {
+        void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);   // zero pages, like calloc
+        if (m == MAP_FAILED) throw std::bad_alloc();   // (dealloc() tells the two kinds apart by size alone)
+        (void)madvise(m, bytes, MADV_HUGEPAGE);
+        return (Slot *)m;
+    }
+    Slot *p = (Slot *)std::calloc(cap, sizeof(Slot));
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+inline void FlatMap64::dealloc(Slot *p, size_t cap) {
+    if (!p) return;
+    if (cap * sizeof(Slot) >= HUGE_BYTES) munmap(p, cap * sizeof(Slot));
+    else std::free(p);
+}
 template <class T>
 void VArray<T>::map_once() {
     void *m = mmap(nullptr, RESERVE_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (m == MAP_FAILED) return;
+    (void)madvise(m, RESERVE_BYTES, MADV_HUGEPAGE);   // pages are touched once, in order, by the million: fault them in 2 MiB at a time
     p_ = (T *)m;
     cap_ = RESERVE_BYTES / sizeof(T);
     mapped_ = true;

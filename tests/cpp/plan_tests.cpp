@@ -1181,7 +1181,7 @@ static void parallel_lowering_equals_sequential() {
         // a Lowering that began in parallel, then edits (incremental, sequential), against from-scratch on one thread
         Lowering low;
         const FlatGraph &f0 = low.update(m, n_slots);
-        CHECK(low.last_was_full());
+        CHECK(low.last_was_full() && low.last_parallel_subtrees() >= 8);
         (void)f0;
         for (int e = 0; e < 20; ++e) {
             const uint32_t victim = roots[rng() % roots.size()];
@@ -1200,6 +1200,29 @@ static void parallel_lowering_equals_sequential() {
             setenv("FR_LOWER_THREADS", "8", 1);
             for (uint32_t s2 = 0; s2 < n_slots; ++s2)
                 for (uint64_t t : {0ull, 33ull, 159ull}) CHECK(same_bits(flat_eval(ref, ref.outputs[s2], t, hist), flat_eval(fi, fi.outputs[s2], t, hist)));
+        }
+        // a note-on: a whole new voice arrives between two updates -- the incremental update lowers its sub-trees on threads
+        {
+            setenv("FR_LOWER_PAR_MIN_EDIT", "0", 1);
+            setenv("FR_LOWER_THREADS", "8", 1);
+            Build nb;
+            nb.next = b.next + 1000;     // fresh handles
+            nb.nodes.clear();
+            const uint32_t v2 = voice(nb, 64, 61.7f + round, rng);
+            for (auto &n : nb.nodes) { fr_effect e{}; e.kind = n.second; m.add_node(n.first, &e); }
+            for (auto &e : nb.edges) m.add_edge(e);
+            m.add_edge(fr_edge{v2, 0, 0, n_slots});
+            const FlatGraph &fi = low.update(m, n_slots + 1);
+            CHECK(!low.last_was_full() && low.last_relowered() >= 64 * 11 && low.last_parallel_subtrees() >= 8);
+            setenv("FR_LOWER_THREADS", "1", 1);
+            FlatGraph ref = lower(m, n_slots + 1);
+            for (uint32_t s2 = 0; s2 <= n_slots; ++s2)
+                for (uint64_t t : {0ull, 33ull, 159ull}) CHECK(same_bits(flat_eval(ref, ref.outputs[s2], t, hist), flat_eval(fi, fi.outputs[s2], t, hist)));
+            for (uint32_t id = 0; id < fi.nodes.size(); ++id) {
+                const FlatNode &n = fi.nodes[id];
+                if (n.op != OP_CONST && n.op != OP_INPUT) CHECK(n.a < id && n.b < id);
+            }
+            unsetenv("FR_LOWER_PAR_MIN_EDIT");
         }
         // errors: an edge from a node that does not exist, in the middle of the rows -> the same error as on one thread
         Mirror bad;
