@@ -1279,6 +1279,11 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     if (hipSetDevice(dev) != hipSuccess) return FR_ERR_NO_DEVICE;
     fr_renderer *r = new (std::nothrow) fr_renderer();
     if (!r) return FR_ERR_OUT_OF_MEMORY;
+    // The first C++ exception a process throws makes the unwinder walk every loaded object's unwind tables (under the
+    // loader's lock: other throwing threads queue behind it) -- 82 ms measured inside a fill_buffer call with the HIP
+    // runtime and hipRTC loaded.  The engine uses exceptions on rare paths of a call (a lowering thread handing its sub-tree
+    // to the sequential pass, a program a compiled kernel cannot take); pay for the walk here instead.
+    try { throw Error(FR_OK, ""); } catch (const Error &) {}
     r->device = dev;
     r->mode = mode;
     r->jit_async_configured = !(cfg && (cfg->flags & FR_CONFIG_SYNC_COMPILE));

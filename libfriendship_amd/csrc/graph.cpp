@@ -5,8 +5,79 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
+#include <sys/resource.h>
+#include <unistd.h>
+
+namespace {
+// The lowering's helper threads, parked between updates: starting 31 threads costs about a millisecond, which is a third of
+// a note-on's whole budget; waking parked ones costs tens of microseconds.  One pool per process, grown on demand, never
+// shrunk; run() is serialised (two engines lowering at once take turns -- each update is a few milliseconds).
+class LowerPool {
+public:
+    static LowerPool &get() { static LowerPool p; return p; }
+    // fn(t) for t in [0, n): t == 0 on the caller, the rest on pool threads; returns when all have
+    void run(unsigned n, const std::function<void(unsigned)> &fn) {
+        if (n <= 1) { fn(0); return; }
+        std::lock_guard<std::mutex> serial(run_mu_);
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            if (pid_ != getpid()) {   // after a fork() the parked threads exist in the parent only: forget them (never joined, never freed)
+                new std::vector<std::thread>(std::move(workers_));
+                workers_.clear();
+                pid_ = getpid();
+            }
+            while (workers_.size() < n - 1) {
+                const unsigned id = (unsigned)workers_.size() + 1;
+                workers_.emplace_back([this, id] { worker(id); });
+            }
+            fn_ = &fn;
+            n_ = n;
+            pending_ = n - 1;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+    ~LowerPool() {
+        if (pid_ != getpid()) { new std::vector<std::thread>(std::move(workers_)); return; }
+        { std::lock_guard<std::mutex> lk(mu_); quit_ = true; }
+        cv_.notify_all();
+        for (std::thread &t : workers_) t.join();
+    }
+private:
+    void worker(unsigned id) {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_.wait(lk, [&] { return quit_ || epoch_ != seen; });
+            if (quit_) return;
+            seen = epoch_;
+            if (id >= n_) continue;   // this round uses fewer threads
+            const std::function<void(unsigned)> *fn = fn_;
+            lk.unlock();
+            (*fn)(id);
+            lk.lock();
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::mutex run_mu_, mu_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> workers_;
+    const std::function<void(unsigned)> *fn_ = nullptr;
+    unsigned n_ = 0, pending_ = 0;
+    uint64_t epoch_ = 0;
+    bool quit_ = false;
+    pid_t pid_ = getpid();
+};
+}   // namespace
 
 namespace fr {
 
@@ -253,6 +324,8 @@ bool FlatGraph::par_begin(size_t max_new_nodes, size_t const_budget) {
     par_next_s_.v = (uint32_t)nodes.size();
     par_input_claimed_ = 0;
     par_input_budget_ = 4096;
+    par_const_pool_ = (int64_t)const_budget;
+    par_const_grant_ = (uint32_t)std::max<size_t>(16, std::min<size_t>(1024, const_budget / 256));   // (64 threads strand a quarter of the pool at worst)
     return true;
 }
 
@@ -265,6 +338,8 @@ bool FlatGraph::par_begin_in_place(size_t max_new_nodes, size_t const_budget) {
     if (cse_[OP_CONST].size() < (1u << 16)) cse_[OP_CONST].reserve(cse_[OP_CONST].size() + const_budget + 1024);
     if (!cse_bin_.concurrent_ready(max_new_nodes) || !cse_[OP_CONST].concurrent_ready(const_budget + 1024)) return false;
     par_next_s_.v = (uint32_t)nodes.size();
+    par_const_pool_ = (int64_t)const_budget;
+    par_const_grant_ = (uint32_t)std::max<size_t>(16, std::min<size_t>(1024, const_budget / 256));
     par_input_claimed_ = 0;
     par_input_budget_ = 0;
     while (cse_[OP_INPUT].concurrent_ready(par_input_budget_ + 128) && par_input_budget_ < 4096) par_input_budget_ += 128;   // what it has room for
@@ -293,7 +368,13 @@ uint32_t FlatGraph::par_push(FlatOp op, uint32_t a, uint32_t b, uint32_t depth, 
 }
 
 uint32_t FlatGraph::par_konst(uint32_t bits, ParCounters &c) {
-    if (c.new_const >= c.const_budget) throw ParBudget{};   // this thread's share of what the constants' table was sized for
+    if (c.new_const >= c.const_budget) {   // a further grant from what the constants' table was sized for (threads take unequal shares:
+        //                                     whoever starts first scans more of the node table)
+        const int64_t grant = par_const_grant_;
+        const int64_t before = __atomic_fetch_sub(&par_const_pool_, grant, __ATOMIC_RELAXED);
+        if (before < grant) { __atomic_fetch_add(&par_const_pool_, grant, __ATOMIC_RELAXED); throw ParBudget{}; }
+        c.const_budget += (size_t)grant;
+    }
     return (uint32_t)(cse_[OP_CONST].concurrent_get(bits, [&] { return (uint64_t)par_push(OP_CONST, bits, 0, 0, c) + 1; }, &c.new_const) - 1);
 }
 
@@ -656,7 +737,12 @@ struct Lowering::Impl {
                 continue;
             }
             if (v == ts.me) throw NeedsSequential{};            // a cycle: the sequential pass reports it
-            if (++spins > (1u << 22)) throw NeedsSequential{};   // another thread's claim that does not resolve: cycle across threads
+            ++fr_trace_memo_spins;
+            if (++spins > (1u << 22)) {   // another thread's claim that does not resolve: cycle across threads
+                if (std::getenv("FR_LOWER_TRACE")) std::fprintf(stderr, "parallel lowering: thread %llx gave up waiting for node %u (kind %u, memo %llx), read by position %llu\n",
+                                                                 (unsigned long long)ts.me, ref.from, (unsigned)n->kind, (unsigned long long)v, (unsigned long long)reader);
+                throw NeedsSequential{};
+            }
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
@@ -800,14 +886,8 @@ struct Lowering::Impl {
         const double t_setup = since();
         std::vector<ParThread> ts(nthreads);
         std::atomic<bool> stop{false};
-        for (unsigned t = 0; t < nthreads; ++t) { ts[t].me = PAR_BUSY | (uint64_t)(t + 1); ts[t].cnt.const_budget = const_budget / nthreads; }
-        auto run_threads = [&](auto &&fn) {
-            std::vector<std::thread> th;
-            th.reserve(nthreads - 1);
-            for (unsigned t = 1; t < nthreads; ++t) th.emplace_back(fn, t);
-            fn(0);
-            for (std::thread &x : th) x.join();
-        };
+        for (unsigned t = 0; t < nthreads; ++t) { ts[t].me = PAR_BUSY | (uint64_t)(t + 1); ts[t].cnt.const_budget = 0; }
+        auto run_threads = [&](const std::function<void(unsigned)> &fn) { LowerPool::get().run(nthreads, fn); };
         // Pass 1 (from-scratch only) -- every constant and input the top-level nodes read, made before any other node: leaves
         // have no operands, so their ids may come from any block, and with all of them below every block pass 2 draws, a node
         // made from a constant some OTHER thread made first keeps its place in its thread's block (the waveform's constants and
@@ -847,20 +927,42 @@ struct Lowering::Impl {
         const double t_leaves = since();
         // Pass 2 -- the sub-trees
         std::atomic<size_t> next_item{0};
+        struct ThreadTrace { double start = 0, wall = 0, sys = 0, worst = 0; long faults = 0; uint64_t spins[3] = {0, 0, 0}; };
+        std::vector<ThreadTrace> tt(trace ? nthreads : 0);
         run_threads([&](unsigned t) {
             ParThread &me = ts[t];
+            rusage r0{};
+            if (trace) { getrusage(RUSAGE_THREAD, &r0); tt[t].start = since(); }
             for (;;) {
-                if (stop.load(std::memory_order_relaxed)) return;
+                if (stop.load(std::memory_order_relaxed)) break;
                 const size_t i = next_item.fetch_add(1);
-                if (i >= frontier.size()) return;
+                if (i >= frontier.size()) break;
+                const double t_item = trace ? since() : 0.0;
                 try {
                     par_eval_node(me, frontier[i]);
                 } catch (const FlatGraph::ParBudget &) {   // the constants' table is as full as it was sized for: the rest sequentially
+                    if (trace && !stop.load()) std::fprintf(stderr, "  thread %u: a table is as full as it was sized for; the rest sequentially\n", t);
                     stop.store(true);
                 } catch (...) {   // composite, error, suspected cycle: the sequential pass lowers this (and reports)
+                    if (trace) std::fprintf(stderr, "  thread %u: sub-tree %zu left to the sequential pass\n", t, i);
                 }
+                if (trace) tt[t].worst = std::max(tt[t].worst, since() - t_item);
+            }
+            if (trace) {
+                rusage r1{};
+                getrusage(RUSAGE_THREAD, &r1);
+                tt[t].wall = since() - tt[t].start;
+                tt[t].sys = (r1.ru_stime.tv_sec - r0.ru_stime.tv_sec) * 1e3 + (r1.ru_stime.tv_usec - r0.ru_stime.tv_usec) * 1e-3;
+                tt[t].faults = r1.ru_minflt - r0.ru_minflt;
+                tt[t].spins[0] = fr_trace_val_spins; tt[t].spins[1] = fr_trace_memo_spins; tt[t].spins[2] = fr_trace_probe_steps;
+                fr_trace_val_spins = fr_trace_memo_spins = fr_trace_probe_steps = 0;
             }
         });
+        if (trace)
+            for (unsigned t = 0; t < nthreads; ++t)
+                if (tt[t].wall > 5.0 || tt[t].start - t_leaves > 5.0)
+                    std::fprintf(stderr, "  thread %u: started %.1f ms into the pass, ran %.1f ms (kernel time %.1f ms, %ld page faults), longest sub-tree %.1f ms; spins: value %llu, memo %llu, probe steps %llu\n", t,
+                                 tt[t].start - t_leaves, tt[t].wall, tt[t].sys, tt[t].faults, tt[t].worst, (unsigned long long)tt[t].spins[0], (unsigned long long)tt[t].spins[1], (unsigned long long)tt[t].spins[2]);
         std::vector<FlatGraph::ParCounters> cnts;
         for (ParThread &x : ts) { cnts.push_back(x.cnt); relowered += x.relowered; fg.n_mirror_nodes_visited += x.visited; }
         fg.par_end(cnts);

@@ -33,6 +33,7 @@ namespace fr {
 // Growth never stalls a caller: the table of twice the size comes from calloc (pages are touched lazily) and the old
 // one is emptied into it a few slots per insertion, lookups consulting both meanwhile -- a doubling at 1.3 M nodes used
 // to be a 0.1 s pause inside a fill_buffer call that followed a graph edit.
+inline thread_local uint64_t fr_trace_val_spins = 0, fr_trace_memo_spins = 0, fr_trace_probe_steps = 0;
 class FlatMap64 {
     struct Slot { uint64_t key1, val; };       // key1 = key + 1, 0 = empty (keys must not be ~0); one cache line per probe
     Slot *slots_ = nullptr;
@@ -187,6 +188,7 @@ public:
             if (cur == k + 1) {
                 uint64_t v;
                 while (!(v = __atomic_load_n(&slots_[i].val, __ATOMIC_ACQUIRE))) {
+                    ++fr_trace_val_spins;
 #if defined(__x86_64__)
                     __builtin_ia32_pause();
 #endif
@@ -194,6 +196,7 @@ public:
                 return v;
             }
             i = (i + 1) & mask_;
+            ++fr_trace_probe_steps;
         }
     }
     void concurrent_added(size_t n) { n_ += n; }
@@ -459,6 +462,8 @@ private:
     struct alignas(128) ParNext { uint32_t v = 0; char pad[124]; };
     ParNext par_next_s_;
     size_t par_input_claimed_ = 0, par_input_budget_ = 0;
+    uint32_t par_const_grant_ = 1024;                   // new constants a thread may make per draw from the pool below
+    alignas(128) int64_t par_const_pool_ = 0;           // what is left of the room the constants' table was sized for
     uint32_t par_push(FlatOp op, uint32_t a, uint32_t b, uint32_t depth, ParCounters &c);
     FlatMap64 cse_[2];   // OP_CONST: bits -> node id + 1; OP_INPUT: slot -> node id + 1
     FlatMap64 cse_bin_;  // (op << 60 | a << 30 | b) -> node id + 1   (ids < 2^30)
@@ -507,12 +512,16 @@ FlatGraph lower(const Mirror &m, uint32_t n_slots);
 }  // namespace fr
 #include <sys/mman.h>
 namespace fr {
+inline bool lowering_hugepages() {   // FR_LOWER_HUGEPAGES=0: leave the lowering's tables on ordinary pages
+    static const bool on = [] { const char *e = std::getenv("FR_LOWER_HUGEPAGES"); return !(e && e[0] == '0'); }();
+    return on;
+}
 inline FlatMap64::Slot *FlatMap64::alloc(size_t cap) {
     const size_t bytes = cap * sizeof(Slot);
     if (bytes >= HUGE_BYTES) {
         void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);   // zero pages, like calloc
         if (m == MAP_FAILED) throw std::bad_alloc();   // (dealloc() tells the two kinds apart by size alone)
-        (void)madvise(m, bytes, MADV_HUGEPAGE);
+        if (lowering_hugepages()) (void)madvise(m, bytes, MADV_HUGEPAGE);
         return (Slot *)m;
     }
     Slot *p = (Slot *)std::calloc(cap, sizeof(Slot));
@@ -528,7 +537,7 @@ template <class T>
 void VArray<T>::map_once() {
     void *m = mmap(nullptr, RESERVE_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (m == MAP_FAILED) return;
-    (void)madvise(m, RESERVE_BYTES, MADV_HUGEPAGE);   // pages are touched once, in order, by the million: fault them in 2 MiB at a time
+    if (lowering_hugepages()) (void)madvise(m, RESERVE_BYTES, MADV_HUGEPAGE);   // pages are touched once, in order, by the million: fault them in 2 MiB at a time
     p_ = (T *)m;
     cap_ = RESERVE_BYTES / sizeof(T);
     mapped_ = true;

@@ -11,7 +11,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from libfriendship_amd import hip_lib, synth  # noqa: E402
-from libfriendship_amd.capi import Renderer, f32_bits  # noqa: E402
+from libfriendship_amd.capi import Renderer, RendererLib, f32_bits  # noqa: E402
 
 
 def main():
@@ -22,13 +22,14 @@ def main():
     ap.add_argument("--tree", default="additive", choices=["additive", "effects"])
     ap.add_argument("--async-compile", action="store_true", help="the ABI's default: hipRTC on a worker thread (Python's default is sync)")
     ap.add_argument("--note-ons", type=int, default=3)
+    ap.add_argument("--lib", default=None, help="another build of the C ABI (the host-logic simulator of tests/sim_tools.py, with --frames 64: host costs only)")
     a = ap.parse_args()
     V, P, T = a.voices, a.partials, a.frames
     tree = synth.additive_tree(V, P) if a.tree == "additive" else synth.effects_tree(V, P)
     e = tree["edges"]
     amp = tree["params"]["amp"]
     rows = np.nonzero((e[:, 0] == synth.CONST_HANDLE) & (e[:, 3] == 0) & (e[:, 2] == f32_bits(amp[0, 100 % P])))[0]
-    with Renderer(hip_lib(), sync_compile=not a.async_compile) as r:
+    with Renderer(RendererLib(a.lib) if a.lib else hip_lib(), sync_compile=not a.async_compile) as r:
         t0 = time.perf_counter()
         synth.install(r, tree)
         t_install = time.perf_counter() - t0
