@@ -840,8 +840,10 @@ struct fr_renderer {
                << ",\"to_ring\":" << (g.to_ring ? "true" : "false") << ",\"to_exchange\":" << (g.to_ws ? "true" : "false")
                << ",\"param_bytes\":" << g.params.size() * sizeof(float) << "}";
         }
-        js << "],\"stage_programs\":" << (p.sp.progs.size() - p.sp.fused_count) << ",\"stage_instrs\":" << p.sp.instrs.size()
+        js << "],\"stage_programs\":" << (p.sp.progs.size() - p.sp.fused_count - p.sp.post_count) << ",\"stage_instrs\":" << p.sp.instrs.size()
            << ",\"fused_programs\":" << p.sp.fused_count << ",\"fused_max_frames\":" << p.sp.fused_max_frames << ",\"fused_stride\":" << p.sp.fused_stride
+           << ",\"feedback\":" << (p.sp.feedback ? "true" : "false") << ",\"feedback_loops\":" << fg.fb_target.size()
+           << ",\"fused_levels\":" << (p.sp.fused_level_first.empty() ? 0 : p.sp.fused_level_first.size() - 1) << ",\"copy_programs\":" << p.sp.post_count
            << ",\"stage_levels\":" << (p.sp.level_first.empty() ? 0 : p.sp.level_first.size() - 1)
            << ",\"stage_jit\":" << (p.stage_jit ? "true" : "false") << ",\"stage_shapes\":" << p.stage_shapes
            << ",\"rings\":" << p.sp.n_rings << ",\"max_lookback\":" << p.sp.lmax
@@ -873,8 +875,18 @@ struct fr_renderer {
         // Window of the staged part.  Contiguous with what the rings already hold: just this call's frames.
         // Otherwise (first call, seek, graph edit, larger call): rebuild the look-back from the input history.
         uint64_t w0 = idx;
+        // Feedback plans (stage.hpp StagedPlan::feedback): no window bounds a loop's look-back, so rings that are not current
+        // are brought up to date by replaying every frame from 0 in chunks -- the ring-bound banks and the fused programs over
+        // [c0, c0 + len), nothing written to the output -- before the call's own frames run in steady-state form.
+        constexpr uint64_t FB_CHUNK = 16384, FB_MAX_REPLAY = 1ull << 28;
+        const bool fb_replay = sp.feedback && !(plan.stage_valid && plan.stage_end == idx) && idx != 0;
+        if (sp.feedback) {
+            if (history_frames != 0) throw Error(FR_ERR_UNSUPPORTED, "feedback through Delay needs the full input history (fr_config.history_frames = 0)");
+            if (fb_replay && idx > FB_MAX_REPLAY)
+                throw Error(FR_ERR_UNSUPPORTED, "a feedback loop's state at frame " + std::to_string(idx) + " would take replaying more than 2^28 frames");
+        }
         if (sp.uses_rings()) {
-            uint64_t need = sp.lmax + n_times;
+            uint64_t need = sp.lmax + std::max<uint64_t>(n_times, fb_replay ? FB_CHUNK : 0);
             uint64_t cap = 1024;
             while (cap < need) cap <<= 1;
             if (cap > ring_cap) {
@@ -886,6 +898,7 @@ struct fr_renderer {
                 plan.stage_valid = false;
             }
             if (!(plan.stage_valid && plan.stage_end == idx)) w0 = idx > sp.lmax ? idx - sp.lmax : 0;
+            if (sp.feedback) w0 = idx;   // (the replay below has brought the rings to idx by the time this window runs)
         }
         const uint64_t w_len = idx + n_times - w0;
         // Split voices (partial-block sharding): every rank renders its sub-trees over the SAME window -- the look-back
@@ -1048,6 +1061,74 @@ struct fr_renderer {
             HIP_CHECK(launch_bank(a, st));
             sc.done();
         };
+        // Stage programs: the input table of a launch and the launch itself (a range of programs over a window of frames).
+        std::vector<DevInput> tab(sp.input_slots.size());
+        auto fill_tab = [&] {
+            for (size_t i = 0; i < tab.size(); ++i) tab[i] = dev_input(sp.input_slots[i]);
+            if (tab.size() > STAGE_INLINE_INPUTS) {   // rare: more input slots than fit in the kernel arguments
+                d_in_table_stage.ensure(tab.size() * sizeof(DevInput));
+                HIP_CHECK(hipMemcpyAsync(d_in_table_stage.p, tab.data(), tab.size() * sizeof(DevInput), hipMemcpyHostToDevice, st));
+                HIP_CHECK(hipStreamSynchronize(st));   // `tab` is a stack object
+            }
+        };
+        uint64_t launch_stride = 0;
+        auto launch_range = [&](uint32_t first, uint32_t count, uint64_t s0, uint64_t slen) {
+            for (uint32_t off = 0; off < count && plan.stage_jit; off += 65535u) {   // grid.y limit
+                JitStageArgs a{};
+                a.ptab = plan.d_ptab.as<uint32_t>();
+                a.progs = plan.d_jprogs.as<JitStageProg>() + first + off;
+                a.rings = d_rings.as<float>();
+                a.ring_mask = ring_cap ? ring_cap - 1 : 0;
+                a.inputs = reinterpret_cast<const JitInput *>(d_in_table_stage.as<DevInput>());
+                a.n_inputs = (uint32_t)tab.size();
+                for (size_t i = 0; i < tab.size() && i < STAGE_INLINE_INPUTS; ++i) a.inline_inputs[i] = JitInput{tab[i].data, tab[i].base, tab[i].len};
+                a.out = d_dst;
+                a.n_times = n_times;
+                a.idx = idx;
+                a.w0 = s0;
+                a.w_len = slen;
+                a.stride = launch_stride;
+                Scope sc(this, &t_stage, st);
+                HIP_CHECK(launch_jit_stage(*plan.stage_jit, a, std::min<uint32_t>(count - off, 65535u), st));
+                sc.done();
+            }
+            for (uint32_t off = 0; off < count && !plan.stage_jit; off += 65535u) {
+                StageArgs a{};
+                a.instrs = plan.d_instrs.as<StageInstr>();
+                a.progs = plan.d_progs.as<StageProg>() + first + off;
+                a.n_progs = std::min<uint32_t>(count - off, 65535u);
+                a.rings = d_rings.as<float>();
+                a.ring_mask = ring_cap ? ring_cap - 1 : 0;
+                a.inputs = d_in_table_stage.as<DevInput>();
+                a.n_inputs = (uint32_t)tab.size();
+                for (size_t i = 0; i < tab.size() && i < STAGE_INLINE_INPUTS; ++i) a.inline_inputs[i] = tab[i];
+                a.out = d_dst;
+                a.n_times = n_times;
+                a.idx = idx;
+                a.w0 = s0;
+                a.w_len = slen;
+                a.stride = launch_stride;
+                a.sparkle = mirror.sparkle ? 1u : 0u;
+                Scope sc(this, &t_stage, st);
+                HIP_CHECK(launch_stage(a, st));
+                sc.done();
+            }
+        };
+        auto launch_fused_levels = [&](uint64_t s0, uint64_t slen) {   // a feedback plan's fused form: a strided launch per level
+            launch_stride = sp.fused_stride;
+            for (size_t l = 0; l + 1 < sp.fused_level_first.size(); ++l)
+                launch_range(sp.fused_first + sp.fused_level_first[l], sp.fused_level_first[l + 1] - sp.fused_level_first[l], s0, slen);
+            launch_stride = 0;
+        };
+        if (fb_replay) {
+            fill_tab();
+            for (uint64_t c0 = 0; c0 < idx; c0 += FB_CHUNK) {
+                const uint64_t len = std::min<uint64_t>(FB_CHUNK, idx - c0);
+                for (BankStage &bs : plan.banks)
+                    if (bs.grp.to_ring) launch_bank_window(bs, c0, len, -1);
+                launch_fused_levels(c0, len);
+            }
+        }
         // The exchange window first, tile by tile, every tile's bank kernels on the call's stream; then the tiles' exchanges on
         // the exchange stream, each behind its tile's event: tile i's exchange runs under the bank kernels of tiles i + 1 ...
         // (also with a transport that blocks the host: the kernels are all enqueued before the first exchange starts).
@@ -1091,13 +1172,7 @@ struct fr_renderer {
         for (const Deferred &d : deferred)
             if (d.dst) throw Error(FR_ERR_DEVICE, "internal: an input row deferred to the bank launch was not appended");
         if (!sp.progs.empty()) {
-            std::vector<DevInput> tab(sp.input_slots.size());
-            for (size_t i = 0; i < tab.size(); ++i) tab[i] = dev_input(sp.input_slots[i]);
-            if (tab.size() > STAGE_INLINE_INPUTS) {   // rare: more input slots than fit in the kernel arguments
-                d_in_table_stage.ensure(tab.size() * sizeof(DevInput));
-                HIP_CHECK(hipMemcpyAsync(d_in_table_stage.p, tab.data(), tab.size() * sizeof(DevInput), hipMemcpyHostToDevice, st));
-                HIP_CHECK(hipStreamSynchronize(st));   // `tab` is a stack object
-            }
+            fill_tab();
             // Steady state: every delayed ring read of the fused form reaches at least fused_max_frames back, so the call
             // is cut into sub-windows of that length, one fused launch each, when that takes fewer launches than levels.
             const size_t n_levels = sp.level_first.size() - 1;
@@ -1111,50 +1186,10 @@ struct fr_renderer {
             const uint64_t strided_sub = sp.fused_stride ? (n_times - 1) / sp.fused_stride + 1 : 0;
             const bool strided = sp.fused_count != 0 && w0 == idx && plan.stage_valid && sp.fused_stride >= 256 && strided_sub >= 2 &&
                                  strided_sub <= 8 && fused_strided_ok;
-            uint64_t launch_stride = 0;
-            auto launch_range = [&](uint32_t first, uint32_t count, uint64_t s0, uint64_t slen) {
-                for (uint32_t off = 0; off < count && plan.stage_jit; off += 65535u) {   // grid.y limit
-                    JitStageArgs a{};
-                    a.ptab = plan.d_ptab.as<uint32_t>();
-                    a.progs = plan.d_jprogs.as<JitStageProg>() + first + off;
-                    a.rings = d_rings.as<float>();
-                    a.ring_mask = ring_cap ? ring_cap - 1 : 0;
-                    a.inputs = reinterpret_cast<const JitInput *>(d_in_table_stage.as<DevInput>());
-                    a.n_inputs = (uint32_t)tab.size();
-                    for (size_t i = 0; i < tab.size() && i < STAGE_INLINE_INPUTS; ++i) a.inline_inputs[i] = JitInput{tab[i].data, tab[i].base, tab[i].len};
-                    a.out = d_dst;
-                    a.n_times = n_times;
-                    a.idx = idx;
-                    a.w0 = s0;
-                    a.w_len = slen;
-                    a.stride = launch_stride;
-                    Scope sc(this, &t_stage, st);
-                    HIP_CHECK(launch_jit_stage(*plan.stage_jit, a, std::min<uint32_t>(count - off, 65535u), st));
-                    sc.done();
-                }
-                for (uint32_t off = 0; off < count && !plan.stage_jit; off += 65535u) {
-                    StageArgs a{};
-                    a.instrs = plan.d_instrs.as<StageInstr>();
-                    a.progs = plan.d_progs.as<StageProg>() + first + off;
-                    a.n_progs = std::min<uint32_t>(count - off, 65535u);
-                    a.rings = d_rings.as<float>();
-                    a.ring_mask = ring_cap ? ring_cap - 1 : 0;
-                    a.inputs = d_in_table_stage.as<DevInput>();
-                    a.n_inputs = (uint32_t)tab.size();
-                    for (size_t i = 0; i < tab.size() && i < STAGE_INLINE_INPUTS; ++i) a.inline_inputs[i] = tab[i];
-                    a.out = d_dst;
-                    a.n_times = n_times;
-                    a.idx = idx;
-                    a.w0 = s0;
-                    a.w_len = slen;
-                    a.stride = launch_stride;
-                    a.sparkle = mirror.sparkle ? 1u : 0u;
-                    Scope sc(this, &t_stage, st);
-                    HIP_CHECK(launch_stage(a, st));
-                    sc.done();
-                }
-            };
-            if (strided) {
+            if (sp.feedback) {
+                launch_fused_levels(idx, n_times);
+                launch_range(sp.post_first, sp.post_count, idx, n_times);
+            } else if (strided) {
                 launch_stride = sp.fused_stride;
                 launch_range(sp.fused_first, sp.fused_count, idx, n_times);
                 launch_stride = 0;

@@ -314,6 +314,12 @@ uint32_t FlatGraph::make(FlatOp op, uint32_t a, uint32_t b) {
     return id;
 }
 
+uint32_t FlatGraph::fbref() {
+    const uint32_t j = (uint32_t)fb_target.size();
+    fb_target.push_back(0);
+    return push(OP_FBREF, j, 0, 0);   // (never hash-consed: one per cut cycle)
+}
+
 // ---- concurrent construction -------------------------------------------------------------------------
 bool FlatGraph::par_begin(size_t max_new_nodes, size_t const_budget) {
     if (!nodes.mapped() || nodes.capacity() < nodes.size() + max_new_nodes + const_budget + 64) return false;
@@ -605,9 +611,12 @@ struct Lowering::Impl {
             const uint64_t k = key(ctx, n);
             add_reader(k, reader);
             if (uint64_t *mv = memo.find(k)) {
-                if (*mv == 1)
-                    throw Error(FR_ERR_CYCLE, "dependency cycle through node " + std::to_string(ref.from) +
-                                                  " (feedback is not evaluable by this engine)");
+                if (*mv == 1) {   // a dependency cycle: eval() cuts it at a Delay on the way round, if there is one
+                    cycle_at = Frame{ctx, n, 0, {0, 0}};
+                    cycle_handle = ref.from;
+                    need = cycle_at;
+                    return false;
+                }
                 if (*mv >= 2) {
                     out = (uint32_t)(*mv - 2);
                     return true;
@@ -629,10 +638,51 @@ struct Lowering::Impl {
         }
     }
 
+    // Feedback.  The reference evaluates a graph with a dependency cycle by recursion all the same (its cycle check never
+    // fires: routegraph.rs:218-237), and the recursion ends exactly when every trip round the cycle passes a Delay that
+    // moves time back: get_edge_value(t) -> Delay -> get_edge_value(t - d) ... -> 0 once t < d (reference.rs:197-216).
+    // When the walk below meets a node that is still being lowered, the cycle is CUT at the innermost Delay on the way round
+    // whose SOURCE operand is being resolved: that operand becomes an OP_FBREF leaf, the frames above the Delay are
+    // abandoned, and the source itself is lowered once the walk has come back down (`pending`), when everything it reaches
+    // is in the memo.  No such Delay: a cycle with no delay in it, which the reference would recurse into forever.
+    struct PendingTarget { uint32_t j; int ctx; EdgeRef source; };
+    std::vector<PendingTarget> pending;
+    Frame cycle_at{};            // set by resolve() when it returns false for a node that is in progress
+    uint32_t cycle_handle = 0;
+
+    // true: cut (the Delay's frame is now the top of the stack, its source resolved to an OP_FBREF)
+    bool cut_cycle(std::vector<Frame> &stack) {
+        size_t bottom = stack.size();
+        for (size_t i = stack.size(); i-- > 0;)
+            if (stack[i].ctx == cycle_at.ctx && stack[i].node == cycle_at.node) { bottom = i; break; }
+        if (bottom == stack.size()) return false;   // (in progress but not on this stack: cannot happen on one thread)
+        for (size_t i = stack.size(); i-- > bottom;) {
+            Frame &d = stack[i];
+            if (d.node->kind != FR_PRIM_DELAY || d.next != 0) continue;
+            {   // only a Delay that always moves time back can end the recursion: its amount a constant of >= 1 frames, read
+                // straight from the constant node (a Delay by 0 frames on the loop is a pass-through: try the next one out)
+                const EdgeRef amt = d.node->inbound.size() > 1 ? d.node->inbound[1] : EdgeRef{};
+                const MNode *src = (amt.present && amt.from != 0) ? find(d.ctx, amt.from) : nullptr;
+                if (!src || src->kind != FR_PRIM_F32CONSTANT || !(f32_from_bits(amt.from_slot) >= 1.0f)) continue;
+            }
+            for (size_t k = stack.size(); k-- > i + 1;) memo.get(key(stack[k].ctx, stack[k].node)) = 0;
+            stack.resize(i + 1);
+            Frame &dd = stack.back();
+            const uint32_t leaf = fg.fbref();
+            pending.push_back(PendingTarget{fg.nodes[leaf].a, dd.ctx, dd.node->inbound.size() == 0 ? EdgeRef{} : dd.node->inbound[0]});
+            dd.vals[0] = leaf;
+            dd.next = 1;
+            return true;
+        }
+        return false;
+    }
+
     uint32_t eval(int ctx0, EdgeRef root) {
         uint32_t result = 0;
         Frame need;
+        cycle_at.node = nullptr;
         if (resolve(ctx0, root, result, need, NOBODY)) return result;
+        if (cycle_at.node) throw Error(FR_ERR_CYCLE, "internal: an output row resolves to a node that is being lowered");
         std::vector<Frame> stack;
         stack.push_back(need);
         memo.get(key(need.ctx, need.node)) = 1;
@@ -644,13 +694,27 @@ struct Lowering::Impl {
                     EdgeRef ref = (size_t)f.next < n->inbound.size() ? n->inbound[f.next] : EdgeRef{};
                     uint32_t id;
                     Frame child;
+                    cycle_at.node = nullptr;
                     if (resolve(f.ctx, ref, id, child, key(f.ctx, n))) {
                         f.vals[f.next++] = id;
+                    } else if (cycle_at.node) {
+                        if (!cut_cycle(stack))
+                            throw Error(FR_ERR_CYCLE, "dependency cycle through node " + std::to_string(cycle_handle) +
+                                                          " with no Delay of a constant >= 1 frames on it (the reference would recurse forever)");
                     } else {
                         memo.get(key(child.ctx, child.node)) = 1;
                         stack.push_back(child);  // invalidates f; loop re-reads the top
                     }
                     continue;
+                }
+                if (f.node->kind == FR_PRIM_DELAY && fg.nodes[f.vals[0]].op == OP_FBREF) {
+                    // the Delay that cuts a cycle must move time back by at least one frame, every time (reference.rs:200-215:
+                    // NaN and negative amounts are 0 frames)
+                    const float d = fg.is_const(f.vals[1]) ? fg.const_val(f.vals[1]) : 0.0f;
+                    if (!fg.is_const(f.vals[1]) || !(d >= 1.0f))
+                        throw Error(FR_ERR_CYCLE, std::string("dependency cycle closed through a Delay whose amount is ") +
+                                                      (fg.is_const(f.vals[1]) ? "less than one frame" : "a signal") +
+                                                      ": only feedback through a constant Delay of >= 1 frames is evaluable");
                 }
                 uint32_t id = fg.make(op_of(f.node->kind), f.vals[0], f.vals[1]);
                 memo.get(key(f.ctx, f.node)) = (uint64_t)id + 2;
@@ -997,12 +1061,26 @@ struct Lowering::Impl {
         // big jobs -- a from-scratch lowering, or an edit that brought thousands of new nodes (a note-on) -- first lower the
         // sub-trees below the rows on several threads; the loop here then finds them in the memo
         if (allow_parallel) lower_parallel(mm, n_slots, full, full ? mm.nodes.size() : (journal ? journal->size() : 0));
-        for (uint32_t s = 0; s < n_slots; ++s) {
-            if (s < row_lo || s >= row_hi) { fg.outputs[s] = fg.konst(0); continue; }   // another rank's row
-            EdgeRef ref = s < mm.outputs.size() ? mm.outputs[s] : EdgeRef{};  // reference.rs:158-161
-            fg.outputs[s] = eval(0, ref);
+        pending.clear();
+        try {
+            for (uint32_t s = 0; s < n_slots; ++s) {
+                if (s < row_lo || s >= row_hi) { fg.outputs[s] = fg.konst(0); continue; }   // another rank's row
+                EdgeRef ref = s < mm.outputs.size() ? mm.outputs[s] : EdgeRef{};  // reference.rs:158-161
+                fg.outputs[s] = eval(0, ref);
+            }
+            while (!pending.empty()) {   // what the cut Delays read (may cut further cycles)
+                const PendingTarget p = pending.back();
+                pending.pop_back();
+                fg.fb_target[p.j] = eval(p.ctx, p.source);
+            }
+        } catch (...) {
+            if (!fg.fb_target.empty()) valid = false;   // half-cut cycles are in the memo: start over next time
+            throw;
         }
         if (full) { base_nodes = fg.nodes.size(); base_ctxs = ctxs.size(); base_cells = cells.size(); }
+        // (feedback graphs are re-lowered from scratch after an edit: an OP_FBREF leaf keeps its id while what it stands for
+        //  changes, which the matcher's and the planner's per-node memos would not see)
+        if (!fg.fb_target.empty()) valid = false;
         return fg;
     }
 };

@@ -411,6 +411,11 @@ enum FlatOp : uint32_t {
     OP_DIV = 5,
     OP_MOD = 6,
     OP_MIN = 7,
+    // Feedback (a dependency cycle closed through a Delay of a constant >= 1 frames, which the reference evaluates by plain
+    // recursion: reference.rs:197-216; routegraph.rs:218-237 never refuses the edge).  The lowered graph stays a DAG: the
+    // Delay on the cycle reads this leaf instead of its source, and FlatGraph::fb_target[a] names the node it stands for
+    // (lowered after the Delay, so with a higher id).  Only ever the source operand of an OP_DELAY.
+    OP_FBREF = 8,   // a = index into fb_target
 };
 
 struct FlatNode {
@@ -425,7 +430,13 @@ struct FlatGraph {
     bool sparkle = false;              // FR_SEMANTICS_SPARKLE (constant folding here, range analysis, kernels)
     bool has_input = false;
     uint64_t n_mirror_nodes_visited = 0;
+    std::vector<uint32_t> fb_target;   // OP_FBREF a -> the node whose value it is (empty: no feedback in the graph)
 
+    uint32_t fbref();                                    // a new OP_FBREF leaf; its target is set once the node is lowered
+    uint32_t src_of(uint32_t delay_source) const {       // the source operand of a Delay, seen through OP_FBREF
+        const FlatNode &s = nodes[delay_source];
+        return s.op == OP_FBREF ? fb_target[s.a] : delay_source;
+    }
     uint32_t konst(uint32_t bits);
     uint32_t input(uint32_t slot);
     uint32_t make(FlatOp op, uint32_t a, uint32_t b);   // hash-consing + constant folding

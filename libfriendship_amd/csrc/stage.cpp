@@ -68,7 +68,7 @@ struct Planner {
                 st.pop_back();
                 continue;
             }
-            if (x.op == OP_INPUT) { range_memo[n] = Range::unbounded(); st.pop_back(); continue; }
+            if (x.op == OP_INPUT || x.op == OP_FBREF) { range_memo[n] = Range::unbounded(); st.pop_back(); continue; }   // (feedback: no bound known)
             bool need_a = !range_memo.count(x.a);
             bool need_b = x.op != OP_DELAY && !range_memo.count(x.b);
             if (need_a) st.push_back(x.a);
@@ -104,7 +104,7 @@ struct Planner {
             uint32_t n = st.back();
             if (supported_memo.count(n)) { st.pop_back(); continue; }
             const FlatNode &x = g.nodes[n];
-            if (x.op == OP_CONST || x.op == OP_INPUT) { supported_memo[n] = 1; st.pop_back(); continue; }
+            if (x.op == OP_CONST || x.op == OP_INPUT || x.op == OP_FBREF) { supported_memo[n] = 1; st.pop_back(); continue; }   // (what an OP_FBREF stands for is checked by plan_stages)
             if (is_voice(n)) { supported_memo[n] = 1; st.pop_back(); continue; }   // a bank computes it: nothing below matters
             uint64_t fr_;
             const bool const_delay = x.op == OP_DELAY && delay_frames_ok(g, x, fr_);
@@ -173,8 +173,9 @@ struct Planner {
             const FlatNode &x = g.nodes[n];
             if (is_voice(n)) continue;
             if (x.op == OP_DELAY) {
-                if (!is_leaf(x.a)) cut.insert(x.a);
-                st.push_back(x.a);
+                const uint32_t src = g.src_of(x.a);   // (a feedback Delay reads a node lowered after it)
+                if (!is_leaf(src)) cut.insert(src);
+                st.push_back(src);
                 if (dyn_max.count(n)) st.push_back(x.b);   // the amount's own expression
             } else {
                 st.push_back(x.a);
@@ -324,14 +325,15 @@ bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unorde
         } else if (x.op == OP_DELAY) {
             uint64_t d;
             Planner::delay_frames_ok(g, x, d);
-            const FlatNode &src = g.nodes[x.a];
+            const uint32_t sa = g.src_of(x.a);
+            const FlatNode &src = g.nodes[sa];
             in.d_lo = (uint32_t)d;
             if (src.op == OP_CONST) { in.op = S_STEP; in.imm = src.a; }
             else if (src.op == OP_INPUT) { in.op = S_READ_INPUT; in.imm = dense(src.a); }
             else {
-                in.op = S_READ; in.buf = x.a; out.reads.push_back({x.a, d});
-                if (min_delay && !P.bank_of.count(x.a)) *min_delay = std::min(*min_delay, d);
-                if (gcd_delay && !P.bank_of.count(x.a)) { uint64_t a_ = *gcd_delay, b_ = d; while (b_) { const uint64_t r_ = a_ % b_; a_ = b_; b_ = r_; } *gcd_delay = a_; }
+                in.op = S_READ; in.buf = sa; out.reads.push_back({sa, d});
+                if (min_delay && !P.bank_of.count(sa)) *min_delay = std::min(*min_delay, d);
+                if (gcd_delay && !P.bank_of.count(sa)) { uint64_t a_ = *gcd_delay, b_ = d; while (b_) { const uint64_t r_ = a_ % b_; a_ = b_; b_ = r_; } *gcd_delay = a_; }
             }
         } else {
             switch (x.op) {
@@ -399,6 +401,32 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         if (root_is_bank || (allow_programs && P.supported(root))) staged_rows.push_back(row);
         else if (mine(row)) sp.pull_rows.push_back(row);   // (another rank's pull row: that rank evaluates all of it)
     }
+    // Feedback (graph.hpp OP_FBREF): what the cut Delays read must be stageable too, nothing the pull interpreter evaluates
+    // may reach one (its stack is sized by the graph's depth; a loop has none), and the plan has only its fused form --
+    // below -- run with threads striding by the gcd of the loop delays, each thread reading what it stored itself.
+    const bool feedback = !g.fb_target.empty();
+    if (feedback) {
+        if (partials) throw Error(FR_ERR_UNSUPPORTED, "feedback through Delay is not available under partial-block sharding");
+        for (uint32_t t : g.fb_target)
+            if (!allow_programs || !P.supported(t))
+                throw Error(FR_ERR_UNSUPPORTED, "a feedback loop needs the staged evaluator and contains something it cannot take "
+                                                "(a Delay by an unbounded signal or by 2^31 frames or more, or FR_MODE_PULL)");
+        std::unordered_set<uint32_t> seen;
+        std::vector<uint32_t> st;
+        for (uint32_t row : sp.pull_rows) st.push_back(g.outputs[row]);
+        while (!st.empty()) {
+            const uint32_t n = st.back();
+            st.pop_back();
+            if (!seen.insert(n).second) continue;
+            const FlatNode &x = g.nodes[n];
+            if (x.op == OP_FBREF)
+                throw Error(FR_ERR_UNSUPPORTED, "an output row that the pull interpreter must evaluate (signal-dependent Delay without a bound) "
+                                                "reaches a feedback loop");
+            if (x.op == OP_CONST || x.op == OP_INPUT) continue;
+            st.push_back(x.a);
+            st.push_back(x.b);
+        }
+    }
     for (uint32_t row : staged_rows) P.explore(g.outputs[row]);
     for (auto &kv : P.bank_of) P.cut.erase(kv.first);   // a Delay's source that is a voice is computed by the bank kernel
 
@@ -433,6 +461,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         else built.clear();                        // programs that inlined a node that is now a cut read its ring instead
         if (limit < 8) ok = false;
     }
+    if (!ok && feedback) throw Error(FR_ERR_UNSUPPORTED, "a feedback loop's expression exceeds the stage programs' budget");
     if (!ok) {
         // budget exceeded somewhere: keep only rows whose root is itself a bank (direct launches), pull the rest
         StagedPlan fb;
@@ -455,6 +484,14 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         for (auto &rd : kv.second.reads) needs_ring.insert(rd.first);
     for (auto &kv : rows_of)
         if (kv.second.size() > 1) needs_ring.insert(kv.first);
+    // program cut nodes another program uses at the SAME frame (the fused form computes them inline)
+    std::unordered_set<uint32_t> same_frame_used;
+    for (auto &kv : built)
+        for (auto &rd : kv.second.reads)
+            if ((rd.second == 0 || kv.second.dynamic_reads.count(rd.first)) && !P.bank_of.count(rd.first)) same_frame_used.insert(rd.first);
+    if (feedback)   // every row root lives in a ring: rows the fused programs do not write themselves (a node another program
+        for (auto &kv : rows_of)   // computes inline, a second row of the same node) are copied from it after the launch (post_first),
+            if (!P.bank_of.count(kv.first)) needs_ring.insert(kv.first);   // and programs merged into one hand their results over through it
 
     // look-back and levels, consumers before producers (descending node id)
     std::unordered_map<uint32_t, uint64_t> L;
@@ -491,6 +528,14 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
     for (uint32_t n : ring_nodes) {
         ring_of[n] = sp.n_rings++;
         sp.lmax = std::max(sp.lmax, L[n]);
+    }
+    if (feedback) {
+        // The look-back of a loop has no bound; the rings are never rebuilt from a window.  They are brought up to date by
+        // replaying the frames from 0 in order (engine.cpp execute()), so a ring only ever serves its readers' own delays.
+        sp.lmax = 0;
+        for (auto &kv : built)
+            for (auto &rd : kv.second.reads) sp.lmax = std::max(sp.lmax, rd.second);
+        sp.input_lookback_unbounded = true;
     }
 
     // Which ranks need each cut node / voice (partial-block sharding): everything reachable from the roots of a rank's
@@ -658,11 +703,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
 
     // Fused steady-state form: one launch.  Sinks = cut nodes no other program uses at the same frame; everything they
     // use at the same frame is computed inline.  Worth it only if the level form needs more than one launch.
-    if (max_level >= 2) {
-        std::unordered_set<uint32_t> same_frame_used;
-        for (auto &kv : built)
-            for (auto &rd : kv.second.reads)
-                if ((rd.second == 0 || kv.second.dynamic_reads.count(rd.first)) && !P.bank_of.count(rd.first)) same_frame_used.insert(rd.first);
+    if (max_level >= 2 || feedback) {
         uint64_t min_delay = ~0ull, gcd_delay = 0;
         bool fits = true;
         std::vector<StageInstr> finstrs;
@@ -686,11 +727,11 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
             auto ro = my_rows_of.find(m);
             bool sink = !same_frame_used.count(m);
             // a non-sink with output rows still needs those rows written: compute it as its own (fused) program too
-            if (!sink && ro == my_rows_of.end()) continue;
+            if (!sink && (feedback || ro == my_rows_of.end())) continue;   // (feedback: its rows are copied from its ring afterwards)
             ProgBuild pb;
             if (!build_program(g, P, m, dense_input, sp.input_slots, pb, true, &needs_ring, &min_delay, &gcd_delay)) { fits = false; break; }
             emit(pb, needs_ring.count(m) ? ring_of[m] : NO_RING, ro != my_rows_of.end() ? (int32_t)ro->second[0] : -1);
-            if (ro != my_rows_of.end())
+            if (ro != my_rows_of.end() && !feedback)
                 for (size_t i = 1; i < ro->second.size(); ++i) emit(pb, NO_RING, (int32_t)ro->second[i]);   // extra rows: recompute
         }
         for (auto &kv : my_rows_of) {   // bank roots that live in a ring: copy programs, as in the level form
@@ -703,7 +744,143 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
                 emit(pb, NO_RING, (int32_t)row);
             }
         }
-        if (fits && !fprogs.empty() && min_delay >= 64) {
+        if (feedback) {
+            if (!fits) throw Error(FR_ERR_UNSUPPORTED, "a feedback loop's expression exceeds the stage programs' budget");
+            if (min_delay == 0) throw Error(FR_ERR_UNSUPPORTED, "a feedback plan reads a program's ring through a signal-dependent Delay");
+            // Order between the fused programs: one that reads (delayed) a ring it does not store itself must run after every
+            // program that stores it -- a launch per level, each over the whole window.  Programs that depend on each other in a
+            // circle (a loop through Delays whose sources are not used at the same frame: x = in + Delay(y, 2), y = g *
+            // Delay(x, 3)) are MERGED into one program -- their instruction lists one after the other, every result but the last
+            // stored to its ring by an S_STORE -- so that one thread computes all of them frame by frame; what they read of
+            // each other is delayed by at least one frame, so the order inside a frame does not matter.
+            std::unordered_set<uint32_t> bank_rings;
+            for (auto &kv : P.bank_of) { auto it = ring_of.find(kv.first); if (it != ring_of.end()) bank_rings.insert(it->second); }
+            const size_t np = fprogs.size();
+            const size_t fbase = sp.instrs.size();
+            std::vector<std::unordered_set<uint32_t>> stores(np), foreign(np);
+            for (size_t i = 0; i < np; ++i) {
+                const StageProg &pg = fprogs[i];
+                if (pg.dst_ring != NO_RING) stores[i].insert(pg.dst_ring);
+                const size_t f0 = pg.first_instr - fbase;
+                for (uint32_t k = 0; k < pg.n_instr; ++k) if (finstrs[f0 + k].op == S_STORE) stores[i].insert(finstrs[f0 + k].buf);
+                for (uint32_t k = 0; k < pg.n_instr; ++k) {
+                    const StageInstr &in = finstrs[f0 + k];
+                    if (in.op == S_READ && !bank_rings.count(in.buf) && !stores[i].count(in.buf)) foreign[i].insert(in.buf);
+                }
+            }
+            std::vector<std::vector<uint32_t>> deps(np);
+            for (size_t i = 0; i < np; ++i)
+                for (size_t q = 0; q < np; ++q) {
+                    if (q == i) continue;
+                    for (uint32_t ring : foreign[i]) if (stores[q].count(ring)) { deps[i].push_back((uint32_t)q); break; }
+                }
+            // strongly connected components (Tarjan, iterative); components come out producers first
+            std::vector<int> index(np, -1), low(np, 0), comp(np, -1);
+            std::vector<bool> on_stack(np, false);
+            std::vector<uint32_t> tstack;
+            std::vector<std::vector<uint32_t>> comps;
+            int counter = 0;
+            for (size_t root = 0; root < np; ++root) {
+                if (index[root] >= 0) continue;
+                std::vector<std::pair<uint32_t, size_t>> work{{(uint32_t)root, 0}};
+                while (!work.empty()) {
+                    const uint32_t v = work.back().first;
+                    size_t &ei = work.back().second;
+                    if (ei == 0) { index[v] = low[v] = counter++; tstack.push_back(v); on_stack[v] = true; }
+                    if (ei < deps[v].size()) {
+                        const uint32_t w = deps[v][ei++];
+                        if (index[w] < 0) work.push_back({w, 0});
+                        else if (on_stack[w]) low[v] = std::min(low[v], index[w]);
+                        continue;
+                    }
+                    if (low[v] == index[v]) {
+                        comps.emplace_back();
+                        for (;;) {
+                            const uint32_t w = tstack.back();
+                            tstack.pop_back();
+                            on_stack[w] = false;
+                            comp[w] = (int)comps.size() - 1;
+                            comps.back().push_back(w);
+                            if (w == v) break;
+                        }
+                        std::sort(comps.back().begin(), comps.back().end());
+                    }
+                    work.pop_back();
+                    if (!work.empty()) low[work.back().first] = std::min(low[work.back().first], low[v]);
+                }
+            }
+            // one program per component; level = longest chain of components below it
+            struct Copy { uint32_t ring; int32_t row; };
+            std::vector<Copy> copies;
+            std::vector<StageInstr> minstrs;
+            std::vector<StageProg> mprogs;
+            std::vector<uint32_t> clevel(comps.size(), 0);
+            for (size_t c = 0; c < comps.size(); ++c) {   // (producers first: every dependency's level is final)
+                for (uint32_t i : comps[c])
+                    for (uint32_t q : deps[i])
+                        if (comp[q] != (int)c) clevel[c] = std::max(clevel[c], clevel[(size_t)comp[q]] + 1);
+                StageProg mp{};
+                mp.first_instr = (uint32_t)(fbase + minstrs.size());
+                for (size_t k = 0; k < comps[c].size(); ++k) {
+                    const StageProg &pg = fprogs[comps[c][k]];
+                    const size_t f0 = pg.first_instr - fbase;
+                    minstrs.insert(minstrs.end(), finstrs.begin() + (ptrdiff_t)f0, finstrs.begin() + (ptrdiff_t)(f0 + pg.n_instr));
+                    if (k == 0) mp.n_loads = pg.n_loads;
+                    if (k + 1 < comps[c].size()) {
+                        if (pg.dst_ring == NO_RING) throw Error(FR_ERR_UNSUPPORTED, "internal: a merged feedback program without a ring");
+                        StageInstr stx{};
+                        stx.op = S_STORE; stx.a = (uint8_t)pg.result_reg; stx.buf = pg.dst_ring;
+                        minstrs.push_back(stx);
+                        if (pg.out_row >= 0) copies.push_back(Copy{pg.dst_ring, pg.out_row});
+                    } else {
+                        mp.result_reg = pg.result_reg;
+                        mp.dst_ring = pg.dst_ring;
+                        mp.out_row = pg.out_row;
+                    }
+                }
+                mp.n_instr = (uint32_t)(fbase + minstrs.size()) - mp.first_instr;
+                if (mp.n_instr > MAX_PROG_INSTR) throw Error(FR_ERR_UNSUPPORTED, "a feedback loop's expression exceeds the stage programs' budget");
+                mprogs.push_back(mp);
+            }
+            std::vector<size_t> order(mprogs.size());
+            for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return clevel[x] < clevel[y]; });
+            sp.fused_first = (uint32_t)sp.progs.size();
+            sp.fused_count = (uint32_t)mprogs.size();
+            sp.fused_max_frames = 0;
+            sp.fused_stride = min_delay == ~0ull ? 0 : gcd_delay;
+            sp.feedback = true;
+            sp.instrs.insert(sp.instrs.end(), minstrs.begin(), minstrs.end());
+            sp.fused_level_first.clear();
+            for (size_t k = 0; k < order.size(); ++k) {
+                if (k == 0 || clevel[order[k]] != clevel[order[k - 1]]) sp.fused_level_first.push_back((uint32_t)k);
+                sp.progs.push_back(mprogs[order[k]]);
+            }
+            sp.fused_level_first.push_back((uint32_t)order.size());
+            // rows of nodes computed inline by another program (or stored mid-way by a merged one): ring -> row copies, one more
+            // launch over the call's frames
+            for (uint32_t m : cuts) {
+                if (!needed(m)) continue;
+                auto ro = my_rows_of.find(m);
+                if (ro == my_rows_of.end()) continue;
+                for (size_t i = same_frame_used.count(m) ? 0 : 1; i < ro->second.size(); ++i) copies.push_back(Copy{ring_of.at(m), (int32_t)ro->second[i]});
+            }
+            sp.post_first = (uint32_t)sp.progs.size();
+            for (const Copy &cp : copies) {
+                StageProg pg{};
+                pg.first_instr = (uint32_t)sp.instrs.size();
+                pg.n_instr = 1;
+                pg.result_reg = 0;
+                pg.dst_ring = NO_RING;
+                pg.out_row = cp.row;
+                pg.n_loads = 0;
+                StageInstr in{};
+                in.op = S_READ; in.buf = cp.ring; in.dst = 0;
+                sp.instrs.push_back(in);
+                sp.progs.push_back(pg);
+                ++sp.post_count;
+            }
+        } else if (fits && !fprogs.empty() && min_delay >= 64) {
             sp.fused_first = (uint32_t)sp.progs.size();
             sp.fused_count = (uint32_t)fprogs.size();
             // no delayed read of a program ring at all (min_delay untouched): a steady call of any length is one launch

@@ -74,6 +74,13 @@ struct StagedPlan {
     // gcd of the delays of the fused form's reads of program rings (0: there are none).  A call longer than
     // fused_max_frames is still ONE launch when its threads stride by this many frames (engine.cpp execute()).
     uint64_t fused_stride = 0;
+    // Feedback plans (graph.hpp OP_FBREF): the fused form is the only valid one and always runs strided; its programs are
+    // ordered in levels (progs[fused_first + fused_level_first[l] .. fused_first + fused_level_first[l + 1]), one launch each),
+    // and progs[post_first .. post_first + post_count) copy rings to output rows after them.  Rings are brought up to date by
+    // replaying the frames from 0 (there is no look-back window that bounds a loop).
+    bool feedback = false;
+    std::vector<uint32_t> fused_level_first;
+    uint32_t post_first = 0, post_count = 0;
     uint32_t n_rings = 0;
     uint64_t lmax = 0;                     // deepest look-back any ring must serve
     // How far back in the INPUT history the staged part can read when it computes frame t (ring look-backs + the delays

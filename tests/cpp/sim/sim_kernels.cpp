@@ -154,9 +154,14 @@ hipError_t launch_stage(const StageArgs &a, hipStream_t) {
         return read_input(a.n_inputs <= STAGE_INLINE_INPUTS ? a.inline_inputs[slot] : a.inputs[slot], t);
     };
     auto ring = [&](uint32_t buf, uint64_t t) -> float & { return a.rings[(size_t)buf * (a.ring_mask + 1) + (t & a.ring_mask)]; };
-    for (uint32_t pi = 0; pi < a.n_progs; ++pi) {
+    // Threads of a launch run in no particular order: the simulator takes the order LEAST favourable to a plan that silently
+    // relies on one -- programs last to first, threads last to first; only the frames of one strided thread are in order
+    // (kernels.hip stage_kernel) -- so a plan that needs the strided form, or an order between programs, fails here too.
+    const uint64_t span = a.stride ? a.stride : a.w_len;
+    for (uint32_t pi = a.n_progs; pi-- > 0;) {
         const StageProg &pg = a.progs[pi];
-        for (uint64_t wi = 0; wi < a.w_len; ++wi) {
+        for (uint64_t wi0 = std::min<uint64_t>(span, a.w_len); wi0-- > 0;)
+        for (uint64_t wi = wi0; wi < a.w_len; wi += span) {
             const uint64_t t = a.w0 + wi;
             float tmp[STAGE_REGS] = {0};
             for (uint32_t i = 0; i < pg.n_instr; ++i) {

@@ -175,3 +175,49 @@ def random_inputs(rng, n_inputs, n_times, kind="mixed"):
         else:
             rows.append(np.float32(rng.normal(size=L) * 4).astype(np.float32))
     return rows
+
+
+def random_feedback_graph(seed, n_frames=16, n_nodes=14, n_inputs=2, n_outputs=3, budget=2e5):
+    """A random graph of primitives in which one Delay (constant amount 1..6) has been re-pointed at a node that depends on it:
+    a feedback loop as the reference evaluates it (reference.rs:197-216).  The oracle's recursion costs (paths round the loop)
+    ** (frames / delay) per sample, so candidates beyond `budget` are passed over.  Returns (steps, n_outputs, delay) or None."""
+    rng = np.random.default_rng(seed + 77000)
+    steps, n_out = random_graph(seed + 77000, n_nodes=n_nodes, n_inputs=n_inputs, n_outputs=n_outputs, signal_delays=False, composites=False, max_delay=7)
+    kind, inbound = {}, {}
+    for s in steps:
+        if s[0] == "node":
+            kind[s[1]] = PRIMITIVES[s[2].kind]
+        else:
+            inbound.setdefault(s[2], {})[s[4]] = s
+    delays = []
+    for h, k in kind.items():
+        amt = inbound.get(h, {}).get(1)
+        if k == "Delay" and amt is not None and amt[1] == 1:
+            d = float(np.array([amt[3]], dtype=np.uint32).view(np.float32)[0])
+            if 1.0 <= d <= 6.0:
+                delays.append((h, int(d)))
+    rng.shuffle(delays)
+
+    def paths(frm, to, memo):   # operand paths frm -> ... -> to (edges run from lower to higher handles)
+        if frm == to:
+            return 1
+        if frm < to or frm in (0, 1):
+            return 0
+        if frm not in memo:
+            memo[frm] = sum(paths(e[1], to, memo) for e in inbound.get(frm, {}).values())
+        return memo[frm]
+
+    for h, d in delays:
+        later = [x for x in kind if x >= h and x != 1]
+        rng.shuffle(later)
+        for src in later:
+            p = paths(src, h, {})
+            if p == 0 or float(p) ** -(-n_frames // d) > budget:
+                continue
+            out = [s for s in steps if not (s[0] == "edge" and s[2] == h and s[4] == 0)]
+            out.append(("edge", src, h, 0, 0))
+            # the loop must be audible: some output depends on the Delay
+            if not any(s[0] == "edge" and s[2] == 0 and paths(s[1], h, {}) for s in out):
+                continue
+            return out, n_out, d
+    return None

@@ -8,7 +8,7 @@ import oracle_tools
 import randgraph
 from kat_replay import same_bits
 from libfriendship_amd import synth
-from libfriendship_amd.capi import (FR_ERR_CYCLE, FR_ERR_INPUT_HISTORY, FR_ERR_INPUT_TOO_LONG, FR_ERR_NO_SUCH_NODE, Effect,
+from libfriendship_amd.capi import (FR_ERR_CYCLE, FR_ERR_INPUT_HISTORY, FR_ERR_INPUT_TOO_LONG, FR_ERR_NO_SUCH_NODE, FR_ERR_UNSUPPORTED, Effect,
                                     RenderError, Renderer, f32_bits)
 
 pytestmark = pytest.mark.gpu
@@ -1756,3 +1756,176 @@ def test_block_streaming_short_rows_and_buffer_checks(hip_lib, oracle_lib):
         with pytest.raises(ValueError):
             hip.stream_block(9024, synth.time_ramp(9024, 9032), out=np.empty((V, 9), np.float32))
         hip.stream_end()
+
+
+# ---- feedback through Delay (the reference as written: routegraph.rs:218-237 never refuses the edge, reference.rs:197-216
+# ---- evaluates the loop by recursion, which ends because every trip round passes a Delay of >= 1 frames) -----------------------
+def _fb_nodes(rs, nodes, edges, n_out_edges):
+    """nodes: {handle: kind}; edges: (from, to, from_slot_or_const_bits, to_slot) with from == 'c' for the constant node (handle 1)."""
+    for r in rs:
+        r.on_add_node(1, "F32Constant")
+        for h, kind in nodes.items():
+            r.on_add_node(h, kind)
+        for frm, to, fs, ts in edges + n_out_edges:
+            r.on_add_edge(1 if frm == "c" else frm, to, f32_bits(fs) if frm == "c" else fs, ts)
+
+
+def _fb_calls(hip, ref, n_out, seq, n_in=1, seed=0):
+    rng = np.random.default_rng(seed)
+    for idx, n in seq:
+        rows = [rng.normal(size=n).astype(np.float32) for _ in range(n_in)]
+        got, exp = hip.fill_buffer(n_out, idx, idx + n, rows), ref.fill_buffer(n_out, idx, idx + n, rows)
+        assert same_bits(got, exp), f"call at {idx} (+{n}): " + first_diff(got, exp)
+
+
+@pytest.mark.parametrize("d", [1, 3, 64, 100])
+def test_feedback_echo(hip_lib, oracle_lib, d):
+    """x = in0 + 0.5 * Delay(x, d): contiguous calls, a call longer than the delay, a seek forward (the loop's state is rebuilt
+    by replaying the frames from 0), an edit of the gain between calls (all of history is heard through the new gain), a seek
+    back.  Bit-exact against the oracle's recursion."""
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        _fb_nodes((hip, ref), {2: "Sum2", 3: "Delay", 4: "Multiply"},
+                  [(0, 2, 0, 0), (4, 2, 0, 1), (2, 3, 0, 0), ("c", 3, float(d), 1), (3, 4, 0, 0), ("c", 4, 0.5, 1)], [(2, 0, 0, 0)])
+        _fb_calls(hip, ref, 1, [(0, 50), (50, 70), (120, 200), (1000, 64)], seed=d)
+        plan = hip.plan()
+        assert plan["feedback"] and plan["feedback_loops"] == 1 and plan["fused_stride"] == d and plan["pull_rows"] == 0, plan
+        for r in (hip, ref):
+            r.on_del_edge(1, 4, f32_bits(0.5), 1)
+            r.on_add_edge(1, 4, f32_bits(-0.25), 1)
+        _fb_calls(hip, ref, 1, [(1064, 64), (1128, 8), (10, 40)], seed=d + 1)
+
+
+def test_feedback_loop_with_rows_inside_and_a_tap_behind(hip_lib, oracle_lib):
+    """m = x * g, x = in0 + Delay(m, 5): the Delay's source is not the row's root.  Rows: x (computed inline by m's program:
+    copied from its ring after the launch), m, and Delay(x, 2) + in1 (another program reading x's ring: a later level)."""
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        _fb_nodes((hip, ref), {2: "Sum2", 3: "Delay", 4: "Multiply", 5: "Delay", 6: "Sum2"},
+                  [(0, 2, 0, 0), (3, 2, 0, 1), (4, 3, 0, 0), ("c", 3, 5.0, 1), (2, 4, 0, 0), ("c", 4, 0.75, 1),
+                   (2, 5, 0, 0), ("c", 5, 2.0, 1), (5, 6, 0, 0), (0, 6, 1, 1)],
+                  [(2, 0, 0, 0), (4, 0, 0, 1), (6, 0, 0, 2)])
+        _fb_calls(hip, ref, 3, [(0, 33), (33, 64), (97, 3), (400, 50), (450, 50)], n_in=2, seed=5)
+        plan = hip.plan()
+        assert plan["feedback"] and plan["copy_programs"] >= 1 and plan["fused_levels"] == 2, plan
+
+
+def test_feedback_two_taps_and_nested_loops(hip_lib, oracle_lib):
+    """Row 0: x = in0 + 0.5 Delay(x, 6) + 0.25 Delay(x, 9) (threads stride by gcd 3).  Row 1: y = x2 + 0.3 Delay(y, 4) over an
+    inner loop x2 = in0 + 0.5 Delay(x2, 2)."""
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        _fb_nodes((hip, ref), {2: "Sum2", 3: "Sum2", 4: "Delay", 5: "Multiply", 6: "Delay", 7: "Multiply",
+                               12: "Sum2", 13: "Delay", 14: "Multiply", 15: "Sum2", 16: "Delay", 17: "Multiply"},
+                  [(0, 2, 0, 0), (3, 2, 0, 1), (5, 3, 0, 0), (7, 3, 0, 1), (2, 4, 0, 0), ("c", 4, 6.0, 1), (4, 5, 0, 0), ("c", 5, 0.5, 1),
+                   (2, 6, 0, 0), ("c", 6, 9.0, 1), (6, 7, 0, 0), ("c", 7, 0.25, 1),
+                   (0, 12, 0, 0), (14, 12, 0, 1), (12, 13, 0, 0), ("c", 13, 2.0, 1), (13, 14, 0, 0), ("c", 14, 0.5, 1),
+                   (12, 15, 0, 0), (17, 15, 0, 1), (15, 16, 0, 0), ("c", 16, 4.0, 1), (16, 17, 0, 0), ("c", 17, 0.3, 1)],
+                  [(2, 0, 0, 0), (15, 0, 0, 1)])
+        _fb_calls(hip, ref, 2, [(0, 20), (20, 30), (50, 14), (40, 24)], seed=7)   # (the two-tap recursion branches: short)
+        plan = hip.plan()
+        assert plan["feedback"] and plan["feedback_loops"] == 4 and plan["fused_stride"] == 1, plan
+
+
+def test_feedback_loop_through_two_delayed_nodes_is_one_program(hip_lib, oracle_lib):
+    """x = in0 + Delay(y, 2), y = 0.9 * Delay(x, 3): neither node uses the other at the same frame, so each would be its own
+    program reading the other's ring -- they are merged into one so that a thread computes both, frame by frame."""
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        _fb_nodes((hip, ref), {2: "Sum2", 3: "Delay", 4: "Multiply", 5: "Delay"},
+                  [(0, 2, 0, 0), (3, 2, 0, 1), (4, 3, 0, 0), ("c", 3, 2.0, 1), (5, 4, 0, 0), ("c", 4, 0.9, 1), (2, 5, 0, 0), ("c", 5, 3.0, 1)],
+                  [(2, 0, 0, 0), (4, 0, 0, 1)])
+        _fb_calls(hip, ref, 2, [(0, 40), (40, 100), (300, 30)], seed=9)
+        plan = hip.plan()
+        assert plan["feedback"] and plan["fused_programs"] == 1 and plan["copy_programs"] == 1, plan
+
+
+def test_feedback_around_a_bank_voice(hip_lib, oracle_lib):
+    """An additive voice (rendered by the bank kernel into a ring) feeding a comb filter: x = voice + 0.6 * Delay(x, 7); the
+    replay after a seek re-renders the voice's ring chunk by chunk."""
+    g = synth.GraphArrays()
+    p = synth.voice_params(1, 64, seed=11)
+    voice = synth.sum_tree(g, synth.partial_leaves(g, p["w"], p["amp"]).reshape(1, 64))
+    x = g.nodes(synth.K_SUM2, 1)
+    d = g.binop(synth.K_DELAY, x, synth.C(np.float32(7.0)), 1)
+    m = g.binop(synth.K_MUL, d, synth.C(np.float32(0.6)), 1)
+    g.edge(voice, x, 0, 0)
+    g.edge(m, x, 0, 1)
+    g.edge(x, 0, 0, 0)
+    tree = g.finish(1)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        for idx, n in [(0, 48), (48, 80), (128, 16), (500, 32)]:
+            t = synth.time_ramp(idx, idx + n)
+            got, exp = hip.fill_buffer(1, idx, idx + n, [t]), ref.fill_buffer(1, idx, idx + n, [t])
+            assert same_bits(got, exp), f"call at {idx}: " + first_diff(got, exp)
+        plan = hip.plan()
+        assert plan["feedback"] and len(plan["banks"]) == 1 and plan["banks"][0]["to_ring"], plan
+
+
+def test_feedback_that_cannot_be_evaluated_is_refused(hip_lib):
+    """FR_ERR_CYCLE only where the reference's recursion would never end: a cycle with no Delay on it, with a Delay of less
+    than one frame, of a signal amount, or entered through a Delay's AMOUNT.  FR_ERR_UNSUPPORTED where it would end but this
+    engine has no evaluator for it: FR_MODE_PULL, a bounded input history."""
+    def loop(r, amount_edges):
+        r.on_add_node(1, "F32Constant")
+        r.on_add_node(2, "Sum2")
+        r.on_add_node(3, "Delay")
+        r.on_add_edge(0, 2, 0, 0)
+        r.on_add_edge(3, 2, 0, 1)
+        r.on_add_edge(2, 3, 0, 0)
+        for e in amount_edges:
+            r.on_add_edge(*e)
+        r.on_add_edge(2, 0, 0, 0)
+
+    for amount in ([(1, 3, f32_bits(0.5), 1)], [(1, 3, f32_bits(-3.0), 1)], [(1, 3, f32_bits(float("nan")), 1)], [], [(0, 3, 1, 1)]):
+        with Renderer(hip_lib) as r:
+            loop(r, amount)
+            with pytest.raises(RenderError) as ei:
+                r.fill_buffer(1, 0, 8, [np.ones(8, np.float32), np.full(8, 2.0, np.float32)])
+            assert ei.value.status == FR_ERR_CYCLE, amount
+    with Renderer(hip_lib) as r:   # the cycle runs through the Delay's amount, its source is acyclic
+        r.on_add_node(1, "F32Constant")
+        r.on_add_node(2, "Sum2")
+        r.on_add_node(3, "Delay")
+        r.on_add_edge(0, 2, 0, 0)
+        r.on_add_edge(3, 2, 0, 1)
+        r.on_add_edge(0, 3, 0, 0)
+        r.on_add_edge(2, 3, 0, 1)
+        r.on_add_edge(2, 0, 0, 0)
+        with pytest.raises(RenderError) as ei:
+            r.fill_buffer(1, 0, 8, [np.ones(8, np.float32)])
+        assert ei.value.status == FR_ERR_CYCLE
+    for kw in ({"mode": "pull"}, {"history_frames": 100}):
+        with Renderer(hip_lib, **kw) as r:
+            loop(r, [(1, 3, f32_bits(4.0), 1)])
+            with pytest.raises(RenderError) as ei:
+                r.fill_buffer(1, 0, 8, [np.ones(8, np.float32)])
+            assert ei.value.status == FR_ERR_UNSUPPORTED, kw
+
+
+@pytest.mark.parametrize("seed0", [0, 40])
+def test_random_feedback_graphs(hip_lib, oracle_lib, seed0):
+    """Random graphs of the seven primitives with one Delay re-pointed at a node that depends on it (randgraph.py), two
+    contiguous calls and an edit-free seek back, against the oracle.  Graphs this engine has no evaluator for (the loop
+    reaches a row the pull interpreter must take) are passed over -- and counted."""
+    done = unsupported = 0
+    for seed in range(seed0, seed0 + 40):
+        made = randgraph.random_feedback_graph(seed)
+        if made is None:
+            continue
+        steps, n_out, d = made
+        with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+            randgraph.install_steps(hip, steps)
+            randgraph.install_steps(ref, steps)
+            rng = np.random.default_rng(seed)
+            try:
+                for idx, n in [(0, 9), (9, 7), (3, 5)]:
+                    rows = [rng.normal(size=n).astype(np.float32) * 3, rng.integers(-2, 6, size=n).astype(np.float32)]
+                    got = hip.fill_buffer(n_out, idx, idx + n, rows)
+                    exp = ref.fill_buffer(n_out, idx, idx + n, rows)
+                    assert same_bits(got, exp), f"seed {seed} (delay {d}) call at {idx}: " + first_diff(got, exp)
+            except RenderError as e:
+                assert e.status == FR_ERR_UNSUPPORTED, (seed, e)
+                unsupported += 1
+                continue
+            assert hip.plan()["feedback"], seed
+            done += 1
+    assert done >= 15 and unsupported <= done // 2, (done, unsupported)

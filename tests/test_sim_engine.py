@@ -460,3 +460,35 @@ def test_block_streaming_is_refused_where_no_launch_can_stay_resident(sim):
         with pytest.raises(RenderError):
             r.stream_block(0, synth.time_ramp(0, 8))
         assert r.fill_buffer(2, 0, 8, [synth.time_ramp(0, 8)]).shape == (2, 8)
+
+
+# ---- feedback through Delay: the same cases as on the device (test_hip_parity.py), on the host-logic simulator, whose stage
+# ---- launches run threads and programs in the LEAST favourable order (sim_kernels.cpp launch_stage) ------------------------
+@pytest.mark.parametrize("d", [1, 3, 64, 100])
+def test_feedback_echo(sim, oracle_lib, d):
+    G.test_feedback_echo(sim, oracle_lib, d)
+
+
+def test_feedback_loop_with_rows_inside_and_a_tap_behind(sim, oracle_lib):
+    G.test_feedback_loop_with_rows_inside_and_a_tap_behind(sim, oracle_lib)
+
+
+def test_feedback_two_taps_and_nested_loops(sim, oracle_lib):
+    G.test_feedback_two_taps_and_nested_loops(sim, oracle_lib)
+
+
+def test_feedback_loop_through_two_delayed_nodes_is_one_program(sim, oracle_lib):
+    G.test_feedback_loop_through_two_delayed_nodes_is_one_program(sim, oracle_lib)
+
+
+def test_feedback_around_a_bank_voice(sim, oracle_lib):
+    G.test_feedback_around_a_bank_voice(sim, oracle_lib)
+
+
+def test_feedback_that_cannot_be_evaluated_is_refused(sim):
+    G.test_feedback_that_cannot_be_evaluated_is_refused(sim)
+
+
+@pytest.mark.parametrize("seed0", [0, 40])
+def test_random_feedback_graphs(sim, oracle_lib, seed0):
+    G.test_random_feedback_graphs(sim, oracle_lib, seed0)
