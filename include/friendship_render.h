@@ -55,8 +55,15 @@ enum {
                                       (reference.rs:131,145,186 unwrap/expect/index panics)        */
     FR_ERR_BAD_SLOT = 5,           /* non-constant primitive read through from_slot != 0
                                       (reference.rs:199,223,230,237,244,251 asserts)               */
-    FR_ERR_CYCLE = 6,              /* dependency cycle reachable from a rendered output with no
-                                      way to terminate (the reference would recurse forever)      */
+    FR_ERR_CYCLE = 6,              /* dependency cycle reachable from a rendered output on which no
+                                      Delay of a constant >= 1 frames lies: the reference's recursion
+                                      (reference.rs:197-216) would never end.  A cycle closed through
+                                      such a Delay -- feedback -- IS rendered, as the reference as
+                                      written renders it (routegraph.rs:218-237 never refuses the
+                                      edge); FR_ERR_UNSUPPORTED where this engine has no evaluator for
+                                      it: FR_MODE_PULL, history_frames != 0, FR_SHARD_PARTIALS, a loop
+                                      reached by a row left to the pull interpreter, a seek of more
+                                      than 2^28 frames (a loop's state is rebuilt by replay from 0)  */
     FR_ERR_DEVICE = 7,             /* HIP runtime failure; see fr_last_error                       */
     FR_ERR_NO_DEVICE = 8,          /* no gfx950 device / HIP code object unusable                  */
     FR_ERR_OUT_OF_MEMORY = 9,

@@ -230,6 +230,17 @@ class RouteGraph {
 public:
     RouteGraph() { nodes_[NodeHandle::toplevel()] = Node{}; }
 
+    // What add_edge does about an edge that closes a dependency cycle.
+    //   Documented (default): WouldCycle, the behaviour routegraph.rs documents (its Error::WouldCycle, its tests' intent).
+    //   AsWritten: the edge is accepted, as the reference's code does -- `is_edge_reachable` (routegraph.rs:218-237) has no
+    //     base case that returns true, so its WouldCycle never fires.  RefRenderer then evaluates the loop by recursion
+    //     (reference.rs:197-216), which ends iff every trip round passes a Delay of >= 1 frames; this engine renders the
+    //     same samples for loops closed through a constant Delay and answers FR_ERR_CYCLE at fill_buffer where the
+    //     reference would recurse forever (feedback).
+    enum class CyclePolicy { Documented, AsWritten };
+    void set_cycle_policy(CyclePolicy p) { cycle_policy_ = p; }
+    CyclePolicy cycle_policy() const { return cycle_policy_; }
+
     std::vector<std::pair<NodeHandle, NodeData>> iter_nodes() const {
         std::vector<std::pair<NodeHandle, NodeData>> v;
         for (auto &kv : nodes_) if (kv.second.node_data) v.emplace_back(kv.first, kv.second.node_data);
@@ -282,6 +293,7 @@ public:
     AdjList to_adjlist() const;
 
 private:
+    CyclePolicy cycle_policy_ = CyclePolicy::Documented;
     // Is there a directed path from node `at`, entered through input slot `at_slot`, to node `target`
     // arriving so that it drives target's output slot `target_out`?  This is what
     // `is_edge_reachable(&edge, &edge)` (routegraph.rs:218-237) is documented to decide.  NOTE: the
@@ -545,7 +557,7 @@ inline void RouteGraph::add_edge(const Edge &edge) {
     if (from == nodes_.end()) throw Error(ErrorKind::NoSuchNode);
     if (from->second.node_data && !from->second.node_data->meta().is_valid_output(edge.from_slot()))
         throw Error(ErrorKind::NoSuchSlot);
-    if (!edge.to_full().is_toplevel() && !edge.from_full().is_toplevel()) {
+    if (cycle_policy_ == CyclePolicy::Documented && !edge.to_full().is_toplevel() && !edge.from_full().is_toplevel()) {
         std::set<std::pair<uint32_t, uint32_t>> seen;
         if (reaches(edge.to_full(), edge.to_slot(), edge.from_full(), edge.from_slot(), seen))
             throw Error(ErrorKind::WouldCycle);
@@ -929,6 +941,10 @@ class Dispatch {
 
 public:
     Dispatch(R renderer, C client) : renderer_(std::move(renderer)), client_(std::move(client)) {}
+    // "reference as written": AddEdge accepts edges that close a cycle (RouteGraph::CyclePolicy); default: WouldCycle
+    void set_reference_as_written(bool on) {
+        routegraph_.set_cycle_policy(on ? routing::RouteGraph::CyclePolicy::AsWritten : routing::RouteGraph::CyclePolicy::Documented);
+    }
     R &renderer() { return renderer_; }
     C &client() { return client_; }
     resman::ResMan &resman() { return resman_; }

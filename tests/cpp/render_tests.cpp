@@ -446,6 +446,44 @@ static void routegraph_validation() {
 
 // client/chanclient.rs: MpscClient forwards callbacks over a channel that another thread can drain; QueryMeta/QueryId
 // reach the client (dispatch.rs:132-145); messages carry the reference's OSC addresses.
+// Feedback with the host mirror switched to "the reference as written": AddEdge accepts the edge that closes the loop
+// (routegraph.rs:218-237 never refuses it) and the renderer evaluates x = 1 + 0.5 * Delay(x, 2) as RefRenderer's recursion
+// would (reference.rs:197-216): 1, 1, 1.5, 1.5, 1.75, 1.75 ...; a loop with no Delay on it is refused at RenderRange.
+static void feedback_reference_as_written() {
+    auto [dispatch, rx] = test_setup();
+    auto c = NodeHandle::make(1), x = NodeHandle::make(2), d = NodeHandle::make(3), m = NodeHandle::make(4);
+    dispatch.dispatch(OscRouteGraph::AddNode{c, const_id()});
+    dispatch.dispatch(OscRouteGraph::AddNode{x, sum2_id()});
+    dispatch.dispatch(OscRouteGraph::AddNode{d, delay_id()});
+    dispatch.dispatch(OscRouteGraph::AddNode{m, mult_id()});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(c, x, EdgeWeight::make(f32_to_bits(1.f), 0))});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(m, x, EdgeWeight::make(0, 1))});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(d, m, EdgeWeight::make(0, 0))});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(c, m, EdgeWeight::make(f32_to_bits(0.5f), 1))});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(c, d, EdgeWeight::make(f32_to_bits(2.f), 1))});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::new_to_null(x, EdgeWeight::make(0, 0))});
+    expect_rg_error(routegraph::ErrorKind::WouldCycle, [&] {   // the documented behaviour is the default
+        dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(x, d, EdgeWeight::make(0, 0))});
+    });
+    dispatch.set_reference_as_written(true);
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(x, d, EdgeWeight::make(0, 0))});
+    dispatch.dispatch(render_range(0, 6, 1));
+    ASSERT_EQ_ARR(recv(rx), array({1.f, 1.f, 1.5f, 1.5f, 1.75f, 1.75f}));
+    dispatch.dispatch(render_range(6, 10, 1));
+    ASSERT_EQ_ARR(recv(rx), array({1.875f, 1.875f, 1.9375f, 1.9375f}));
+    // a second loop with no Delay on it: accepted as an edge, refused when it is rendered (the reference would overflow its
+    // stack -- and so would the oracle, which restates it: not run there)
+    const char *lib = std::getenv("FRIENDSHIP_RENDERER_LIB");
+    if (lib && std::string(lib).find("fr_oracle") != std::string::npos) return;
+    auto s1 = NodeHandle::make(5);
+    dispatch.dispatch(OscRouteGraph::AddNode{s1, sum2_id()});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::make(s1, s1, EdgeWeight::make(0, 0))});
+    dispatch.dispatch(OscRouteGraph::AddEdge{Edge::new_to_null(s1, EdgeWeight::make(0, 1))});
+    bool refused = false;
+    try { dispatch.dispatch(render_range(10, 12, 2)); } catch (const std::exception &) { refused = true; }
+    if (!refused) throw std::runtime_error("a delay-free loop rendered");
+}
+
 static void mpsc_client_and_queries() {
     const char *lib = std::getenv("FRIENDSHIP_RENDERER_LIB");
     auto [client, rx] = friendship::client::MpscClient::make();
@@ -510,7 +548,8 @@ int main(int argc, char **argv) {
         {"render_mod", render_mod}, {"render_min", render_min},
         {"ext_render_passthrough", ext_render_passthrough}, {"ext_render_delay", ext_render_delay},
         {"load_multby2", load_multby2}, {"shipped_effect_files", shipped_effect_files}, {"block_streaming", block_streaming}, {"effect_desc_json", effect_desc_json},
-        {"routegraph_validation", routegraph_validation}, {"mpsc_client_and_queries", mpsc_client_and_queries}};
+        {"routegraph_validation", routegraph_validation}, {"feedback_reference_as_written", feedback_reference_as_written},
+        {"mpsc_client_and_queries", mpsc_client_and_queries}};
     int failed = 0, ran = 0;
     for (auto &t : tests) {
         if (argc > 1 && std::string(argv[1]) != t.first) continue;
