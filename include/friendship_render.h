@@ -285,6 +285,25 @@ fr_status fr_stream_begin(fr_renderer *r, uint32_t n_slots);
 fr_status fr_stream_block(fr_renderer *r, float *out, uint64_t n_times, uint64_t idx, const float *row, uint64_t row_len);
 fr_status fr_stream_end(fr_renderer *r);
 
+/* ---- control-rate tracks ---------------------------------------------------------------------------------------------
+ * Renderer::fill_buffer takes its inputs as an Array2 -- one row per input slot, one column per frame rendered
+ * (reference.rs:66-74) -- and every row is appended to that slot's history (:68-74) because a Delay may read it later.
+ * Per-partial frequency / amplitude envelopes are such rows too: 2 x 4096 x 64 of them at BASELINE config C, 8 bytes per
+ * partial-frame, which no history can afford to keep and nothing ever reads back.  fr_set_track_inputs(first_slot) declares
+ * the input slots >= first_slot to be TRACKS: their rows must span exactly the call's frames, are NOT stored, and are read
+ * in place -- from the caller's device matrix, or from one H2D copy of it -- by the leaves of the voices of that call.  Only
+ * leaves of shape-matched voices can read a track, and not under a Delay: anything else that reads one makes
+ * fill_buffer return FR_ERR_UNSUPPORTED, as does a voice whose track slots the call did not supply.  Results are those of
+ * the reference given the same rows.  UINT32_MAX (the default): no tracks.  This is the one workload of the hot path that
+ * is HBM-bound (bench.py `tracks`).
+ * The _dense calls take the reference's own input shape, `in` = [n_in_rows][n_times] row-major (host / device memory), and
+ * cost O(1) host work per track row where the CSR form costs a length check each. */
+fr_status fr_set_track_inputs(fr_renderer *r, uint32_t first_slot);
+fr_status fr_fill_buffer_dense(fr_renderer *r, float *out, uint32_t n_slots, uint64_t n_times, uint64_t idx,
+                               const float *in, uint32_t n_in_rows);
+fr_status fr_fill_buffer_device_dense(fr_renderer *r, float *d_out, uint32_t n_slots, uint64_t n_times, uint64_t idx,
+                                      const float *d_in, uint32_t n_in_rows, void *stream);
+
 /* Optional: page-locks [p, p + bytes) and maps it for the device (hipHostRegister).  An `out` buffer of fr_fill_buffer
  * that lies inside a registered range is then written by the kernels themselves -- no device-to-host copy of the
  * samples at all (config C: 166 -> 142 us per call) -- for a host that REUSES its sample buffer between calls (the

@@ -166,6 +166,11 @@ class RendererLib:
         L.fr_on_add_edges.argtypes = [vp, vp, C.c_size_t]
         L.fr_fill_buffer.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp, C.c_uint32]
         L.fr_fill_buffer_device.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp, C.c_uint32, vp]
+        L.fr_set_track_inputs.argtypes = [vp, C.c_uint32]
+        L.fr_fill_buffer_dense.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, vp, C.c_uint32]
+        L.fr_fill_buffer_device_dense.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, vp, C.c_uint32, vp]
+        for fn in ("fr_set_track_inputs", "fr_fill_buffer_dense", "fr_fill_buffer_device_dense"):
+            getattr(L, fn).restype = C.c_int32
         for fn in ("fr_on_add_node", "fr_on_del_node", "fr_on_add_edge", "fr_on_del_edge", "fr_on_add_nodes",
                    "fr_on_add_edges", "fr_fill_buffer", "fr_fill_buffer_device", "fr_set_timing",
                    "fr_get_timing", "fr_reset_timing"):
@@ -394,6 +399,24 @@ class Renderer:
         self._check(self.L.fr_fill_buffer(self.h, out.ctypes.data, n_slots, n_times, start,
                                           data.ctypes.data, offs.ctypes.data, n_rows))
         return out
+
+    # --- control-rate tracks (friendship_render.h): input slots >= first_slot are read in place, never stored ---
+    def set_track_inputs(self, first_slot):
+        self._check(self.L.fr_set_track_inputs(self.h, 0xFFFFFFFF if first_slot is None else first_slot))
+
+    def fill_buffer_dense(self, n_slots, start, end, inputs, out=None):
+        """fill_buffer with the reference's own input shape: inputs = float32 [n_in_rows, end - start] (row r feeds slot r)."""
+        n_times = end - start
+        inputs = np.ascontiguousarray(inputs, dtype=np.float32)
+        assert inputs.ndim == 2 and (inputs.shape[1] == n_times or inputs.shape[0] == 0)
+        if out is None:
+            out = np.zeros((n_slots, n_times), dtype=np.float32)
+        assert out.dtype == np.float32 and out.shape == (n_slots, n_times) and out.flags.c_contiguous
+        self._check(self.L.fr_fill_buffer_dense(self.h, out.ctypes.data, n_slots, n_times, start, inputs.ctypes.data, inputs.shape[0]))
+        return out
+
+    def fill_buffer_device_dense(self, d_out_ptr, n_slots, n_times, idx, d_in_ptr, n_in_rows, stream=0):
+        self._check(self.L.fr_fill_buffer_device_dense(self.h, d_out_ptr, n_slots, n_times, idx, d_in_ptr, n_in_rows, stream))
 
     def fill_buffer_device(self, d_out_ptr, n_slots, n_times, idx, d_in_ptr, row_offsets, stream=0):
         """Device-resident variant: raw device pointers (e.g. torch.Tensor.data_ptr()), host offsets."""

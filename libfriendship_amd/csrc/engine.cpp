@@ -153,6 +153,14 @@ struct fr_renderer {
     // finished frames come down through h_out_stage, which the kernels write DIRECTLY (mapped pinned memory: the stores
     // travel over PCIe while the launch is still computing), then one wait and one CPU copy into the caller's buffer
     PinnedBuf h_in_stage, h_out_stage;
+    // Tracks (fr_set_track_inputs): input slots >= track_from are control-rate rows -- per-partial frequency / amplitude
+    // envelopes -- that are NOT stored: the leaves of shape-matched voices read them from the call's own dense input matrix
+    // (reference.rs:66-74: `inputs` is an Array2, one row per slot), 8 bytes per partial-frame straight from HBM.
+    uint32_t track_from = 0xFFFFFFFFu;
+    uint32_t dense_total_rows = 0;          // set around a dense call: rows of the caller's matrix
+    const float *call_tracks = nullptr;     // row of slot 0 if the matrix started there (never dereferenced below track_from)
+    uint64_t call_track_stride = 0, call_track_rows = 0;
+    DevBuf d_tracks_stage;                  // host-buffer calls: the rows' copy in HBM
     // FR_HOST_MAPPED (A/B): bit 0 = kernels write the output through the mapping, bit 1 = the bank kernel reads the
     // input row through the mapping; 0 = the staged copies of round 1 (H2D row, D2H of the whole buffer)
     bool host_out_mapped = false, host_rows_mapped = true;
@@ -607,11 +615,38 @@ struct fr_renderer {
     }
 
     // `device_rows`: in_data is a device pointer (fr_fill_buffer_device).
+    // `dense`: the rows are an [n_rows][n_times] matrix (fr_fill_buffer_dense); `offs` then covers the stored rows only.
     void store_inputs(uint32_t n_slots, uint64_t n_times, uint64_t idx, const float *in_data,
-                      const uint64_t *offs, uint32_t n_rows, bool device_rows, hipStream_t st) {
+                      const uint64_t *offs, uint32_t n_rows, bool device_rows, hipStream_t st, bool dense = false) {
         deferred.clear();
         reap();
         call_idx = idx;
+        call_tracks = nullptr;
+        call_track_stride = call_track_rows = 0;
+        if (dense_total_rows) { dense = true; n_rows = dense_total_rows; }   // (fr_fill_buffer_dense: `offs` covers min(rows, track_from) rows)
+        {   // rows beyond the reference's input vectors -- n_slots * n_times of the largest call so far -- are dropped (reference.rs:59-68)
+            const uint64_t vecs_after = std::max<uint64_t>(n_vecs, (uint64_t)n_slots * n_times);
+            if (track_from != 0xFFFFFFFFu && n_rows > vecs_after) n_rows = (uint32_t)vecs_after;
+        }
+        if (n_rows > track_from && n_times > 0) {   // rows of track slots: not stored, read in place by this call's voices
+            if (!dense)
+                for (uint32_t r = track_from; r < n_rows; ++r)
+                    if (offs[r + 1] - offs[r] != n_times)
+                        throw Error(FR_ERR_UNSUPPORTED, "track input row " + std::to_string(r) + " must hold exactly the " + std::to_string(n_times) + " frames rendered");
+            const float *first = in_data + (dense ? (uint64_t)track_from * n_times : offs[track_from]);
+            const uint64_t rows_t = n_rows - track_from;
+            if (!device_rows) {
+                d_tracks_stage.ensure(rows_t * n_times * sizeof(float));
+                HIP_CHECK(hipMemcpyAsync(d_tracks_stage.p, first, rows_t * n_times * sizeof(float), hipMemcpyHostToDevice, st));
+                first = d_tracks_stage.as<float>();
+            }
+            call_tracks = reinterpret_cast<const float *>(reinterpret_cast<uintptr_t>(first) - (uintptr_t)track_from * n_times * sizeof(float));
+            call_track_stride = n_times;
+            call_track_rows = rows_t;
+            n_rows = track_from;
+        } else if (dense_total_rows) {
+            n_rows = std::min(n_rows, track_from);
+        }
         const bool seek = idx != head;   // forget history, act as if inputs were 0 before idx (renderer.rs:12-15)
         // validate everything before mutating so a refused call leaves the history intact: the lengths the rows must
         // continue are those AFTER the seek (idx for every vec) and after the vec count grew (reference.rs:52-71)
@@ -723,10 +758,10 @@ struct fr_renderer {
         p.max_depth = fg.max_depth;
         bool use_jit = allow_jit && mode == FR_MODE_AUTO;
         if (!matcher || matcher_gen != lowering.generation()) {
-            matcher.reset(new BankMatcher(fg, 20, use_jit, allow_template));
+            matcher.reset(new BankMatcher(fg, 20, use_jit, allow_template, track_from));
             matcher_gen = lowering.generation();
         }
-        p.sp = plan_stages(fg, mode == FR_MODE_AUTO, mode != FR_MODE_PULL, 20, use_jit, allow_template, matcher.get(), shard_spec);
+        p.sp = plan_stages(fg, mode == FR_MODE_AUTO, mode != FR_MODE_PULL, 20, use_jit, allow_template, matcher.get(), shard_spec, track_from);
         std::vector<std::shared_ptr<JitKernel>> jits(p.sp.banks.size());
         p.jit_epoch = jit_cache.epoch();   // (read first: a compile finishing from here on makes this plan stale)
         if (use_jit) {
@@ -734,6 +769,10 @@ struct fr_renderer {
             try {
                 for (size_t i = 0; i < p.sp.banks.size(); ++i)
                     if (p.sp.banks[i].jit) {
+                        // (voices that read tracks have no other evaluator to render with meanwhile: wait for the compiler)
+                        const bool wait = p.sp.banks[i].tracks && jit_async_configured;
+                        if (wait) jit_cache.set_async(false);
+                        struct Restore { JitCache &c; bool on; ~Restore() { if (on) c.set_async(true); } } restore{jit_cache, wait};
                         jits[i] = jit_cache.get(p.sp.banks[i].shape, p.sp.banks[i].varying, p.sp.banks[i].literal_bits, p.sp.banks[i].alias);
                         if (!jits[i]) p.jit_pending = without = true;   // being compiled on the worker thread: do not wait
                     }
@@ -748,7 +787,7 @@ struct fr_renderer {
                     throw Error(FR_ERR_DEVICE, std::string("a kernel of the sharded plan could not be compiled on this rank (every rank must plan alike): ") + e.what());
             }
             if (without) {
-                p.sp = plan_stages(fg, true, true, 20, false, true, nullptr, shard_spec);
+                p.sp = plan_stages(fg, true, true, 20, false, true, nullptr, shard_spec, track_from);
                 jits.assign(p.sp.banks.size(), nullptr);
             }
         }
@@ -838,6 +877,7 @@ struct fr_renderer {
                << ",\"leaf_ops\":" << (g.jit ? g.shape.ops.size() : 0) << ",\"leaf_params\":" << (g.jit ? g.k : 2)
                << ",\"input_slot\":" << g.input_slot << ",\"fast_ok\":" << (g.fast_ok ? "true" : "false")
                << ",\"to_ring\":" << (g.to_ring ? "true" : "false") << ",\"to_exchange\":" << (g.to_ws ? "true" : "false")
+               << ",\"tracks\":" << (g.tracks ? "true" : "false")
                << ",\"param_bytes\":" << g.params.size() * sizeof(float) << "}";
         }
         js << "],\"stage_programs\":" << (p.sp.progs.size() - p.sp.fused_count - p.sp.post_count) << ",\"stage_instrs\":" << p.sp.instrs.size()
@@ -1007,6 +1047,12 @@ struct fr_renderer {
                     if (nb(vpw) >= 1024) { j.voices_per_wave = vpw; j.nblocks = (uint32_t)nb(vpw); }
                 }
                 j.fract_ok = bs.grp.fast_ok ? 1u : 0u;
+                if (bs.grp.tracks && call_tracks) {
+                    if (b0 != idx || blen != n_times) throw Error(FR_ERR_UNSUPPORTED, "internal: a voice that reads tracks rendered over another window than the call's");
+                    j.tracks = call_tracks;
+                    j.track_stride = call_track_stride;
+                    j.track_limit = (uint32_t)std::min<uint64_t>((uint64_t)track_from + call_track_rows, 0xFFFFFFFFull);
+                }
                 Scope sc(this, &t_bank, st);
                 HIP_CHECK(launch_jit_bank(*bs.jit, j, st));
                 sc.done();
@@ -1549,6 +1595,39 @@ fr_status fr_fill_buffer_device(fr_renderer *r, float *d_out, uint32_t n_slots, 
         r->remember_async(st, independent && !r->used_scratch);
         r->head = idx + n_times;
     });
+}
+
+fr_status fr_set_track_inputs(fr_renderer *r, uint32_t first_slot) {
+    return guarded(r, [&] {
+        if (r->track_from == first_slot) return;
+        r->track_from = first_slot;
+        r->plan.valid = false;      // voices are matched differently
+        r->matcher.reset();
+    });
+}
+
+namespace {
+fr_status fill_dense(fr_renderer *r, float *out, uint32_t n_slots, uint64_t n_times, uint64_t idx, const float *in, uint32_t n_in_rows,
+                     bool device, void *stream) {
+    if (!r) return FR_ERR_INVALID_ARG;
+    if (n_in_rows && n_times && !in) { r->last_error = "null input matrix"; return FR_ERR_INVALID_ARG; }
+    const uint32_t stored = std::min(n_in_rows, r->track_from);
+    std::vector<uint64_t> offs((size_t)stored + 1);
+    for (uint32_t i = 0; i <= stored; ++i) offs[i] = (uint64_t)i * n_times;
+    r->dense_total_rows = n_in_rows;
+    const fr_status st = device ? fr_fill_buffer_device(r, out, n_slots, n_times, idx, in, offs.data(), stored, stream)
+                                : fr_fill_buffer(r, out, n_slots, n_times, idx, in, offs.data(), stored);
+    r->dense_total_rows = 0;
+    return st;
+}
+}   // namespace
+
+fr_status fr_fill_buffer_dense(fr_renderer *r, float *out, uint32_t n_slots, uint64_t n_times, uint64_t idx, const float *in, uint32_t n_in_rows) {
+    return fill_dense(r, out, n_slots, n_times, idx, in, n_in_rows, false, nullptr);
+}
+fr_status fr_fill_buffer_device_dense(fr_renderer *r, float *d_out, uint32_t n_slots, uint64_t n_times, uint64_t idx, const float *d_in,
+                                      uint32_t n_in_rows, void *stream) {
+    return fill_dense(r, d_out, n_slots, n_times, idx, d_in, n_in_rows, true, stream);
 }
 
 fr_status fr_host_register(fr_renderer *r, void *p, size_t bytes) {

@@ -35,7 +35,7 @@ LEAF_FUNCTION
 
 // one wave's share of a voice: Pw leaves in groups of 8, group sums merged by the binary-counter carry chain
 template <bool FAST>
-__device__ __forceinline__ float wave_sum(cptr p, const float *x, unsigned ngroups, unsigned levels) {
+__device__ __forceinline__ float wave_sum(cptr p, const float *x TRACK_PARAMS, unsigned ngroups, unsigned levels) {
     float s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0, s8 = 0;
     for (unsigned g = 0; g < ngroups; ++g) {
         float c[8 * K];
@@ -70,6 +70,8 @@ extern "C" __global__ void __launch_bounds__(256) jit_bank(JitBankArgs a) {
     const unsigned lane = threadIdx.x & 63u;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned long long ti = (unsigned long long)tile * 64u + lane;
+    const unsigned long long tt = ti < a.n_times ? ti : a.n_times - 1;   // (tracks: the lanes past the call's end re-read its last frame)
+    (void)tt;
     float x[NIN > 0 ? NIN : 1];
 #pragma unroll
     for (int i = 0; i < NIN; ++i)
@@ -85,10 +87,10 @@ extern "C" __global__ void __launch_bounds__(256) jit_bank(JitBankArgs a) {
 #pragma unroll
     for (int i = 0; i < NIN; ++i)
         if ((FRACT_INPUTS >> i) & 1u) in_range = in_range && __builtin_bit_cast(unsigned, x[i]) <= 0x4F800000u;
-    if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) r = wave_sum<true>(p, x, ngroups, levels);
+    if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) r = wave_sum<true>(p, x TRACK_ARGS, ngroups, levels);
     else
 #endif
-        r = wave_sum<false>(p, x, ngroups, levels);
+        r = wave_sum<false>(p, x TRACK_ARGS, ngroups, levels);
 
     __shared__ float sm[4][64];
     sm[wave][lane] = r;
@@ -108,6 +110,8 @@ extern "C" __global__ void __launch_bounds__(256) jit_bank_multi(JitBankArgs a) 
     const unsigned lane = threadIdx.x & 63u;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned long long ti = (unsigned long long)tile * 64u + lane;
+    const unsigned long long tt = ti < a.n_times ? ti : a.n_times - 1;   // (tracks: the lanes past the call's end re-read its last frame)
+    (void)tt;
     float x[NIN > 0 ? NIN : 1];
 #pragma unroll
     for (int i = 0; i < NIN; ++i)
@@ -127,7 +131,7 @@ extern "C" __global__ void __launch_bounds__(256) jit_bank_multi(JitBankArgs a) 
         const unsigned voice = v0 + j;
         if (voice >= a.n_voices) break;
         cptr p = (cptr)(a.params + (size_t)voice * P * K);
-        const float r = fast ? wave_sum<true>(p, x, ngroups, levels) : wave_sum<false>(p, x, ngroups, levels);
+        const float r = fast ? wave_sum<true>(p, x TRACK_ARGS, ngroups, levels) : wave_sum<false>(p, x TRACK_ARGS, ngroups, levels);
         if (ti < a.n_times) a.out[(size_t)a.rows[voice] * a.out_stride + o] = r;
     }
 }
@@ -137,7 +141,7 @@ std::string JitCache::generate_source(const LeafShape &shape, const std::vector<
                                       const std::vector<uint32_t> &alias, bool sparkle) {
     LeafSource ls = generate_leaf_source(shape, varying, literal_bits, alias, sparkle);
     std::ostringstream call;
-    call << "leaf<FAST>(x";
+    call << "leaf<FAST>(x" << (ls.tracks ? ", trk, tstride, tlimit, tt" : "");
     for (uint32_t i = 0; i < ls.k; ++i) call << ", c[(j) * K + " << i << "]";
     call << ")";
     std::ostringstream src;
@@ -146,6 +150,8 @@ std::string JitCache::generate_source(const LeafShape &shape, const std::vector<
     src << "#define K " << ls.k << "\n#define NIN " << shape.input_slots.size() << "\n#define HAS_MOD1 " << (ls.has_mod1 ? 1 : 0)
         << "\n#define FRACT_INPUTS " << ls.fract_inputs << "u\n";
     src << "#define LEAF_CALL(j) " << call.str() << "\n";
+    src << (ls.tracks ? "#define TRACK_PARAMS , const float *trk, unsigned long long tstride, unsigned tlimit, unsigned long long tt\n#define TRACK_ARGS , a.tracks, a.track_stride, a.track_limit, tt\n"
+                      : "#define TRACK_PARAMS\n#define TRACK_ARGS\n");
     std::string body = kSkeleton;
     const std::string tag = "LEAF_FUNCTION";
     body.replace(body.find(tag), tag.size(), ls.text);
@@ -247,8 +253,8 @@ static std::string disk_key_text(const std::string &src, const std::string &arch
     (void)hiprtcVersion(&major, &minor);
     if (hipRuntimeGetVersion(&rt) != hipSuccess) { (void)hipGetLastError(); rt = 0; }
     if (hipDriverGetVersion(&drv) != hipSuccess) { (void)hipGetLastError(); drv = 0; }
-    // "fr-jit-2": bumped whenever this engine's code generators change what they print for the same request
-    std::string key = "fr-jit-2|" + arch + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) + "|hip " +
+    // "fr-jit-3": bumped whenever this engine's code generators change what they print for the same request
+    std::string key = "fr-jit-3|" + arch + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) + "|hip " +
                       std::to_string(HIP_VERSION_MAJOR) + "." + std::to_string(HIP_VERSION_MINOR) + "." + std::to_string(HIP_VERSION_PATCH) + " " +
                       HIP_VERSION_GITHASH + "|runtime " + std::to_string(rt) + "|driver " + std::to_string(drv) + "|";
     for (const char *o : kJitOptions) { key += o; key += ' '; }

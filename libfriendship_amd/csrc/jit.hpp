@@ -47,6 +47,9 @@ namespace fr {
         unsigned int nblocks;                                                                                  \
         unsigned int fract_ok;          /* host-proved: Modulo(x, 1) == fract(x) for inputs in [+0, 2^32] */   \
         unsigned int voices_per_wave;   /* > 0: jit_bank_multi, nblocks = tiles * ceil(n_voices / (4 * this)) */ \
+        const float *tracks;            /* row 0 of the call's dense input matrix (LEAF_TRACK leaves), or null */ \
+        unsigned long long track_stride; /* floats between its rows */                                          \
+        unsigned int track_limit;       /* slots >= this were not supplied (or do not exist yet): they read +0 */ \
     };
 FR_JIT_ARGS_TEXT
 
@@ -92,6 +95,7 @@ struct LeafSource {
     uint32_t k = 1;              // parameters per leaf (>= 1)
     bool has_mod1 = false;       // the leaf contains a Modulo(x, 1.0)
     uint32_t fract_inputs = 0;   // mask of the inputs its arguments depend on
+    bool tracks = false;         // the leaf takes (trk, tstride, tt) after x: it reads per-leaf track rows (LEAF_TRACK)
 };
 LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
                                 const std::vector<uint32_t> &alias, bool sparkle = false);

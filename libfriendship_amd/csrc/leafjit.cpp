@@ -23,6 +23,14 @@ __device__ __forceinline__ float jit_opaque(float v) {
 #endif
     return v;
 }
+// A track: input row number `slot` (its bits travel as a float parameter) of the call's dense [rows][stride] input matrix
+// at frame ti (the kernel clamps ti to the call's last frame for the lanes of a partial tile); no matrix this call: +0.
+// A slot at or beyond `limit` was not supplied (or does not exist for the reference: its input vectors number n_slots * n_times
+// of the largest call so far, reference.rs:59-64, and further rows are dropped): +0, reference.rs:92-94.
+__device__ __forceinline__ float jit_track(const float *trk, unsigned long long stride, unsigned limit, unsigned long long ti, float slot) {
+    const unsigned s = __builtin_bit_cast(unsigned, slot);
+    return (trk && s < limit) ? trk[(unsigned long long)s * stride + ti] : jit_opaque(0.0f);
+}
 __device__ __forceinline__ float jit_mod(float a, float b) {   // reference.rs:254-261
     float rem = fmodf(a, b);
     return rem < 0.0f ? rem + b : rem;
@@ -61,7 +69,7 @@ LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> 
         const LeafShape::Op &a = shape.ops[i], &b = shape.ops[j];
         if (a.op != b.op) return false;
         if (a.op == OP_INPUT) return a.a == b.a;
-        if (a.op == OP_CONST) {
+        if (a.op == OP_CONST || a.op == LEAF_TRACK) {
             if (varying[a.a] != varying[b.a]) return false;
             return varying[a.a] ? pidx[a.a] == pidx[b.a] : literal_bits[a.a] == literal_bits[b.a];
         }
@@ -80,7 +88,10 @@ LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> 
         const LeafShape::Op &c = shape.ops[i];
         return c.op == OP_CONST && !varying[c.a] && literal_bits[c.a] == bits;
     };
+    bool tracks = false;
+    for (const LeafShape::Op &o : shape.ops) tracks = tracks || o.op == LEAF_TRACK;
     leaf << "template <bool FAST>\n__device__ __forceinline__ float leaf(const float *x";
+    if (tracks) leaf << ", const float *trk, unsigned long long tstride, unsigned tlimit, unsigned long long tt";
     for (uint32_t i = 0; i < (k ? k : 1); ++i) leaf << ", float p" << i;
     leaf << ") {\n    (void)x; (void)p0;\n";
     for (size_t i = 0; i < shape.ops.size(); ++i) {
@@ -97,6 +108,10 @@ LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> 
             }
             break;
         case OP_INPUT: leaf << "x[" << o.a << "]"; dep[i] = 1u << o.a; break;
+        case LEAF_TRACK:
+            if (varying[o.a]) leaf << "jit_track(trk, tstride, tlimit, tt, p" << pidx[o.a] << ")";
+            else { std::snprintf(buf, sizeof buf, "jit_track(trk, tstride, tlimit, tt, __builtin_bit_cast(float, 0x%08xu))", literal_bits[o.a]); leaf << buf; }
+            break;
         case OP_SUM2: {
             // y + (+-2^k * v), k >= 1, |2^k * v| provably finite: the product is exact, so one fused multiply-add rounds the
             // same real number the graph's two operations round -- bit for bit, zero signs included (a product that is
@@ -145,14 +160,14 @@ LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> 
         }
         }
         leaf << ";\n";
-        if (o.op != OP_CONST && o.op != OP_INPUT) dep[i] = dep[o.a] | dep[o.b];
+        if (o.op != OP_CONST && o.op != OP_INPUT && o.op != LEAF_TRACK) dep[i] = dep[o.a] | dep[o.b];
         switch (o.op) {
         case OP_CONST: {
             const float c = f32_from_bits(literal_bits[o.a]);
             bound[i] = (!varying[o.a] && c == c && std::fabs(c) <= 3e38f) ? std::fabs((double)c) : HUGE_VAL;
             break;
         }
-        case OP_INPUT: case OP_DIV: bound[i] = HUGE_VAL; break;
+        case OP_INPUT: case OP_DIV: case LEAF_TRACK: bound[i] = HUGE_VAL; break;
         case OP_SUM2: bound[i] = bound[o.a] + bound[o.b]; break;
         case OP_MUL: bound[i] = (std::isinf(bound[o.a]) || std::isinf(bound[o.b])) ? HUGE_VAL : bound[o.a] * bound[o.b]; break;
         case OP_MOD: bound[i] = 2.0 * bound[o.b]; break;   // |fmod(a, b)| < |b|, and the fix-up adds b once (a finite literal b here)
@@ -161,6 +176,7 @@ LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> 
         if (!(bound[i] <= 1e38)) bound[i] = HUGE_VAL;
         switch (o.op) {
         case OP_CONST: maybe_negzero[i] = varying[o.a] || literal_bits[o.a] == 0x80000000u; break;
+        case LEAF_TRACK: maybe_negzero[i] = true; break;
         case OP_SUM2: maybe_negzero[i] = maybe_negzero[o.a] && maybe_negzero[o.b]; break;
         case OP_MIN: maybe_negzero[i] = maybe_negzero[o.a] || maybe_negzero[o.b]; break;
         default: maybe_negzero[i] = true; break;   // inputs, products, quotients, remainders: not analysed
@@ -171,6 +187,7 @@ LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> 
     out.k = k ? k : 1;
     out.has_mod1 = has_mod1;
     out.fract_inputs = fract_inputs;
+    out.tracks = tracks;
     out.text = std::string(sparkle ? "#define FR_SPARKLE 1\n" : "#define FR_SPARKLE 0\n") + kLeafHelpers + leaf.str();
     return out;
 }

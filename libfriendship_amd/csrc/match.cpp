@@ -225,6 +225,7 @@ struct BankMatcher::Impl : Matcher {
     }
 
     // ---- shape matching (for jit.hpp): leaves of ANY common expression shape -------------------------------
+    uint32_t track_from = 0xFFFFFFFFu;   // input slots from here on are tracks (leafshape.hpp LEAF_TRACK)
     std::unordered_map<uint32_t, uint64_t> shape_memo;   // 0 = not a leaf expression (contains a Delay, too deep)
     static uint64_t hmix(uint64_t h, uint64_t v) {
         h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
@@ -238,7 +239,7 @@ struct BankMatcher::Impl : Matcher {
         const FlatNode &x = n(id);
         if (depth > 48 || x.op == OP_DELAY) r = 0;
         else if (x.op == OP_CONST) r = 0xC0757ull;
-        else if (x.op == OP_INPUT) r = hmix(0x17B07ull, x.a) | 1;
+        else if (x.op == OP_INPUT) r = x.a >= track_from ? 0x7BAC4ull | 1 : hmix(0x17B07ull, x.a) | 1;   // (tracks: any slot, same shape)
         else {
             uint64_t a = shape_hash(x.a, depth + 1), b = shape_hash(x.b, depth + 1);
             if (!a || !b) r = 0;
@@ -269,6 +270,11 @@ struct BankMatcher::Impl : Matcher {
                 consts.push_back(x.a);
                 return (uint32_t)ops.size() - 1;
             }
+            if (x.op == OP_INPUT && x.a >= track_from) {   // the row's number is a per-leaf parameter like a constant
+                ops.push_back({LEAF_TRACK, (uint32_t)consts.size(), 0});
+                consts.push_back(x.a);
+                return (uint32_t)ops.size() - 1;
+            }
             if (x.op == OP_INPUT) {
                 uint32_t idx = 0;
                 while (idx < inputs.size() && inputs[idx] != x.a) ++idx;
@@ -281,6 +287,9 @@ struct BankMatcher::Impl : Matcher {
             }
             uint32_t a = x.a, b = x.b;
             if ((x.op == OP_SUM2 || x.op == OP_MUL) && shape_hash(a) > shape_hash(b)) std::swap(a, b);
+            // (two tracks under one commutative op hash alike: lower slot first, as make() ordered them by id or not)
+            if ((x.op == OP_SUM2 || x.op == OP_MUL) && n(a).op == OP_INPUT && n(b).op == OP_INPUT && n(a).a >= track_from && n(b).a >= track_from &&
+                n(a).a > n(b).a) std::swap(a, b);
             uint32_t la = emit(a), lb = emit(b);
             ops.push_back({x.op, la, lb});
             return (uint32_t)ops.size() - 1;
@@ -362,6 +371,13 @@ struct BankMatcher::Impl : Matcher {
         vm.log2_p = h;
         vm.n_leaves = (uint32_t)leaves.size();
         vm.fast_ok = fract_form_is_exact(vm, all, first);
+        vm.tracks = false;
+        for (const LeafShape::Op &o : vm.shape.ops) vm.tracks = vm.tracks || o.op == LEAF_TRACK;
+        if (vm.tracks) vm.fast_ok = false;   // (a track's values are not range-tested per wave as the shared inputs are)
+        vm.max_track_slot = 0;
+        for (const LeafShape::Op &o : vm.shape.ops)
+            if (o.op == LEAF_TRACK)
+                for (size_t i = 0; i < leaves.size(); ++i) vm.max_track_slot = std::max(vm.max_track_slot, all[i * nc + o.a]);
         return true;
     }
 
@@ -398,6 +414,7 @@ struct BankMatcher::Impl : Matcher {
             const LeafShape::Op &o = vm.shape.ops[i];
             if (o.op == OP_CONST) { val[i] = col[o.a]; continue; }
             if (o.op == OP_INPUT) { val[i] = Val{Range{0.0, 4294967296.0, false}, true}; continue; }
+            if (o.op == LEAF_TRACK) { val[i] = Val{Range::unbounded(), false}; continue; }
             const Val &a = val[o.a], &b = val[o.b];
             bool nonneg;
             switch (o.op) {
@@ -416,8 +433,8 @@ struct BankMatcher::Impl : Matcher {
     }
 };
 
-BankMatcher::BankMatcher(const FlatGraph &g, uint32_t max_log2_p, bool allow_jit, bool allow_template)
-    : impl_(new Impl(g)), g_(g), max_log2_p_(max_log2_p), allow_jit_(allow_jit), allow_template_(allow_template) {}
+BankMatcher::BankMatcher(const FlatGraph &g, uint32_t max_log2_p, bool allow_jit, bool allow_template, uint32_t track_from)
+    : impl_(new Impl(g)), g_(g), max_log2_p_(max_log2_p), allow_jit_(allow_jit), allow_template_(allow_template) { impl_->track_from = track_from; }
 BankMatcher::~BankMatcher() { delete impl_; }
 
 void BankMatcher::begin_plan() { used_.clear(); }

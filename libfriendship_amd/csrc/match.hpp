@@ -36,11 +36,14 @@ struct VoiceMatch {
     std::vector<uint32_t> literal_bits;
     std::vector<uint32_t> alias;      // alias[c] = first column whose values equal column c's in every leaf (c itself if none)
     uint32_t k = 0;
+    bool tracks = false;              // some leaf input is a per-leaf track row (shape ops LEAF_TRACK)
+    uint32_t max_track_slot = 0;      // highest input slot any leaf reads as a track
 };
 
 class BankMatcher {
 public:
-    BankMatcher(const FlatGraph &g, uint32_t max_log2_p, bool allow_jit = false, bool allow_template = true);
+    // track_from: input slots >= it are control-rate tracks (leafshape.hpp LEAF_TRACK; fr_set_track_inputs)
+    BankMatcher(const FlatGraph &g, uint32_t max_log2_p, bool allow_jit = false, bool allow_template = true, uint32_t track_from = 0xFFFFFFFFu);
     ~BankMatcher();
     BankMatcher(const BankMatcher &) = delete;
     BankMatcher &operator=(const BankMatcher &) = delete;

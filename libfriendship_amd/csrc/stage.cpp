@@ -209,7 +209,7 @@ void add_voice(std::vector<BankLaunch> &banks, std::unordered_map<std::string, s
         BankLaunch bl;
         bl.log2_p = vm.log2_p; bl.input_slot = vm.input_slot; bl.to_ring = ring; bl.to_ws = ws; bl.general = vm.general;
         if (vm.general) { bl.group_off.push_back(0); bl.group_off.push_back(0); }
-        if (vm.jit) { bl.jit = true; bl.shape = vm.shape; bl.varying = vm.varying; bl.literal_bits = vm.literal_bits; bl.alias = vm.alias; bl.k = vm.k; }
+        if (vm.jit) { bl.jit = true; bl.shape = vm.shape; bl.varying = vm.varying; bl.literal_bits = vm.literal_bits; bl.alias = vm.alias; bl.k = vm.k; bl.tracks = vm.tracks; }
         if (totals) {
             auto ti = totals->find(key);
             if (ti != totals->end()) bl.params.reserve(ti->second);
@@ -220,6 +220,7 @@ void add_voice(std::vector<BankLaunch> &banks, std::unordered_map<std::string, s
     bl.rows.push_back(row);
     bl.params.insert(bl.params.end(), vm.params.begin(), vm.params.end());
     bl.fast_ok = bl.fast_ok && vm.fast_ok;
+    bl.max_track_slot = std::max(bl.max_track_slot, vm.max_track_slot);
     if (vm.general) {
         bl.groups.insert(bl.groups.end(), vm.groups.begin(), vm.groups.end());
         bl.group_off.push_back((uint32_t)bl.groups.size());
@@ -368,10 +369,37 @@ bool build_program(const FlatGraph &g, const Planner &P, uint32_t m, std::unorde
     return true;
 }
 
+// Tracks (fr_set_track_inputs) are never stored: only a voice leaf of the call that supplies them can read one.
+void check_tracks(const FlatGraph &g, const StagedPlan &sp, uint32_t track_from) {
+    if (track_from != 0xFFFFFFFFu && g.has_input && g.max_input_slot >= track_from) {
+        // tracks are never stored: only a voice leaf of the call that supplies them can read one
+        auto refuse = [](const char *who) { throw Error(FR_ERR_UNSUPPORTED, std::string("a track input (fr_set_track_inputs) is read by ") + who +
+                                                                                ": only the leaves of shape-matched voices can read tracks"); };
+        for (uint32_t sl : sp.input_slots) if (sl >= track_from) refuse("a stage program");
+        for (const BankLaunch &bl : sp.banks) {
+            if (!bl.jit && bl.input_slot >= track_from) refuse("a template voice as its time input");
+            if (bl.tracks && (bl.to_ring || bl.to_ws)) refuse("a voice that feeds a delay line or is split across GPUs");
+        }
+        std::unordered_set<uint32_t> seen;
+        std::vector<uint32_t> st;
+        for (uint32_t row : sp.pull_rows) st.push_back(g.outputs[row]);
+        while (!st.empty()) {
+            const uint32_t n = st.back();
+            st.pop_back();
+            if (!seen.insert(n).second) continue;
+            const FlatNode &x = g.nodes[n];
+            if (x.op == OP_INPUT && x.a >= track_from) refuse("a row left to the pull interpreter");
+            if (x.op == OP_CONST || x.op == OP_INPUT || x.op == OP_FBREF) continue;
+            st.push_back(x.a);
+            st.push_back(x.b);
+        }
+    }
+}
+
 }  // namespace
 
 StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p, bool allow_jit, bool allow_template,
-                       BankMatcher *reuse, const ShardSpec *shard) {
+                       BankMatcher *reuse, const ShardSpec *shard, uint32_t track_from) {
     StagedPlan sp;
     const uint32_t n_rows = (uint32_t)g.outputs.size();
     // Sharding (friendship_render.h fr_shard).  FR_SHARD_VOICES: plan only what this rank's rows need.  FR_SHARD_PARTIALS:
@@ -387,7 +415,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
     BankMatcher *matcher = nullptr;
     if (allow_banks) {
         if (reuse) matcher = reuse;
-        else { own.reset(new BankMatcher(g, max_log2_p, allow_jit, allow_template)); matcher = own.get(); }
+        else { own.reset(new BankMatcher(g, max_log2_p, allow_jit, allow_template, track_from)); matcher = own.get(); }
         matcher->begin_plan();
     }
     struct Retain { BankMatcher *m; ~Retain() { if (m) m->retain_used(); } } retain{reuse ? matcher : nullptr};
@@ -475,6 +503,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
             add_voice(fb.banks, grp, vm, row, false);
         }
         std::sort(fb.pull_rows.begin(), fb.pull_rows.end());
+        check_tracks(g, fb, track_from);
         return fb;
     }
 
@@ -907,6 +936,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         }
     }
     std::sort(sp.pull_rows.begin(), sp.pull_rows.end());
+    check_tracks(g, sp, track_from);
     return sp;
 }
 

@@ -32,6 +32,8 @@ struct BankLaunch {
     std::vector<uint32_t> literal_bits;
     std::vector<uint32_t> alias;
     uint32_t k = 0;
+    bool tracks = false;             // jit leaves read per-leaf track rows of the call's dense input matrix (leafshape.hpp LEAF_TRACK)
+    uint32_t max_track_slot = 0;
 };
 
 // How the job is split over `world` renderers, one per GPU (friendship_render.h fr_shard).  Output rows are owned in
@@ -97,7 +99,9 @@ struct StagedPlan {
 // `reuse`: a matcher built over this same FlatGraph object with the same limits, kept by the caller across plans
 // (incremental re-planning after a graph edit: unchanged voices are answered from its memo).
 class BankMatcher;
+// `track_from`: input slots >= it are control-rate tracks (fr_set_track_inputs): visible only to the call that supplies them,
+// readable only by the leaves of shape-matched voices (anything else that reads one makes the plan FR_ERR_UNSUPPORTED).
 StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p, bool allow_jit = false,
-                       bool allow_template = true, BankMatcher *reuse = nullptr, const ShardSpec *shard = nullptr);
+                       bool allow_template = true, BankMatcher *reuse = nullptr, const ShardSpec *shard = nullptr, uint32_t track_from = 0xFFFFFFFFu);
 
 }  // namespace fr

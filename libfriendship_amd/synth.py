@@ -140,6 +140,63 @@ def partial_leaves(g, w, amp, time_slot=0, w_nodes=None):
     return g.binop(K_MUL, C(amp), y, n)
 
 
+def track_leaves(g, w_slots, amp_slots, time_slot=0):
+    """The same 11-node partial oscillator with its phase increment and its amplitude read from INPUT rows (control-rate
+    tracks, one pair of rows per partial: reference.rs:66-74,181-183) instead of constants."""
+    w_slots = np.asarray(w_slots, dtype=np.uint32).ravel()
+    amp_slots = np.asarray(amp_slots, dtype=np.uint32).ravel()
+    n = len(w_slots)
+    x = g.nodes(K_MUL, n)
+    g.edge(0, x, time_slot, 0)
+    g.edge(0, x, w_slots, 1)
+    ph = g.binop(K_MOD, x, C(np.float32(1.0)), n)
+    u = g.binop(K_SUM2, ph, C(np.float32(-0.5)), n)
+    nu = g.binop(K_MUL, C(np.float32(-1.0)), u, n)
+    m = g.binop(K_MIN, u, nu, n)
+    ab = g.binop(K_MUL, C(np.float32(-1.0)), m, n)
+    n1 = g.binop(K_MUL, C(np.float32(-1.0)), ab, n)
+    q = g.binop(K_SUM2, C(np.float32(0.5)), n1, n)
+    p = g.binop(K_MUL, C(np.float32(-16.0)), u, n)
+    y = g.binop(K_MUL, p, q, n)
+    leaf = g.nodes(K_MUL, n)
+    g.edge(0, leaf, amp_slots, 0)
+    g.edge(y, leaf, 0, 1)
+    return leaf
+
+
+def track_tree(n_voices, n_partials, time_slot=0, first_track=1):
+    """The HBM-bound variant of configs B/C: every partial's phase increment w and amplitude arrive as input
+    rows -- slot first_track + 2 (v P + k) holds w, the next one amp -- so a frame of a partial costs 8 bytes of HBM.
+    Output slot per voice; `n_inputs` rows per call (time row + tracks)."""
+    g = GraphArrays()
+    n = n_voices * n_partials
+    w_slots = first_track + 2 * np.arange(n, dtype=np.uint32)
+    leaves = track_leaves(g, w_slots, w_slots + 1, time_slot).reshape(n_voices, n_partials)
+    roots = sum_tree(g, leaves)
+    g.edge(roots, 0, 0, np.arange(n_voices, dtype=np.uint32))
+    t = g.finish(n_voices)
+    t["first_track"] = first_track
+    t["n_inputs"] = first_track + 2 * n
+    return t
+
+
+def track_rows(n_voices, n_partials, start, end, seed=0x5EED0200, first_track=1, time_slot=0, sr=48000.0):
+    """The dense input matrix [first_track + 2 V P, end - start] of a call of track_tree: the time ramp, and per partial a
+    slowly gliding w (vibrato: +-0.3 % at a few hertz, phase per partial) and a decaying, tremolo'd amplitude."""
+    p = voice_params(n_voices, n_partials, seed, sr=sr)
+    t = np.arange(start, end, dtype=np.float64)[None, :]
+    n = n_voices * n_partials
+    ph = uniform01(seed, n).astype(np.float64)[:, None] * 6.283185307179586
+    rate = (3.0 + 4.0 * uniform01(seed + 1, n).astype(np.float64))[:, None] / sr
+    w = p["w"].astype(np.float64).reshape(n, 1) * (1.0 + 0.003 * np.sin(6.283185307179586 * rate * t + ph))
+    amp = p["amp"].astype(np.float64).reshape(n, 1) * (0.75 + 0.25 * np.cos(6.283185307179586 * 2.0 * rate * t + ph)) * np.exp(-t / (4.0 * sr))
+    m = np.zeros((first_track + 2 * n, end - start), dtype=np.float32)
+    m[time_slot] = time_ramp(start, end)
+    m[first_track::2] = w.astype(np.float32)
+    m[first_track + 1::2] = amp.astype(np.float32)
+    return m
+
+
 def triangle_leaves(g, w, amp, time_slot=0, am_slot=None):
     """A different partial: triangle wave  amp * (1 - 4*|phase - 0.5|), optionally amplitude-modulated by a second
     input (leaf * in[am_slot]).  Not the hand-matched template: the engine specialises it with hipRTC (csrc/jit.hpp)."""

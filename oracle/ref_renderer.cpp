@@ -505,6 +505,19 @@ fr_status fr_shard_rows(const fr_renderer *r, uint32_t n_slots, uint32_t *lo, ui
     return FR_OK;
 }
 
+// Tracks (friendship_render.h): to the reference they are input rows like any other -- stored, readable by anything -- so
+// the oracle takes the declaration and ignores it; the dense call is fill_buffer on the reference's own Array2 shape.
+fr_status fr_set_track_inputs(fr_renderer *r, uint32_t) { return r ? FR_OK : FR_ERR_INVALID_ARG; }
+fr_status fr_fill_buffer_dense(fr_renderer *r, float *out, uint32_t n_slots, uint64_t n_times, uint64_t idx, const float *in, uint32_t n_in_rows) {
+    std::vector<uint64_t> offs((size_t)n_in_rows + 1);
+    for (uint32_t i = 0; i <= n_in_rows; ++i) offs[i] = (uint64_t)i * n_times;
+    return fr_fill_buffer(r, out, n_slots, n_times, idx, in, offs.data(), n_in_rows);
+}
+fr_status fr_fill_buffer_device_dense(fr_renderer *r, float *, uint32_t, uint64_t, uint64_t, const float *, uint32_t, void *) {
+    if (r) r->last_error = "the CPU oracle has no device path";
+    return FR_ERR_UNSUPPORTED;
+}
+
 fr_status fr_fill_buffer_device(fr_renderer *r, float *, uint32_t, uint64_t, uint64_t, const float *,
                                 const uint64_t *, uint32_t, void *) {
     if (r) r->last_error = "the CPU oracle has no device path";

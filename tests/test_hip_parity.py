@@ -1929,3 +1929,64 @@ def test_random_feedback_graphs(hip_lib, oracle_lib, seed0):
             assert hip.plan()["feedback"], seed
             done += 1
     assert done >= 15 and unsupported <= done // 2, (done, unsupported)
+
+
+# ---- control-rate tracks: per-partial w / amp rows read in place from the call's dense input matrix (the HBM-bound variant) --
+@pytest.mark.parametrize("V,P", [(3, 64), (2, 256), (5, 32)])
+def test_track_voices_against_oracle(hip_lib, oracle_lib, V, P):
+    """Voices whose partials take their phase increment and amplitude from input rows (synth.track_tree): the engine reads the
+    rows in place (fr_set_track_inputs), the oracle stores them like any input.  Host matrix, device matrix and the CSR call;
+    a short first call on a fresh renderer, where the reference has only n_slots * n_times input vectors and drops the rows
+    beyond them (reference.rs:59-68) -- those partials are silent in both."""
+    import torch
+    tree = synth.track_tree(V, P)
+    R = tree["n_inputs"]
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        hip.set_track_inputs(tree["first_track"])
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        idx = 0
+        for k, n in enumerate([max(200, R // V + 1), 130, 16, 1, 64]):
+            m = synth.track_rows(V, P, idx, idx + n)
+            exp = ref.fill_buffer_dense(V, idx, idx + n, m)
+            if k % 3 == 0:
+                got = hip.fill_buffer_dense(V, idx, idx + n, m)
+            elif k % 3 == 1:
+                got = hip.fill_buffer(V, idx, idx + n, list(m))
+            else:
+                d_m = torch.from_numpy(m).cuda()
+                d_out = torch.empty((V, n), dtype=torch.float32, device="cuda")
+                hip.fill_buffer_device_dense(d_out.data_ptr(), V, n, idx, d_m.data_ptr(), R, torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                got = d_out.cpu().numpy()
+            assert same_bits(got, exp), f"call {k} ({n} frames): " + first_diff(got, exp)
+            assert np.abs(got).max() > 0
+            idx += n
+        plan = hip.plan()
+        assert plan["pull_rows"] == 0 and len(plan["banks"]) == 1 and plan["banks"][0]["jit"] and plan["banks"][0]["tracks"], plan
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:   # the reference's input vectors: V * 16 of them, the rest dropped
+        hip.set_track_inputs(tree["first_track"])
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        m = synth.track_rows(V, P, 0, 16)
+        got, exp = hip.fill_buffer_dense(V, 0, 16, m), ref.fill_buffer_dense(V, 0, 16, m)
+        assert same_bits(got, exp), first_diff(got, exp)
+        assert not got[V - 1].any()    # the last voice's tracks lie beyond slot V * 16
+
+
+def test_tracks_read_by_anything_else_are_refused(hip_lib):
+    """A track is visible only to the leaves of the voices of the call that supplies it: a Delay of one, a program, a template
+    voice's time input -> FR_ERR_UNSUPPORTED (the reference would serve them from the stored history)."""
+    tree = synth.track_tree(2, 32)
+    for extra in ("delay", "program"):
+        with Renderer(hip_lib) as hip:
+            hip.set_track_inputs(tree["first_track"])
+            synth.install(hip, tree)
+            h = int(tree["handles"].max()) + 1
+            hip.on_add_node(h, "Delay" if extra == "delay" else "Sum2")
+            hip.on_add_edge(0, h, 5, 0)                      # input slot 5: a track
+            hip.on_add_edge(1, h, f32_bits(3.0), 1)
+            hip.on_add_edge(h, 0, 0, 2)
+            with pytest.raises(RenderError) as ei:
+                hip.fill_buffer_dense(3, 0, 64, synth.track_rows(2, 32, 0, 64))
+            assert ei.value.status == FR_ERR_UNSUPPORTED, extra
