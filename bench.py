@@ -741,6 +741,24 @@ def run():
                 result["configs"][name] = other_config(name, torch, libfriendship_amd, synth, local_rank, K=max(50, min(K, 200)), W=20)
             except Exception as ex:
                 result["configs"][name] = {"error": repr(ex)}
+    # The HBM-bound variant of the same tree: every partial's w and amp arrive as control-rate track rows,
+    # 8 bytes per partial-frame, read in place from the call's dense device matrix (fr_set_track_inputs).  The achieved
+    # fraction of the HBM roofline on algorithmic bytes, at a short and a long call (tools/track_bench.py; parity:
+    # tests/test_hip_parity.py::test_track_voices_against_oracle).
+    if extras and not args.no_configs and args.tree == "additive" and (V, P) == (64, 4096):
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import track_bench
+            tr = track_bench.run(V, P, frames=(64, 1024), steps=20, log=log)
+            tr["workload"] = ("BASELINE.json configs[2] shape (64 voices x 4096 partials) with per-partial frequency / amplitude tracks as "
+                              "input rows: 524289 rows x T frames per call, device-resident, 8 B per partial-frame")
+            tr["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achievable": 6290.0,
+                              "achieved": tr["runs"][-1]["achieved_GBps"], "frac": tr["runs"][-1]["frac_of_8TBps"],
+                              "frac_of_achievable": tr["runs"][-1]["frac_of_6.29TBps"], "at_frames": tr["runs"][-1]["frames"],
+                              "traffic": None}
+            result["tracks"] = tr
+        except Exception as ex:
+            result["tracks"] = {"error": repr(ex)}
     # HBM traffic per launch from PMC counters: rocprofv3 cannot wrap a process from inside it, so the figure is read from
     # the committed summary of the separate --pmc passes of this same command (tools/collect_profiles.sh), which records
     # the commit it was taken at.

@@ -161,6 +161,10 @@ struct fr_renderer {
     const float *call_tracks = nullptr;     // row of slot 0 if the matrix started there (never dereferenced below track_from)
     uint64_t call_track_stride = 0, call_track_rows = 0;
     DevBuf d_tracks_stage;                  // host-buffer calls: the rows' copy in HBM
+    // shape-matched voices rendered in pieces (few voices x short call): the pieces' sums and the identity row list
+    DevBuf d_chunk_ws, d_chunk_rows;
+    uint32_t d_chunk_rows_n = 0;
+    bool jit_chunks = true;                 // FR_JIT_CHUNKS=0: one workgroup per (voice, tile) always (A/B)
     // FR_HOST_MAPPED (A/B): bit 0 = kernels write the output through the mapping, bit 1 = the bank kernel reads the
     // input row through the mapping; 0 = the staged copies of round 1 (H2D row, D2H of the whole buffer)
     bool host_out_mapped = false, host_rows_mapped = true;
@@ -1047,6 +1051,31 @@ struct fr_renderer {
                     if (nb(vpw) >= 1024) { j.voices_per_wave = vpw; j.nblocks = (uint32_t)nb(vpw); }
                 }
                 j.fract_ok = bs.grp.fast_ok ? 1u : 0u;
+                // Few voices, short call: one workgroup per (voice, 64-frame tile) leaves most of the chip idle (64 voices x 64
+                // frames = 64 workgroups).  Render every voice as 2^c consecutive pieces of its leaves instead -- to the kernel
+                // 2^c times as many voices of 2^-c the size, rows of a workspace -- and add the pieces up in the tree's order.
+                uint32_t pieces_log2 = 0;
+                if (jit_chunks && !ring && !ws && !j.voices_per_wave && a.n_voices <= 1024u) {
+                    while (pieces_log2 < 6 && a.log2_p - pieces_log2 > 5 && ((uint64_t)j.nblocks << pieces_log2) < 1024u) ++pieces_log2;
+                }
+                if (pieces_log2) {
+                    const uint32_t pv = a.n_voices << pieces_log2;
+                    d_chunk_ws.ensure((size_t)pv * blen * sizeof(float));
+                    if (d_chunk_rows_n < pv) {
+                        std::vector<uint32_t> seq(std::max<uint32_t>(pv, 4096));
+                        for (uint32_t i = 0; i < seq.size(); ++i) seq[i] = i;
+                        d_chunk_rows.ensure(seq.size() * sizeof(uint32_t));
+                        HIP_CHECK(hipMemcpyAsync(d_chunk_rows.p, seq.data(), seq.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+                        HIP_CHECK(hipStreamSynchronize(st));   // (`seq` is a stack object; once per growth)
+                        d_chunk_rows_n = (uint32_t)seq.size();
+                    }
+                    j.out = d_chunk_ws.as<float>();
+                    j.rows = d_chunk_rows.as<uint32_t>();
+                    j.out_stride = blen;
+                    j.n_voices = pv;
+                    j.log2_p = a.log2_p - pieces_log2;
+                    j.nblocks = j.tiles * j.n_voices;
+                }
                 if (bs.grp.tracks && call_tracks) {
                     if (b0 != idx || blen != n_times) throw Error(FR_ERR_UNSUPPORTED, "internal: a voice that reads tracks rendered over another window than the call's");
                     j.tracks = call_tracks;
@@ -1055,6 +1084,17 @@ struct fr_renderer {
                 }
                 Scope sc(this, &t_bank, st);
                 HIP_CHECK(launch_jit_bank(*bs.jit, j, st));
+                if (pieces_log2) {
+                    ChunkCombineArgs c{};
+                    c.ws = d_chunk_ws.as<float>();
+                    c.out = a.out;
+                    c.rows = a.rows;
+                    c.out_stride = a.out_stride;
+                    c.n_times = blen;
+                    c.n_voices = a.n_voices;
+                    c.log2_c = pieces_log2;
+                    HIP_CHECK(launch_chunk_combine(c, st));
+                }
                 sc.done();
                 return;
             }
@@ -1388,6 +1428,7 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     }
     if (const char *sv = std::getenv("FR_STAGE_JIT")) r->stage_jit_mode = sv[0] == '0' ? 0 : (sv[0] == '1' ? 1 : 2);
     if (const char *fv = std::getenv("FR_STAGE_STRIDED")) r->fused_strided_ok = fv[0] != '0';
+    if (const char *cv = std::getenv("FR_JIT_CHUNKS")) r->jit_chunks = cv[0] != '0';
     if (const char *xv = std::getenv("FR_EXCHANGE_TILES")) { r->x_max_tiles = (uint32_t)std::min(64, std::max(1, std::atoi(xv))); r->x_tiles_explicit = true; }
     if (const char *xv = std::getenv("FR_EXCHANGE_MIN_TILE")) { r->x_min_tile = (uint32_t)std::min(1 << 20, std::max(64, std::atoi(xv))); r->x_tiles_explicit = true; }
     if (const char *iv = std::getenv("FR_STREAM_IDLE_MS")) r->stream_idle_ms = (uint32_t)std::min(60000, std::max(1, std::atoi(iv)));

@@ -1576,6 +1576,38 @@ hipError_t launch_shard_combine(const ShardCombineArgs &a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Pieces of a voice -> the voice (kernels.hpp ChunkCombineArgs).  HBM-bound and tiny: 4 B x 2^C per output sample.
+template <int C>
+__global__ void __launch_bounds__(256) chunk_combine_kernel(ChunkCombineArgs a) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t voice = blockIdx.y;
+    if (t >= a.n_times) return;
+    float v[1 << C];
+#pragma unroll
+    for (int i = 0; i < (1 << C); ++i) v[i] = a.ws[(((size_t)voice << C) | (size_t)i) * a.n_times + t];
+#pragma unroll
+    for (int n = 1 << C; n > 1; n >>= 1)
+#pragma unroll
+        for (int i = 0; i < n / 2; ++i) v[i] = v[2 * i] + v[2 * i + 1];
+    a.out[(size_t)a.rows[voice] * a.out_stride + t] = v[0];
+}
+
+hipError_t launch_chunk_combine(const ChunkCombineArgs &a, hipStream_t s) {
+    if (a.n_voices == 0 || a.n_times == 0) return hipSuccess;
+    if (a.log2_c < 1 || a.log2_c > 6 || a.n_voices > 65535u) return hipErrorInvalidValue;
+    const dim3 grid((uint32_t)((a.n_times + 255) / 256), a.n_voices), block(256);
+    switch (a.log2_c) {
+    case 1: hipLaunchKernelGGL(chunk_combine_kernel<1>, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(chunk_combine_kernel<2>, grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(chunk_combine_kernel<3>, grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL(chunk_combine_kernel<4>, grid, block, 0, s, a); break;
+    case 5: hipLaunchKernelGGL(chunk_combine_kernel<5>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(chunk_combine_kernel<6>, grid, block, 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 __global__ void pad_kernel(float *dst, uint64_t n, const float *src_last) {
     float v = src_last ? *src_last : 0.0f;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = v;

@@ -203,6 +203,20 @@ struct ShardCombineArgs {
 };
 hipError_t launch_shard_combine(const ShardCombineArgs &a, hipStream_t s);
 
+// A voice rendered as 2^log2_c consecutive pieces of its leaves (a short call of few voices would not fill the chip
+// otherwise): ws holds the pieces' sums as rows [(voice << log2_c) | piece][n_times]; this adds them up the way the voice's
+// Sum2 tree does above the pieces -- adjacent pairs, level by level -- and stores the voice at out[rows[voice]].  log2_c <= 6.
+struct ChunkCombineArgs {
+    const float *ws;
+    float *out;
+    const uint32_t *rows;
+    uint64_t out_stride;
+    uint64_t n_times;
+    uint32_t n_voices;
+    uint32_t log2_c;
+};
+hipError_t launch_chunk_combine(const ChunkCombineArgs &a, hipStream_t s);
+
 // Fills dst[0..n) with *src_last (or 0 when src_last is null): last-value padding of a short input
 // row (reference.rs:72-73) for the device-resident entry point.
 hipError_t launch_pad(float *dst, uint64_t n, const float *src_last, hipStream_t s);

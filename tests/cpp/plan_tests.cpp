@@ -1021,6 +1021,86 @@ static void oversized_expressions_are_split() {
 // The leaf function the hipRTC bank kernel is built around, compiled with g++ and compared with the lowered graph's
 // own value for every leaf of a voice, on ordinary and hostile inputs: the general body always, the v_fract body
 // (FAST) wherever the kernel would select it.  Pins the peepholes (x mod 1 as fract, Minimum(u, -u) as -|u|).
+// Voices whose leaves read per-leaf TRACK rows (leafshape.hpp LEAF_TRACK): matched only when the slots are declared tracks,
+// the slot numbers travel as per-leaf parameters in leaf order, and the generated leaf -- built here with g++ against a small
+// dense matrix -- equals the graph's own evaluation, including slots the call did not supply (beyond `limit`: +0).
+static void track_leaves_are_matched_and_generated() {
+    const uint32_t first = 10;
+    Build b;
+    std::vector<uint32_t> leaves;
+    for (uint32_t k = 0; k < 32; ++k) {
+        uint32_t x = b.op(FR_PRIM_MULTIPLY, In(0), In(first + 2 * k));
+        uint32_t ph = b.op(FR_PRIM_MODULO, N(x), Cf(1.0f));
+        uint32_t u = b.op(FR_PRIM_SUM2, N(ph), Cf(-0.5f));
+        uint32_t m = b.op(FR_PRIM_MINIMUM, N(u), N(b.op(FR_PRIM_MULTIPLY, Cf(-1.0f), N(u))));
+        uint32_t q = b.op(FR_PRIM_SUM2, Cf(0.5f), N(m));
+        uint32_t y = b.op(FR_PRIM_MULTIPLY, N(b.op(FR_PRIM_MULTIPLY, Cf(-16.0f), N(u))), N(q));
+        leaves.push_back(b.op(FR_PRIM_MULTIPLY, In(first + 2 * k + 1), N(y)));
+    }
+    b.out(N(sum_tree(b, leaves)), 0);
+    Mirror m;
+    b.apply(m);
+    FlatGraph fg = lower(m, 1);
+    {   // not declared: every leaf reads other input slots, so the leaves are different shapes -- no voice
+        BankMatcher plain(fg, 20, true, false);
+        VoiceMatch vm;
+        CHECK(!plain.try_voice(fg.outputs[0], vm));
+    }
+    BankMatcher bm(fg, 20, true, false, first);
+    VoiceMatch vm;
+    CHECK(bm.try_voice(fg.outputs[0], vm) && vm.jit && vm.tracks && vm.log2_p == 5 && vm.k == 2 && !vm.fast_ok);
+    CHECK(vm.max_track_slot == first + 63 && vm.shape.input_slots.size() == 1 && vm.shape.input_slots[0] == 0);
+    // parameters: the two slot numbers of every leaf, leaves left to right
+    for (uint32_t k = 0; k < 32; ++k) {
+        uint32_t a = f32_to_bits(vm.params[k * 2]), c = f32_to_bits(vm.params[k * 2 + 1]);
+        if (a > c) std::swap(a, c);
+        CHECK(a == first + 2 * k && c == first + 2 * k + 1);
+    }
+    LeafSource ls = generate_leaf_source(vm.shape, vm.varying, vm.literal_bits, vm.alias);
+    CHECK(ls.tracks && ls.k == 2);
+    std::string base = "/tmp/fr_trackleaf_" + std::to_string((long)getpid());
+    FILE *f = std::fopen((base + ".cpp").c_str(), "w");
+    CHECK(f != nullptr);
+    std::fputs("#include <cmath>\n#define __device__\n#define __forceinline__ inline\n"
+               "static inline float __builtin_amdgcn_fractf(float a) { return a - floorf(a); }\n", f);
+    std::fputs(ls.text.c_str(), f);
+    std::fputs("extern \"C\" float leaf_general(const float *x, const float *trk, unsigned long long stride, unsigned limit, unsigned long long t, const float *p) "
+               "{ return leaf<false>(x, trk, stride, limit, t, p[0], p[1]); }\n", f);
+    std::fclose(f);
+    CHECK(std::system(("g++ -std=c++17 -O1 -ffp-contract=off -w -shared -fPIC -o " + base + ".so " + base + ".cpp").c_str()) == 0);
+    void *so = dlopen((base + ".so").c_str(), RTLD_NOW | RTLD_LOCAL);
+    CHECK(so != nullptr);
+    auto leaf = (float (*)(const float *, const float *, unsigned long long, unsigned, unsigned long long, const float *))dlsym(so, "leaf_general");
+    CHECK(leaf != nullptr);
+    std::remove((base + ".cpp").c_str());
+    std::remove((base + ".so").c_str());
+    const uint32_t T = 24, R = first + 64;
+    std::mt19937 rng(5);
+    std::uniform_real_distribution<float> uni(-0.2f, 1.0f);
+    std::vector<float> mat((size_t)R * T);
+    for (float &v : mat) v = uni(rng);
+    std::vector<uint32_t> leaf_ids;
+    std::function<void(uint32_t, int)> walk = [&](uint32_t id, int h) {
+        if (h == 0) { leaf_ids.push_back(id); return; }
+        walk(fg.nodes[id].a, h - 1);
+        walk(fg.nodes[id].b, h - 1);
+    };
+    walk(fg.outputs[0], 5);
+    for (uint32_t limit : {R, first + 20u}) {   // the second: rows from slot first + 20 on were not supplied
+        Inputs in(R);
+        for (uint32_t s2 = 0; s2 < R; ++s2)
+            if (s2 < limit) in[s2].assign(mat.begin() + (size_t)s2 * T, mat.begin() + (size_t)(s2 + 1) * T);
+        for (uint32_t t = 0; t < T; ++t)
+            for (size_t li = 0; li < leaf_ids.size(); ++li) {
+                const float x0 = mat[t];   // slot 0's row
+                const float got = leaf(&x0, mat.data(), T, limit, t, &vm.params[li * 2]);
+                const float expect = flat_eval(fg, leaf_ids[li], t, in);
+                CHECK(f32_to_bits(got) == f32_to_bits(expect) || (got != got && expect != expect));
+            }
+    }
+    dlclose(so);
+}
+
 static void generated_leaves_equal_the_graph() {
     const float hostile[] = {0.0f, -0.0f, 1.0f, 0.5f, 0.25f, 3.0f, 1e-30f, 1e-42f, 48000.0f, 16777216.0f, 4294967296.0f, 4294967808.0f,
                              1e30f, 3e38f, -1.0f, -0.5f, -2.75f, -1e30f, INFINITY, -INFINITY, NAN};
@@ -1269,7 +1349,8 @@ int main(int argc, char **argv) {
         {"bounded_signal_delays_are_staged", bounded_signal_delays_are_staged},
         {"value_ranges_are_sound", value_ranges_are_sound},
         {"oversized_expressions_are_split", oversized_expressions_are_split},
-        {"generated_leaves_equal_the_graph", generated_leaves_equal_the_graph}};
+        {"generated_leaves_equal_the_graph", generated_leaves_equal_the_graph},
+        {"track_leaves_are_matched_and_generated", track_leaves_are_matched_and_generated}};
     int failed = 0, ran = 0;
     for (auto &t : tests) {
         if (argc > 1 && std::string(argv[1]) != t.first) continue;

@@ -199,6 +199,18 @@ hipError_t launch_stage(const StageArgs &a, hipStream_t) {
     return hipSuccess;
 }
 
+hipError_t launch_chunk_combine(const ChunkCombineArgs &a, hipStream_t) {
+    std::vector<float> v((size_t)1 << a.log2_c);
+    for (uint32_t voice = 0; voice < a.n_voices; ++voice)
+        for (uint64_t t = 0; t < a.n_times; ++t) {
+            for (size_t i = 0; i < v.size(); ++i) v[i] = a.ws[(((size_t)voice << a.log2_c) | i) * a.n_times + t];
+            for (size_t n = v.size(); n > 1; n >>= 1)
+                for (size_t i = 0; i < n / 2; ++i) v[i] = v[2 * i] + v[2 * i + 1];
+            a.out[(size_t)a.rows[voice] * a.out_stride + t] = v[0];
+        }
+    return hipSuccess;
+}
+
 hipError_t launch_pad(float *dst, uint64_t n, const float *src_last, hipStream_t) {
     ++fr_sim_launches[C_PAD];
     const float v = src_last ? *src_last : 0.0f;
