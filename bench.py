@@ -42,7 +42,7 @@ VALU_LANE_RATE = 256 * 4 * 32 * 2.4e9       # f32 VALU lane-ops/s: 256 CUs x 4 S
 OPS_EXECUTED_PER_PF = 6                     # VALU ops the fused kernel issues per partial-frame: mul, fract, fma, fma, mul + 1 tree add
 ISSUE_SLOTS_PER_PF = 7                      # v_fract_f32 issues at half rate on gfx950 (measured 4.07 vs 2.2 cyc, profiles/r01_valu_rate.txt)
 OPS_GRAPH_PER_PF = 12                       # primitive nodes the reference evaluates per partial-frame (11 + Sum2)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_bank_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_bank_pmc_summary.json")
 
 
 def log(*a):
@@ -756,6 +756,14 @@ def run():
                               "achieved": tr["runs"][-1]["achieved_GBps"], "frac": tr["runs"][-1]["frac_of_8TBps"],
                               "frac_of_achievable": tr["runs"][-1]["frac_of_6.29TBps"], "at_frames": tr["runs"][-1]["frames"],
                               "traffic": None}
+            try:   # HBM bytes per 1024-frame launch from the committed PMC passes of tools/track_bench.py (tools/collect_profiles.sh)
+                with open(PMC_SUMMARY) as f:
+                    pt = json.load(f)["tracks"]
+                tr["roofline"]["traffic"] = pt["derived"]["hbm_traffic_bytes"]
+                tr["roofline"]["traffic_over_algorithmic"] = pt["derived"]["traffic_over_algorithmic"]
+                tr["roofline"]["traffic_source"] = f"{os.path.relpath(PMC_SUMMARY, ROOT)} (rocprofv3 --pmc FETCH_SIZE x 2 [gfx950] / WRITE_SIZE, separate passes)"
+            except Exception:
+                pass
             result["tracks"] = tr
         except Exception as ex:
             result["tracks"] = {"error": repr(ex)}
@@ -763,7 +771,7 @@ def run():
     # the committed summary of the separate --pmc passes of this same command (tools/collect_profiles.sh), which records
     # the commit it was taken at.
     if (V, P, T) == (64, 4096, 4800) and world == 1:
-        for path in (PMC_SUMMARY, PMC_SUMMARY.replace("r02", "r01")):
+        for path in (PMC_SUMMARY, PMC_SUMMARY.replace("r03", "r02")):
             if not os.path.exists(path):
                 continue
             try:
