@@ -165,6 +165,7 @@ struct fr_renderer {
     DevBuf d_chunk_ws, d_chunk_rows;
     uint32_t d_chunk_rows_n = 0;
     bool jit_chunks = true;                 // FR_JIT_CHUNKS=0: one workgroup per (voice, tile) always (A/B)
+    uint64_t jit_chunk_target = 0;          // FR_JIT_CHUNK_TARGET: workgroups below which a voice is cut further (0: 1024, tracks 16384)
     // FR_HOST_MAPPED (A/B): bit 0 = kernels write the output through the mapping, bit 1 = the bank kernel reads the
     // input row through the mapping; 0 = the staged copies of round 1 (H2D row, D2H of the whole buffer)
     bool host_out_mapped = false, host_rows_mapped = true;
@@ -1056,7 +1057,12 @@ struct fr_renderer {
                 // 2^c times as many voices of 2^-c the size, rows of a workspace -- and add the pieces up in the tree's order.
                 uint32_t pieces_log2 = 0;
                 if (jit_chunks && !ring && !ws && !j.voices_per_wave && a.n_voices <= 1024u) {
-                    while (pieces_log2 < 6 && a.log2_p - pieces_log2 > 5 && ((uint64_t)j.nblocks << pieces_log2) < 1024u) ++pieces_log2;
+                    // (voices that stream tracks from HBM want many small workgroups -- 64 x 4096 x 1024 frames: 0.84 of the achievable
+                    //  bandwidth with 1024 workgroups, 0.93 with 16 384; profiles/r03_tracks.txt -- the arithmetic-bound ones only a full chip)
+                    const uint64_t target = jit_chunk_target ? jit_chunk_target : (bs.grp.tracks ? 16384u : 1024u);
+                    while (pieces_log2 < 6 && a.log2_p - pieces_log2 > 5 && ((uint64_t)j.nblocks << pieces_log2) < target) ++pieces_log2;
+                    // (T = 64: pieces of 256 partials beat 128 and 64 -- 34.5 / 37.3 / 35.3 us at 64 x 4096)
+                    if (bs.grp.tracks && a.n_times <= 128 && a.log2_p >= 8 && a.log2_p - pieces_log2 < 8) pieces_log2 = a.log2_p - 8;
                 }
                 if (pieces_log2) {
                     const uint32_t pv = a.n_voices << pieces_log2;
@@ -1429,6 +1435,7 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     if (const char *sv = std::getenv("FR_STAGE_JIT")) r->stage_jit_mode = sv[0] == '0' ? 0 : (sv[0] == '1' ? 1 : 2);
     if (const char *fv = std::getenv("FR_STAGE_STRIDED")) r->fused_strided_ok = fv[0] != '0';
     if (const char *cv = std::getenv("FR_JIT_CHUNKS")) r->jit_chunks = cv[0] != '0';
+    if (const char *cv = std::getenv("FR_JIT_CHUNK_TARGET")) r->jit_chunk_target = (uint64_t)std::max(1, std::atoi(cv));
     if (const char *xv = std::getenv("FR_EXCHANGE_TILES")) { r->x_max_tiles = (uint32_t)std::min(64, std::max(1, std::atoi(xv))); r->x_tiles_explicit = true; }
     if (const char *xv = std::getenv("FR_EXCHANGE_MIN_TILE")) { r->x_min_tile = (uint32_t)std::min(1 << 20, std::max(64, std::atoi(xv))); r->x_tiles_explicit = true; }
     if (const char *iv = std::getenv("FR_STREAM_IDLE_MS")) r->stream_idle_ms = (uint32_t)std::min(60000, std::max(1, std::atoi(iv)));
