@@ -559,7 +559,10 @@ def run():
 
     # independent calls overlapped on two streams (an extra, never `value`)
     overlapped = None
-    if extras and n_streams == 1 and not plan.get("rings") and not plan.get("stage_programs") and not plan.get("pull_rows"):
+    # (also for a voice-sharded job: a rank's share is a few-voice launch whose tail -- a handful of latency-bound waves,
+    #  DESIGN.md 4.5a -- is exactly what the next call's first waves can fill; every rank runs this leg, time = max over ranks)
+    stateless = not plan.get("rings") and not plan.get("stage_programs") and not plan.get("pull_rows")
+    if (extras or (world > 1 and shard_mode == "voices" and not args.no_extras)) and n_streams == 1 and stateless:
         s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
         o2 = [torch.empty_like(d_out), torch.empty_like(d_out)]
 
@@ -570,13 +573,17 @@ def run():
         for k in range(next_k, next_k + W):
             step2(k)
         torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
         t2 = time.perf_counter()
         for k in range(next_k + W, next_k + W + K):
             step2(k)
         torch.cuda.synchronize()
         e2 = time.perf_counter() - t2
+        barrier()
+        e2 = max_over_ranks(e2)
         next_k += W + K
-        overlapped = {"streams": 2, "value": K * T / e2 / 1e6, "unit": "Msamples/s", "ms_per_step": e2 / K * 1e3,
+        overlapped = {"streams": 2, "value": K * T / e2 / 1e6, "unit": "Msamples/s", "ms_per_step": e2 / K * 1e3, "n_gpus": world,
                       "note": "same K steps issued round-robin on 2 HIP streams with separate output buffers; kernels of consecutive "
                               "calls overlap, so per-launch durations are not comparable with the sequential run above"}
 

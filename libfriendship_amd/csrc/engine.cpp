@@ -1065,6 +1065,7 @@ struct fr_renderer {
                     if (bs.grp.tracks && a.n_times <= 128 && a.log2_p >= 8 && a.log2_p - pieces_log2 < 8) pieces_log2 = a.log2_p - 8;
                 }
                 if (pieces_log2) {
+                    used_scratch = true;   // (the pieces' workspace is shared between calls: no overlap with the next one on another stream)
                     const uint32_t pv = a.n_voices << pieces_log2;
                     d_chunk_ws.ensure((size_t)pv * blen * sizeof(float));
                     if (d_chunk_rows_n < pv) {
