@@ -97,7 +97,7 @@ LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> 
     for (size_t i = 0; i < shape.ops.size(); ++i) {
         const LeafShape::Op &o = shape.ops[i];
         leaf << "    float v" << i << " = ";
-        char buf[64];
+        char buf[160];
         switch (o.op) {
         case OP_CONST:
             if (varying[o.a]) leaf << "p" << pidx[o.a];

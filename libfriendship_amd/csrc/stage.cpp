@@ -21,8 +21,22 @@
 #include <unordered_map>
 #include <unordered_set>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 namespace fr {
 namespace {
+struct PlanTrace {
+    bool on = std::getenv("FR_PLAN_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "  plan_stages: -> %s after %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+#define FR_PT(x) plan_trace.mark(x)
 
 constexpr uint32_t NO_RING = 0xFFFFFFFFu;
 constexpr size_t MAX_PROG_INSTR = 4096;
@@ -401,6 +415,7 @@ void check_tracks(const FlatGraph &g, const StagedPlan &sp, uint32_t track_from)
 StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs, uint32_t max_log2_p, bool allow_jit, bool allow_template,
                        BankMatcher *reuse, const ShardSpec *shard, uint32_t track_from) {
     StagedPlan sp;
+    PlanTrace plan_trace;
     const uint32_t n_rows = (uint32_t)g.outputs.size();
     // Sharding (friendship_render.h fr_shard).  FR_SHARD_VOICES: plan only what this rank's rows need.  FR_SHARD_PARTIALS:
     // analyse the whole graph (every rank must arrive at the same list of split voices and the same look-back), then keep
@@ -421,6 +436,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
     struct Retain { BankMatcher *m; ~Retain() { if (m) m->retain_used(); } } retain{reuse ? matcher : nullptr};
     Planner P(g, matcher);
 
+    FR_PT("A_rows");
     std::vector<uint32_t> staged_rows;
     for (uint32_t row = 0; row < n_rows; ++row) {
         if (sharded && !partials && !mine(row)) continue;
@@ -455,6 +471,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
             st.push_back(x.b);
         }
     }
+    FR_PT("B_explore");
     for (uint32_t row : staged_rows) P.explore(g.outputs[row]);
     for (auto &kv : P.bank_of) P.cut.erase(kv.first);   // a Delay's source that is a voice is computed by the bank kernel
 
@@ -464,6 +481,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
     for (auto &kv : rows_of)
         if (!P.bank_of.count(kv.first)) P.cut.insert(kv.first);   // a root that is a leaf gets a trivial program too
 
+    FR_PT("C_build");
     // programs (cut node ids ascending == topological).  An expression too big for one program (instructions or
     // registers) is split: nodes inside it become extra cut nodes -- materialised in a ring, read back at the same
     // frame -- until every piece fits; the levels below order them.
@@ -507,6 +525,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         return fb;
     }
 
+    FR_PT("D_rings");
     // who needs a ring: anything read by a program, or feeding more than one output row
     std::unordered_set<uint32_t> needs_ring;
     for (auto &kv : built)
@@ -602,6 +621,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         for (uint32_t row : kv.second)
             if (mine(row)) my_rows_of[kv.first].push_back(row);
 
+    FR_PT("E_banks");
     // bank launches: voices that go straight to one output row, and voices that fill rings
     {
         std::unordered_map<std::string, size_t> grp;
@@ -683,6 +703,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
         }
     }
 
+    FR_PT("F_progs");
     // programs, ordered by level
     struct Pending { uint32_t level; uint32_t node; ProgBuild *pb; uint32_t dst_ring; int32_t out_row; };
     std::vector<Pending> pend;
@@ -730,6 +751,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
     }
     for (size_t l = 1; l < sp.level_first.size(); ++l) sp.level_first[l] += sp.level_first[l - 1];
 
+    FR_PT("G_fused");
     // Fused steady-state form: one launch.  Sinks = cut nodes no other program uses at the same frame; everything they
     // use at the same frame is computed inline.  Worth it only if the level form needs more than one launch.
     if (max_level >= 2 || feedback) {
@@ -935,6 +957,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
             sp.progs.insert(sp.progs.end(), fprogs.begin(), fprogs.end());
         }
     }
+    FR_PT("H_end");
     std::sort(sp.pull_rows.begin(), sp.pull_rows.end());
     check_tracks(g, sp, track_from);
     return sp;

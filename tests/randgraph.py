@@ -212,12 +212,13 @@ def random_feedback_graph(seed, n_frames=16, n_nodes=14, n_inputs=2, n_outputs=3
         rng.shuffle(later)
         for src in later:
             p = paths(src, h, {})
-            if p == 0 or float(p) ** -(-n_frames // d) > budget:
+            if p == 0:
                 continue
             out = [s for s in steps if not (s[0] == "edge" and s[2] == h and s[4] == 0)]
             out.append(("edge", src, h, 0, 0))
-            # the loop must be audible: some output depends on the Delay
-            if not any(s[0] == "edge" and s[2] == 0 and paths(s[1], h, {}) for s in out):
+            # the loop must be audible: some output depends on the Delay; every way from an output into the loop multiplies the cost
+            entries = sum(paths(s[1], h, {}) for s in out if s[0] == "edge" and s[2] == 0)
+            if entries == 0 or float(entries) * float(p) ** -(-n_frames // d) > budget:
                 continue
             return out, n_out, d
     return None

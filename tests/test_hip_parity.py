@@ -1990,3 +1990,35 @@ def test_tracks_read_by_anything_else_are_refused(hip_lib):
             with pytest.raises(RenderError) as ei:
                 hip.fill_buffer_dense(3, 0, 64, synth.track_rows(2, 32, 0, 64))
             assert ei.value.status == FR_ERR_UNSUPPORTED, extra
+
+
+def test_track_row_shared_by_every_leaf(hip_lib, oracle_lib):
+    """Every partial reads its own w track but ONE common amplitude track (a master envelope as a control-rate row): the slot
+    number of the shared row is a literal of the generated leaf, not a per-leaf parameter."""
+    V, P, first = 2, 64, 3
+    g = synth.GraphArrays()
+    n = V * P
+    w_slots = first + 1 + np.arange(n, dtype=np.uint32)
+    leaves = synth.track_leaves(g, w_slots, np.full(n, first, dtype=np.uint32), time_slot=0).reshape(V, P)
+    roots = synth.sum_tree(g, leaves)
+    g.edge(roots, 0, 0, np.arange(V, dtype=np.uint32))
+    tree = g.finish(V)
+    R = first + 1 + n
+    rng = np.random.default_rng(12)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        hip.set_track_inputs(first)
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        idx = 0
+        for T in (R // V + 8, 50):
+            m = np.zeros((R, T), np.float32)
+            m[0] = synth.time_ramp(idx, idx + T)
+            m[1:first] = rng.normal(size=(first - 1, T)).astype(np.float32)          # stored inputs nobody reads
+            m[first] = np.linspace(1.0, 0.2, T, dtype=np.float32)                     # the master envelope
+            m[first + 1:] = (rng.random((n, T)) * 0.05).astype(np.float32)
+            got, exp = hip.fill_buffer_dense(V, idx, idx + T, m), ref.fill_buffer_dense(V, idx, idx + T, m)
+            assert same_bits(got, exp), first_diff(got, exp)
+            assert np.abs(got).max() > 0
+            idx += T
+        bank = hip.plan()["banks"][0]
+        assert bank["tracks"] and bank["leaf_params"] == 1, bank

@@ -275,3 +275,37 @@ def test_random_patches_sharded_every_way(sim, oracle_lib, seed):
             got = job.assemble(job.fill(n_rows, c[0], c[1], rows_for[c]), n_rows)
             assert same_bits(got, expect[c]), f"seed {seed} {mode} x{world} call {c}: " + first_diff(got, expect[c])
         job.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_voices_mode_with_feedback_loops(sim, oracle_lib, world):
+    """Voice sharding of graphs with feedback through Delay: every rank lowers and plans only its rows -- a loop is cut, planned
+    and replayed on the rank that owns the row it feeds -- and partial-block sharding refuses them (FR_ERR_UNSUPPORTED)."""
+    done = 0
+    for seed in range(40):
+        made = randgraph.random_feedback_graph(seed, n_outputs=5)
+        if made is None:
+            continue
+        steps, n_out, _d = made
+        job = shard_harness.Job(sim, world, "voices")
+        rng = np.random.default_rng(seed)
+        with Renderer(oracle_lib) as ref:
+            randgraph.install_steps(ref, steps)
+            for ren in job.ranks:
+                randgraph.install_steps(ren, steps)
+            for start, n in [(0, 9), (9, 6), (30, 4)]:
+                rows = [rng.normal(size=n).astype(np.float32), rng.integers(-2, 5, size=n).astype(np.float32)]
+                exp = ref.fill_buffer(n_out, start, start + n, rows)
+                got = job.assemble(job.fill(n_out, start, start + n, rows), n_out)
+                assert same_bits(got, exp), f"seed {seed}: " + first_diff(got, exp)
+        job.close()
+        done += 1
+    assert done >= 10
+    made = next(m for m in (randgraph.random_feedback_graph(s, n_outputs=5) for s in range(40)) if m is not None)
+    job = shard_harness.Job(sim, 2, "partials")
+    for ren in job.ranks:
+        randgraph.install_steps(ren, made[0])
+    with pytest.raises(RenderError) as ei:
+        job.fill(made[1], 0, 8, [np.ones(8, np.float32), np.ones(8, np.float32)])
+    assert ei.value.status == 10
+    job.close()
