@@ -1130,6 +1130,11 @@ struct fr_renderer {
             }
             if (a.small_call == 1 && a.hist_dst) throw Error(FR_ERR_DEVICE, "internal: deferred history append on a short call");
             a.leaf_variant = bank_leaf_variant;
+            // small voices, many workgroups: ONE wave per (voice, tile) -- no LDS combine, no barrier (256 x 512 x 4800: 71.6 -> 66.4 us;
+            // at 1024 partials and above 4 waves are as fast or faster: profiles/r03_bank_waves.txt)
+            if (a.log2_p <= 9 && a.log2_p >= 3 && a.chunk_log2 == a.log2_p && !a.small_call && !a.voices_per_wave && a.waves_per_group == 4 &&
+                a.leaf_variant == 1 && !flag_out.host_flags && a.frames_per_lane == 1 && bank_blocks(a) >= 4096)
+                a.waves_per_group = 1;
             if (flag_out.host_flags) {
                 a.host_flags = flag_out.host_flags;
                 a.row_done = flag_out.row_done;

@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tile
     const float2 *cparams = a.params + ((size_t)voice << a.log2_p) + (size_t)chunk * Pc;
     const float *params = (const float *)(cparams + (size_t)wave * Pw);
     const uint32_t ngroups = Pw >> 3;
-    const uint32_t levels = a.chunk_log2 - 3u - (NW == 8 ? 3u : 2u);   // log2(ngroups) <= 8
+    const uint32_t levels = a.chunk_log2 - 3u - (NW == 8 ? 3u : NW == 4 ? 2u : NW == 2 ? 1u : 0u);   // log2(ngroups) <= 8
 
     float res[F];
     constexpr bool EXACT = (MODE == 0);
@@ -450,8 +450,10 @@ __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tile
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             uint64_t ti = t0 + (uint32_t)f * 64u + lane;
-            float r = (sm[0][f][lane] + sm[1][f][lane]) + (sm[2][f][lane] + sm[3][f][lane]);
-            if (NW == 8) r = r + ((sm[4][f][lane] + sm[5][f][lane]) + (sm[6][f][lane] + sm[7][f][lane]));
+            float r = sm[0][f][lane];
+            if (NW >= 2) r = r + sm[1 % NW][f][lane];
+            if (NW >= 4) r = r + (sm[2 % NW][f][lane] + sm[3 % NW][f][lane]);
+            if (NW == 8) r = r + ((sm[4 % NW][f][lane] + sm[5 % NW][f][lane]) + (sm[6 % NW][f][lane] + sm[7 % NW][f][lane]));
             bool live = ti < a.n_times;
             // Streaming store: nothing re-reads it here, and when the row lives in page-locked HOST memory (fr_host_register)
             // the wave is released ~9 us/launch sooner.  FLAGS: the row is read by the host BEFORE the launch ends, as soon as
@@ -479,8 +481,9 @@ __global__ void __launch_bounds__(64 * NW) bank_kernel(BankArgs a, uint32_t tile
                 sm[wave][f][lane] = mine ? 1.0f : 0.0f;   // (the sums in sm were consumed before the barrier above)
                 __syncthreads();
                 if (wave == 0 && ((m >> lane) & 1ull)) {
-                    bool all = sm[0][f][lane] != 0.0f && sm[1][f][lane] != 0.0f && sm[2][f][lane] != 0.0f && sm[3][f][lane] != 0.0f;
-                    if (NW == 8) all = all && sm[4][f][lane] != 0.0f && sm[5][f][lane] != 0.0f && sm[6][f][lane] != 0.0f && sm[7][f][lane] != 0.0f;
+                    bool all = true;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) all = all && sm[w][f][lane] != 0.0f;
                     uint64_t ti = t0 + (uint32_t)f * 64u + lane;
                     float *dst = &orow[direct ? bank_out_index(a, ti) : ti];
                     if (FLAGS) __hip_atomic_store(dst, all ? -0.0f : 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -987,6 +990,8 @@ static hipError_t launch_bank_f(const BankArgs &a, hipStream_t s) {
         else hipLaunchKernelGGL((bank_kernel<F, 1, 4, true>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
     } else if (a.leaf_variant == 1) {
         if (w8) hipLaunchKernelGGL((bank_kernel<F, 1, 8>), dim3(nblocks), dim3(512), 0, s, a, tiles, nblocks);
+        else if (a.waves_per_group == 2 && a.chunk_log2 <= 12) hipLaunchKernelGGL((bank_kernel<F, 1, 2>), dim3(nblocks), dim3(128), 0, s, a, tiles, nblocks);
+        else if (a.waves_per_group == 1 && a.chunk_log2 <= 11) hipLaunchKernelGGL((bank_kernel<F, 1, 1>), dim3(nblocks), dim3(64), 0, s, a, tiles, nblocks);
         else hipLaunchKernelGGL((bank_kernel<F, 1, 4>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
     } else {
         hipLaunchKernelGGL((bank_kernel<F, 2, 4>), dim3(nblocks), dim3(256), 0, s, a, tiles, nblocks);
@@ -1148,8 +1153,11 @@ hipError_t launch_bank(const BankArgs &a, hipStream_t s) {
         }
         return hipGetLastError();
     }
-    if (a.waves_per_group != 4 && a.waves_per_group != 8) return hipErrorInvalidValue;
-    const uint32_t cmin = a.waves_per_group == 8 ? 6 : 5, cmax = a.waves_per_group == 8 ? 14 : 13;
+    if (a.waves_per_group != 4 && a.waves_per_group != 8 && a.waves_per_group != 2 && a.waves_per_group != 1) return hipErrorInvalidValue;
+    if (a.waves_per_group < 4 && (a.leaf_variant != 1 || a.host_flags)) return hipErrorInvalidValue;   // (1- and 2-wave workgroups: FMA-form leaves only)
+    // a wave sums 8 .. 2048 partials (whole groups of 8, at most 8 carry levels)
+    const uint32_t cmin = a.waves_per_group == 8 ? 6 : a.waves_per_group == 4 ? 5 : a.waves_per_group == 2 ? 4 : 3;
+    const uint32_t cmax = a.waves_per_group == 8 ? 14 : a.waves_per_group == 4 ? 13 : a.waves_per_group == 2 ? 12 : 11;
     if (a.log2_p < cmin || a.log2_p > 24 || a.chunk_log2 < cmin || a.chunk_log2 > cmax || a.chunk_log2 > a.log2_p)
         return hipErrorInvalidValue;
     if (a.chunk_log2 != a.log2_p && !a.ws) return hipErrorInvalidValue;

@@ -473,7 +473,8 @@ def test_short_call_kernel_equals_block_render(hip_lib, V, P, T, block):
 
 
 @pytest.mark.parametrize("V,P,T,block", [(8, 4096, 4800, 1024), (16, 4096, 4800, 640), (5, 2048, 4777, 1000), (3, 16384, 6400, 704),
-                                         (32, 4096, 4800, 448), (9, 8192, 2000, 512)])
+                                         (32, 4096, 4800, 448), (9, 8192, 2000, 512),
+                                         (300, 512, 1000, 192), (70, 512, 4000, 320)])   # (>= 4096 workgroups of small voices: one wave each)
 def test_few_voice_launch_equals_block_render(hip_lib, V, P, T, block):
     """A GPU's share of a voice-sharded job -- few voices, a long call: a few hundred to a few thousand (voice, tile) pairs,
     8 x 4096 x 4800 being one GPU's step of config C on 8 GPUs -- takes the short-call kernel with chunks + tickets or the

@@ -123,6 +123,8 @@ int main(int argc, char **argv) {
     vars.push_back({1, 1, full, "", 8});
     vars.push_back({1, 0, full, "", 8});
     vars.push_back({2, 1, full, "", 8});
+    if (log2p <= 12) { vars.push_back({1, 1, full, "", 2}); vars.push_back({2, 1, full, "", 2}); }
+    if (log2p <= 11) { vars.push_back({1, 1, full, "", 1}); vars.push_back({2, 1, full, "", 1}); }
     for (int c = full - 1; c >= 9 && c >= full - 3; --c) { vars.push_back({2, 1, c, ""}); vars.push_back({1, 1, c, ""}); }
     std::vector<std::vector<double>> times(vars.size());
     std::vector<std::vector<float>> outs(vars.size());
