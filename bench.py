@@ -756,14 +756,14 @@ def run():
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import track_bench
-            tr = track_bench.run(V, P, frames=(64, 1024), steps=20, log=log)
+            tr = track_bench.run(V, P, frames=(64, 1024, 4800), steps=20, log=log)
             tr["workload"] = ("BASELINE.json configs[2] shape (64 voices x 4096 partials) with per-partial frequency / amplitude tracks as "
                               "input rows: 524289 rows x T frames per call, device-resident, 8 B per partial-frame")
             tr["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achievable": 6290.0,
                               "achieved": tr["runs"][-1]["achieved_GBps"], "frac": tr["runs"][-1]["frac_of_8TBps"],
                               "frac_of_achievable": tr["runs"][-1]["frac_of_6.29TBps"], "at_frames": tr["runs"][-1]["frames"],
                               "traffic": None}
-            try:   # HBM bytes per 1024-frame launch from the committed PMC passes of tools/track_bench.py (tools/collect_profiles.sh)
+            try:   # HBM bytes per 4800-frame launch from the committed PMC passes of tools/track_bench.py (tools/collect_profiles.sh)
                 with open(PMC_SUMMARY) as f:
                     pt = json.load(f)["tracks"]
                 tr["roofline"]["traffic"] = pt["derived"]["hbm_traffic_bytes"]

@@ -37,10 +37,32 @@ LEAF_FUNCTION
 template <bool FAST>
 __device__ __forceinline__ float wave_sum(cptr p, const float *x TRACK_PARAMS, unsigned ngroups, unsigned levels) {
     float s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0, s8 = 0;
+#if NT > 0
+    // per-leaf tracks: the group's 8 * NT row values are requested one group AHEAD (the slot numbers come through the scalar
+    // cache, the values through one coalesced 256-byte load per wave and row), so a wave always has a group's loads in flight
+    // under the arithmetic of the one before -- the kernel is HBM-bound (8 bytes per partial-frame)
+    float cn[8 * K], tvn[8 * NT];
+#pragma unroll
+    for (int i = 0; i < 8 * K; ++i) cn[i] = p[i];
+    TRACK_LOADS(tvn, cn)
+#endif
     for (unsigned g = 0; g < ngroups; ++g) {
         float c[8 * K];
+#if NT > 0
+        float tv[8 * NT];
+#pragma unroll
+        for (int i = 0; i < 8 * K; ++i) c[i] = cn[i];
+#pragma unroll
+        for (int i = 0; i < 8 * NT; ++i) tv[i] = tvn[i];
+        if (g + 1 < ngroups) {
+#pragma unroll
+            for (int i = 0; i < 8 * K; ++i) cn[i] = p[(size_t)(g + 1) * (8 * K) + i];
+            TRACK_LOADS(tvn, cn)
+        }
+#else
 #pragma unroll
         for (int i = 0; i < 8 * K; ++i) c[i] = p[(size_t)g * (8 * K) + i];
+#endif
         float l0 = LEAF_CALL(0), l1 = LEAF_CALL(1), l2 = LEAF_CALL(2), l3 = LEAF_CALL(3);
         float l4 = LEAF_CALL(4), l5 = LEAF_CALL(5), l6 = LEAF_CALL(6), l7 = LEAF_CALL(7);
         float v = ((l0 + l1) + (l2 + l3)) + ((l4 + l5) + (l6 + l7));
@@ -142,14 +164,24 @@ std::string JitCache::generate_source(const LeafShape &shape, const std::vector<
     LeafSource ls = generate_leaf_source(shape, varying, literal_bits, alias, sparkle);
     std::ostringstream call;
     call << "leaf<FAST>(x" << (ls.tracks ? ", trk, tstride, tlimit, tt" : "");
-    for (uint32_t i = 0; i < ls.k; ++i) call << ", c[(j) * K + " << i << "]";
+    auto track_index = [&](uint32_t i) { for (size_t q = 0; q < ls.track_params.size(); ++q) if (ls.track_params[q] == i) return (int)q; return -1; };
+    for (uint32_t i = 0; i < ls.k; ++i) {
+        const int q = track_index(i);
+        if (q >= 0) call << ", tv[(j) * NT + " << q << "]";
+        else call << ", c[(j) * K + " << i << "]";
+    }
     call << ")";
+    std::ostringstream loads;   // TRACK_LOADS(dst, src): the 8 leaves' track values of a group whose parameters are in src
+    for (int j = 0; j < 8; ++j)
+        for (size_t q = 0; q < ls.track_params.size(); ++q)
+            loads << " dst[" << j << " * NT + " << q << "] = jit_track(trk, tstride, tlimit, tt, src[" << j << " * K + " << ls.track_params[q] << "]);";
     std::ostringstream src;
     src << "#pragma clang fp contract(off)\n";
     src << FR_STR(FR_JIT_ARGS_TEXT) << "\n";
     src << "#define K " << ls.k << "\n#define NIN " << shape.input_slots.size() << "\n#define HAS_MOD1 " << (ls.has_mod1 ? 1 : 0)
         << "\n#define FRACT_INPUTS " << ls.fract_inputs << "u\n";
     src << "#define LEAF_CALL(j) " << call.str() << "\n";
+    src << "#define NT " << ls.track_params.size() << "\n#define TRACK_LOADS(dst, src)" << loads.str() << "\n";
     src << (ls.tracks ? "#define TRACK_PARAMS , const float *trk, unsigned long long tstride, unsigned tlimit, unsigned long long tt\n#define TRACK_ARGS , a.tracks, a.track_stride, a.track_limit, tt\n"
                       : "#define TRACK_PARAMS\n#define TRACK_ARGS\n");
     std::string body = kSkeleton;
@@ -253,8 +285,8 @@ static std::string disk_key_text(const std::string &src, const std::string &arch
     (void)hiprtcVersion(&major, &minor);
     if (hipRuntimeGetVersion(&rt) != hipSuccess) { (void)hipGetLastError(); rt = 0; }
     if (hipDriverGetVersion(&drv) != hipSuccess) { (void)hipGetLastError(); drv = 0; }
-    // "fr-jit-3": bumped whenever this engine's code generators change what they print for the same request
-    std::string key = "fr-jit-3|" + arch + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) + "|hip " +
+    // "fr-jit-4": bumped whenever this engine's code generators change what they print for the same request
+    std::string key = "fr-jit-4|" + arch + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) + "|hip " +
                       std::to_string(HIP_VERSION_MAJOR) + "." + std::to_string(HIP_VERSION_MINOR) + "." + std::to_string(HIP_VERSION_PATCH) + " " +
                       HIP_VERSION_GITHASH + "|runtime " + std::to_string(rt) + "|driver " + std::to_string(drv) + "|";
     for (const char *o : kJitOptions) { key += o; key += ' '; }

@@ -95,7 +95,8 @@ struct LeafSource {
     uint32_t k = 1;              // parameters per leaf (>= 1)
     bool has_mod1 = false;       // the leaf contains a Modulo(x, 1.0)
     uint32_t fract_inputs = 0;   // mask of the inputs its arguments depend on
-    bool tracks = false;         // the leaf takes (trk, tstride, tt) after x: it reads per-leaf track rows (LEAF_TRACK)
+    bool tracks = false;         // the leaf takes (trk, tstride, tlimit, tt) after x: it reads track rows (LEAF_TRACK)
+    std::vector<uint32_t> track_params;   // parameters (0 .. k-1) that are per-leaf track slots: the leaf takes the row's VALUE there
 };
 LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> &varying, const std::vector<uint32_t> &literal_bits,
                                 const std::vector<uint32_t> &alias, bool sparkle = false);

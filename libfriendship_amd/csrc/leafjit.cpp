@@ -109,7 +109,9 @@ LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> 
             break;
         case OP_INPUT: leaf << "x[" << o.a << "]"; dep[i] = 1u << o.a; break;
         case LEAF_TRACK:
-            if (varying[o.a]) leaf << "jit_track(trk, tstride, tlimit, tt, p" << pidx[o.a] << ")";
+            // a per-leaf track: the kernel loads the value one group ahead and hands it in where the slot number's parameter
+            // would be (jit.cpp wave_sum); a slot common to all leaves is loaded here (loop-invariant: once per wave)
+            if (varying[o.a]) leaf << "p" << pidx[o.a];
             else { std::snprintf(buf, sizeof buf, "jit_track(trk, tstride, tlimit, tt, __builtin_bit_cast(float, 0x%08xu))", literal_bits[o.a]); leaf << buf; }
             break;
         case OP_SUM2: {
@@ -188,6 +190,13 @@ LeafSource generate_leaf_source(const LeafShape &shape, const std::vector<bool> 
     out.has_mod1 = has_mod1;
     out.fract_inputs = fract_inputs;
     out.tracks = tracks;
+    for (const LeafShape::Op &o : shape.ops)
+        if (o.op == LEAF_TRACK && varying[o.a]) {
+            const uint32_t pi = (uint32_t)pidx[o.a];
+            bool seen = false;
+            for (uint32_t q : out.track_params) seen = seen || q == pi;
+            if (!seen) out.track_params.push_back(pi);
+        }
     out.text = std::string(sparkle ? "#define FR_SPARKLE 1\n" : "#define FR_SPARKLE 0\n") + kLeafHelpers + leaf.str();
     return out;
 }

@@ -1057,7 +1057,7 @@ static void track_leaves_are_matched_and_generated() {
         CHECK(a == first + 2 * k && c == first + 2 * k + 1);
     }
     LeafSource ls = generate_leaf_source(vm.shape, vm.varying, vm.literal_bits, vm.alias);
-    CHECK(ls.tracks && ls.k == 2);
+    CHECK(ls.tracks && ls.k == 2 && ls.track_params.size() == 2);   // both parameters are per-leaf tracks: the leaf takes the rows' values
     std::string base = "/tmp/fr_trackleaf_" + std::to_string((long)getpid());
     FILE *f = std::fopen((base + ".cpp").c_str(), "w");
     CHECK(f != nullptr);
@@ -1093,7 +1093,12 @@ static void track_leaves_are_matched_and_generated() {
         for (uint32_t t = 0; t < T; ++t)
             for (size_t li = 0; li < leaf_ids.size(); ++li) {
                 const float x0 = mat[t];   // slot 0's row
-                const float got = leaf(&x0, mat.data(), T, limit, t, &vm.params[li * 2]);
+                float vals[2];   // what the kernel's TRACK_LOADS hands the leaf: the row's value at t, +0 for a row not supplied
+                for (int q = 0; q < 2; ++q) {
+                    const uint32_t slot = f32_to_bits(vm.params[li * 2 + q]);
+                    vals[q] = slot < limit ? mat[(size_t)slot * T + t] : 0.0f;
+                }
+                const float got = leaf(&x0, mat.data(), T, limit, t, vals);
                 const float expect = flat_eval(fg, leaf_ids[li], t, in);
                 CHECK(f32_to_bits(got) == f32_to_bits(expect) || (got != got && expect != expect));
             }

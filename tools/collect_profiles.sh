@@ -24,8 +24,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_d" -- $BENCH
 # 4b. short blocks: the short-call kernel under the tracer (T = 64)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_short" -- $BENCH --frames 64 --steps 400 --warmup 40 --repeats 3 \
           > "$OUT/${TAG}_short64_bench_under_rocprof.json" 2> "$OUT/trace_short.err"
-# 4c. the HBM-bound variant: voices whose w / amp are track rows (tools/track_bench.py), T = 1024: kernel time, then HBM bytes
-TRACKS="python3 $R/tools/track_bench.py --frames 1024"
+# 4c. the HBM-bound variant: voices whose w / amp are track rows (tools/track_bench.py), T = 4800: kernel time, then HBM bytes
+TRACKS="python3 $R/tools/track_bench.py --frames 4800"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_tracks" -- $TRACKS --steps 40 --json > "$OUT/${TAG}_tracks_under_rocprof.txt" 2> "$OUT/trace_tracks.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_tracks" -- $TRACKS --steps 4 > /dev/null 2> "$OUT/pmc_fetch_tracks.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_tracks" -- $TRACKS --steps 4 > /dev/null 2> "$OUT/pmc_write_tracks.err"

@@ -44,7 +44,7 @@ summ = {
         "clock_ghz_from_GRBM_GUI_ACTIVE": out["GRBM_GUI_ACTIVE"]["mean"] / 8 / avg_s / 1e9 if avg_s else None,
     },
 }
-# the HBM-bound variant (tools/track_bench.py --frames 1024): the hipRTC-built bank kernel reading track rows
+# the HBM-bound variant (tools/track_bench.py --frames 4800): the hipRTC-built bank kernel reading track rows
 tr = {}
 for name in ("pmc_fetch_tracks", "pmc_write_tracks"):
     for f in glob.glob(f"{src}/{name}/*/*counter_collection.csv"):
@@ -53,20 +53,20 @@ for name in ("pmc_fetch_tracks", "pmc_write_tracks"):
             if r["Kernel_Name"].startswith("jit_bank"):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
-            # (the priming call -- one long launch that reads no tracks -- is not a step: fewest bytes read, most written)
-            v = sorted(v)[1:] if k == "FETCH_SIZE" else sorted(v)[:-1]
-            tr[k] = {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
+            # (the priming call -- one long launch that reads no tracks -- is not a step: the median of the launches is a step's figure)
+            v = sorted(v)
+            tr[k] = {"launches": len(v), "mean": v[len(v) // 2], "min": v[0], "max": v[-1], "mean_is": "median of the launches (one of them is the priming call)"}
 tstats = {}
 for f in glob.glob(f"{src}/trace_tracks/*/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         if r["Name"].startswith("jit_bank"):
             tstats = {"calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
 if "FETCH_SIZE" in tr and "WRITE_SIZE" in tr:
-    Tt = 1024
+    Tt = 4800
     alg = 8.0 * V * P * Tt + 4.0 * Tt + 4.0 * V * Tt
     summ["tracks"] = {
-        "command": "python3 tools/track_bench.py --frames 1024 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; --kernel-trace --stats for the time)",
-        "kernel": "jit_bank (hipRTC: the 35-op leaf reading two track rows per partial)", "per": "launch (one 1024-frame call, 524289 input rows)",
+        "command": "python3 tools/track_bench.py --frames 4800 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; --kernel-trace --stats for the time)",
+        "kernel": "jit_bank (hipRTC: the 35-op leaf reading two track rows per partial)", "per": "launch (one 4800-frame call, 524289 input rows: the jit_bank launch; its pieces are added up by chunk_combine_kernel, 5 MB more)",
         "kernel_trace_stats": tstats, "counters": tr,
         "derived": {"hbm_read_bytes": tr["FETCH_SIZE"]["mean"] * 1024 * 2, "hbm_write_bytes": tr["WRITE_SIZE"]["mean"] * 1024,
                     "hbm_traffic_bytes": (2 * tr["FETCH_SIZE"]["mean"] + tr["WRITE_SIZE"]["mean"]) * 1024, "algorithmic_bytes": alg,
@@ -75,9 +75,9 @@ if "FETCH_SIZE" in tr and "WRITE_SIZE" in tr:
                     "fetch_note": "FETCH_SIZE / WRITE_SIZE are KiB.  The read figure carries the gfx950 correction of MI355X_MICROARCH.md (HBM section): "
                                   "FETCH_SIZE reports exactly half the bytes of a coalesced streaming read (128-B requests tallied at 64 B).  The guide "
                                   "calibrates that for 16 B per lane and asks for a calibration of other widths on a known byte count: here the wave's "
-                                  "load instruction covers 256 contiguous bytes (4 B per lane), every byte of the 2.15 GB matrix is read exactly once per "
-                                  "launch (no reuse; the matrix is 8x the Infinity Cache), so the launch cannot fetch less than the matrix -- the raw "
-                                  "counter says 1.076 GB = 0.501 of it, i.e. the same factor.  WRITE_SIZE (256 KiB = 64 x 1024 x 4 B) is exact."}}
+                                  "load instruction covers 256 contiguous bytes (4 B per lane), every byte of the 10.07 GB matrix is read exactly once per "
+                                  "launch (no reuse; the matrix is 40x the Infinity Cache), so the launch cannot fetch less than the matrix -- the raw "
+                                  "counter reads half of it, i.e. the same factor.  WRITE_SIZE is the pieces' workspace (4 pieces x 64 voices x 4800 frames x 4 B)."}}
 json.dump(summ, open(f"{outdir}/{tag}_bank_pmc_summary.json", "w"), indent=1)
 if "tracks" in summ:
     print(json.dumps(summ["tracks"]["derived"], indent=1))
