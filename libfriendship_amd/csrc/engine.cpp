@@ -210,6 +210,7 @@ struct fr_renderer {
     bool last_pending = false;
     bool last_independent = false;       // the last asynchronous call left nothing behind that a later call reads or reuses
     bool used_scratch = false;           // this call used a buffer shared between calls (the chunk workspace)
+    bool host_pipelines = false;         // this call came on another stream than the previous, still pending one, and is independent of it
     bool overlapped_streams = false;     // independent calls were let loose on more than one stream since the last ordering point
     // Calls of a plan without delay lines, programs or pull rows touch only their own input rows and output buffer (and
     // append their own, disjoint part of the input history): on different streams they may overlap on the device.
@@ -1123,7 +1124,10 @@ struct fr_renderer {
                 sc.done();
                 return;
             }
-            bank_shape(a.log2_p, a.n_voices, blen, a.chunk_log2, a.frames_per_lane, a.waves_per_group, a.small_call, a.voices_per_wave);
+            // (a host that renders ahead on alternating streams gets launches that can overlap: a GPU's share of a voice-sharded
+            //  job, 8 x 4096 x 4800, takes 16.3 us per call that way against 20.9 with chunks + tickets on one stream -- the tail of
+            //  one call's few latency-bound waves fills with the next call's first; profiles/r03_fewvoices.txt)
+            bank_shape(a.log2_p, a.n_voices, blen, a.chunk_log2, a.frames_per_lane, a.waves_per_group, a.small_call, a.voices_per_wave, host_pipelines);
             if (a.voices_per_wave && !allow_multi) {   // A/B: the quarter-voice-per-wave kernel, one frame per lane
                 a.voices_per_wave = 0;
                 a.frames_per_lane = 1;
@@ -1634,6 +1638,8 @@ fr_status fr_fill_buffer_device(fr_renderer *r, float *d_out, uint32_t n_slots, 
         // call may still be writing.
         bool independent = r->plan_is_stateless(n_slots) && idx == r->head;
         for (uint32_t i = 0; independent && i < n_in_rows; ++i) independent = in_row_offsets[i + 1] - in_row_offsets[i] == n_times;
+        r->host_pipelines = independent && r->last_pending && r->last_stream != st;
+        struct Reset { fr_renderer *r; ~Reset() { r->host_pipelines = false; } } reset{r};
         r->order_after_previous(st, independent);
         r->used_scratch = false;
         r->ensure_plan(n_slots, st);

@@ -1017,7 +1017,7 @@ static bool short_kernel_enabled() {   // FR_BANK_SHORT=0: A/B against the time-
 }
 
 void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane,
-                uint32_t &waves_per_group, uint32_t &small_call, uint32_t &voices_per_wave) {
+                uint32_t &waves_per_group, uint32_t &small_call, uint32_t &voices_per_wave, bool many_pairs_whole) {
     frames_per_lane = 1;
     voices_per_wave = 0;
     small_call = 0;
@@ -1042,7 +1042,7 @@ void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &
             uint32_t c = log2_p;
             uint64_t wgs = pairs;
             while (c > 9 && (wgs < target || c > 13)) { --c; wgs *= 2; }
-            if (log2_p - c <= 8 && (few || (lumpy && c != log2_p))) {
+            if (log2_p - c <= 8 && (few || (lumpy && c != log2_p && !many_pairs_whole))) {
                 chunk_log2 = c;
                 waves_per_group = nw_env ? nw_env : (few ? 16u : 8u);
                 while ((1u << c) / waves_per_group < 8u) waves_per_group /= 2;   // a wave needs a whole group of 8

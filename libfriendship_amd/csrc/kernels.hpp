@@ -120,8 +120,10 @@ constexpr uint32_t BANK_STREAM_IDLE_MS = 2000; // the resident launch ends itsel
 // out = device pointer of the mapped [n_voices][64] host result (out_stride = 64), ws / tickets allocated for 64 frames.
 // Launches exactly n_voices * chunks workgroups.  idle_ms: 0 = BANK_STREAM_IDLE_MS.
 hipError_t launch_bank_stream(const BankArgs &a, BankStreamCtl *ctl_dev, BankStreamDev *dev, uint32_t idle_ms, hipStream_t s);
+// `many_pairs_whole`: do not cut a job of more than 320 (voice, tile) pairs into chunks (the short-call kernel's tickets and
+// workspace are shared between calls, so such a launch cannot overlap with the next call on another stream).
 void bank_shape(uint32_t log2_p, uint32_t n_voices, uint64_t n_times, uint32_t &chunk_log2, uint32_t &frames_per_lane,
-                uint32_t &waves_per_group, uint32_t &small_call, uint32_t &voices_per_wave);
+                uint32_t &waves_per_group, uint32_t &small_call, uint32_t &voices_per_wave, bool many_pairs_whole = false);
 uint64_t bank_blocks(const BankArgs &a);
 bool bank_publishes_rows(const BankArgs &a);
 hipError_t launch_bank(const BankArgs &a, hipStream_t s);

@@ -94,7 +94,7 @@ hipError_t launch_pull(const PullArgs &a, hipStream_t) {
 }
 
 void bank_shape(uint32_t log2_p, uint32_t, uint64_t, uint32_t &chunk_log2, uint32_t &frames_per_lane, uint32_t &waves_per_group,
-                uint32_t &small_call, uint32_t &voices_per_wave) {
+                uint32_t &small_call, uint32_t &voices_per_wave, bool) {
     chunk_log2 = log2_p;   // (one chunk: the simulator never needs the combine workspace)
     frames_per_lane = 1;
     waves_per_group = 4;

@@ -2023,3 +2023,32 @@ def test_track_row_shared_by_every_leaf(hip_lib, oracle_lib):
             idx += T
         bank = hip.plan()["banks"][0]
         assert bank["tracks"] and bank["leaf_params"] == 1, bank
+
+
+def test_few_voice_calls_pipelined_on_two_streams(hip_lib):
+    """A host that renders ahead on alternating streams (a rank of a voice-sharded job: 8 x 4096 x 4800 per call): from the second
+    call on the launches are whole (voice, tile) pairs without shared scratch, so consecutive calls overlap on the device; every
+    call's buffer must hold the same bits as the same frames rendered by blocking calls on one stream."""
+    import torch
+    V, P, T, calls = 8, 4096, 4800, 8
+    tree = synth.additive_tree(V, P, seed=21, detune=True)
+    t = synth.time_ramp(0, calls * T)
+    with Renderer(hip_lib) as a, Renderer(hip_lib) as b:
+        synth.install(a, tree)
+        synth.install(b, tree)
+        exp = [b.fill_buffer(V, k * T, (k + 1) * T, [t[k * T:(k + 1) * T]]) for k in range(calls)]
+        d_t = torch.from_numpy(t).cuda()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [torch.empty((V, T), dtype=torch.float32, device="cuda") for _ in range(calls)]
+        torch.cuda.synchronize()
+        for k in range(calls):
+            a.fill_buffer_device(outs[k].data_ptr(), V, T, k * T, d_t[k * T:].data_ptr(), [0, T], streams[k % 2].cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(calls):
+            got = outs[k].cpu().numpy()
+            assert same_bits(got, exp[k]), f"call {k}: " + first_diff(got, exp[k])
+        # back on one stream: the chunked launch again, still the same bits
+        for k in range(2):
+            a.fill_buffer_device(outs[k].data_ptr(), V, T, (calls + k) * T, d_t[k * T:].data_ptr(), [0, T], streams[0].cuda_stream)
+        torch.cuda.synchronize()
+        assert same_bits(outs[1].cpu().numpy(), exp[1])
