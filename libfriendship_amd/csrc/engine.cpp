@@ -925,14 +925,11 @@ struct fr_renderer {
         // are brought up to date by replaying every frame from 0 in chunks -- the ring-bound banks and the fused programs over
         // [c0, c0 + len), nothing written to the output -- before the call's own frames run in steady-state form.
         constexpr uint64_t FB_CHUNK = 16384, FB_MAX_REPLAY = 1ull << 28;
-        const bool fb_replay = sp.feedback && !(plan.stage_valid && plan.stage_end == idx) && idx != 0;
-        if (sp.feedback) {
-            if (history_frames != 0) throw Error(FR_ERR_UNSUPPORTED, "feedback through Delay needs the full input history (fr_config.history_frames = 0)");
-            if (fb_replay && idx > FB_MAX_REPLAY)
-                throw Error(FR_ERR_UNSUPPORTED, "a feedback loop's state at frame " + std::to_string(idx) + " would take replaying more than 2^28 frames");
-        }
+        if (sp.feedback && history_frames != 0)
+            throw Error(FR_ERR_UNSUPPORTED, "feedback through Delay needs the full input history (fr_config.history_frames = 0)");
         if (sp.uses_rings()) {
-            uint64_t need = sp.lmax + std::max<uint64_t>(n_times, fb_replay ? FB_CHUNK : 0);
+            // (a feedback plan's rings always have room for a replay chunk: growing them later would lose the loop's state)
+            uint64_t need = sp.lmax + std::max<uint64_t>(n_times, sp.feedback ? FB_CHUNK : 0);
             uint64_t cap = 1024;
             while (cap < need) cap <<= 1;
             if (cap > ring_cap) {
@@ -946,6 +943,10 @@ struct fr_renderer {
             if (!(plan.stage_valid && plan.stage_end == idx)) w0 = idx > sp.lmax ? idx - sp.lmax : 0;
             if (sp.feedback) w0 = idx;   // (the replay below has brought the rings to idx by the time this window runs)
         }
+        // (decided AFTER the rings may have been re-allocated above: a longer call than any before loses what they held)
+        const bool fb_replay = sp.feedback && !(plan.stage_valid && plan.stage_end == idx) && idx != 0;
+        if (fb_replay && idx > FB_MAX_REPLAY)
+            throw Error(FR_ERR_UNSUPPORTED, "a feedback loop's state at frame " + std::to_string(idx) + " would take replaying more than 2^28 frames");
         const uint64_t w_len = idx + n_times - w0;
         // Split voices (partial-block sharding): every rank renders its sub-trees over the SAME window -- the look-back
         // window when any split voice feeds a ring (lmax, ring capacity and validity are the same on every rank: same

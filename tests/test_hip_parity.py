@@ -1794,6 +1794,8 @@ def test_feedback_echo(hip_lib, oracle_lib, d):
             r.on_del_edge(1, 4, f32_bits(0.5), 1)
             r.on_add_edge(1, 4, f32_bits(-0.25), 1)
         _fb_calls(hip, ref, 1, [(1064, 64), (1128, 8), (10, 40)], seed=d + 1)
+        if d >= 64:   # a steady call longer than anything the rings were sized for: they are re-allocated, the loop's state replayed
+            _fb_calls(hip, ref, 1, [(50, 40000)], seed=d + 2)
 
 
 def test_feedback_loop_with_rows_inside_and_a_tap_behind(hip_lib, oracle_lib):
