@@ -2054,3 +2054,22 @@ def test_few_voice_calls_pipelined_on_two_streams(hip_lib):
             a.fill_buffer_device(outs[k].data_ptr(), V, T, (calls + k) * T, d_t[k * T:].data_ptr(), [0, T], streams[0].cuda_stream)
         torch.cuda.synchronize()
         assert same_bits(outs[1].cpu().numpy(), exp[1])
+
+
+def test_feedback_inside_composite_instances(hip_lib, oracle_lib):
+    """A composite effect whose own graph holds the loop (an echo: out = x = in + 0.5 * Delay(x, 2)), instantiated twice in series:
+    each instance context gets its own cut (two OP_FBREF leaves), rows on the inner and the outer instance."""
+    nodes = [(1000, Effect.primitive("F32Constant")), (1, Effect.primitive("Sum2")), (2, Effect.primitive("Delay")), (3, Effect.primitive("Multiply"))]
+    edges = [(0, 1, 0, 0), (3, 1, 0, 1), (1, 2, 0, 0), (1000, 2, f32_bits(2.0), 1), (2, 3, 0, 0), (1000, 3, f32_bits(0.5), 1), (1, 0, 0, 0)]
+    echo = Effect.graph(nodes, edges)
+    with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+        for r in (hip, ref):
+            r.on_add_node(5, echo)
+            r.on_add_node(6, echo)
+            r.on_add_edge(0, 5, 0, 0)
+            r.on_add_edge(5, 6, 0, 0)
+            r.on_add_edge(6, 0, 0, 0)
+            r.on_add_edge(5, 0, 0, 1)
+        _fb_calls(hip, ref, 2, [(0, 20), (20, 33), (100, 10), (7, 5)], seed=31)
+        plan = hip.plan()
+        assert plan["feedback"] and plan["feedback_loops"] == 2, plan

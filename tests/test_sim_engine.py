@@ -492,3 +492,7 @@ def test_feedback_that_cannot_be_evaluated_is_refused(sim):
 @pytest.mark.parametrize("seed0", [0, 40])
 def test_random_feedback_graphs(sim, oracle_lib, seed0):
     G.test_random_feedback_graphs(sim, oracle_lib, seed0)
+
+
+def test_feedback_inside_composite_instances(sim, oracle_lib):
+    G.test_feedback_inside_composite_instances(sim, oracle_lib)
