@@ -828,7 +828,7 @@ struct fr_renderer {
             HIP_CHECK(hipMemcpyAsync(p.d_instrs.p, p.sp.instrs.data(), p.sp.instrs.size() * sizeof(StageInstr), hipMemcpyHostToDevice, st));
             HIP_CHECK(hipMemcpyAsync(p.d_progs.p, p.sp.progs.data(), p.sp.progs.size() * sizeof(StageProg), hipMemcpyHostToDevice, st));
             StageJitPlan sj;
-            if (allow_jit && stage_jit_mode != 0 && plan_stage_jit(p.sp.progs, p.sp.instrs, 32, stage_jit_mode == 2, sj, mirror.sparkle)) {
+            if (allow_jit && stage_jit_mode != 0 && plan_stage_jit(p.sp.progs, p.sp.instrs, 32, stage_jit_mode == 2, sj, mirror.sparkle, !p.sp.feedback ? 2u : (p.sp.fused_stride >= 16 ? 16u : 1u))) {
                 try {
                     p.stage_jit = jit_cache.get_source(sj.source, "jit_stage");
                     if (!p.stage_jit) {   // still compiling: the interpreter serves the calls until the plan is rebuilt
@@ -1191,6 +1191,7 @@ struct fr_renderer {
                 a.w0 = s0;
                 a.w_len = slen;
                 a.stride = launch_stride;
+                a.carry_only = (launch_stride && sp.feedback && sp.fused_carry_only) ? 1u : 0u;
                 Scope sc(this, &t_stage, st);
                 HIP_CHECK(launch_jit_stage(*plan.stage_jit, a, std::min<uint32_t>(count - off, 65535u), st));
                 sc.done();
@@ -1211,6 +1212,7 @@ struct fr_renderer {
                 a.w0 = s0;
                 a.w_len = slen;
                 a.stride = launch_stride;
+                a.carry_only = (launch_stride && sp.feedback && sp.fused_carry_only) ? 1u : 0u;
                 a.sparkle = mirror.sparkle ? 1u : 0u;
                 Scope sc(this, &t_stage, st);
                 HIP_CHECK(launch_stage(a, st));

@@ -1487,6 +1487,7 @@ __device__ __forceinline__ float stage_load(const StageArgs &a, const StageInstr
 
 __global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
     __shared__ float tmp[STAGE_REGS][256];
+    __shared__ float carry[2][STAGE_CARRY][256];   // (kernels.hpp STAGE_CARRY: what this thread stored one iteration ago)
     const uint64_t wi0 = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     // one frame per thread, or (stride != 0) the frames wi0, wi0 + stride, ... of the window in order: the planner's
     // fused_stride divides every delay with which this launch reads a ring it also writes, so a thread reads only what it
@@ -1497,14 +1498,20 @@ __global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
     const uint32_t tid = threadIdx.x;
     const StageInstr *gins = a.instrs + pg.first_instr;
     auto fetch = [&](uint32_t i) -> StageInstr { return gins[i]; };
-    for (uint64_t wi = wi0; wi < a.w_len; wi += span) {
+    uint32_t par = 0;
+    for (uint64_t wi = wi0; wi < a.w_len; wi += span, par ^= 1u) {
     const uint64_t t = a.w0 + wi;
+    const bool carried = wi != wi0;   // (the first iteration reads what an earlier launch stored)
+    auto load = [&](const StageInstr &in) -> float {
+        if (in.op == S_READ && in.imm != 0u && in.imm <= STAGE_CARRY && carried) return carry[par ^ 1u][in.imm - 1u][tid];
+        return stage_load(a, in, t);
+    };
     // 1. the program's loads (ring reads at t - d, inputs, constants), all in flight together
     {
         float ld[STAGE_MAX_HOISTED];
 #pragma unroll
         for (uint32_t i = 0; i < STAGE_MAX_HOISTED; ++i)
-            if (i < pg.n_loads) ld[i] = stage_load(a, fetch(i), t);
+            if (i < pg.n_loads) ld[i] = load(fetch(i));
 #pragma unroll
         for (uint32_t i = 0; i < STAGE_MAX_HOISTED; ++i)
             if (i < pg.n_loads) tmp[fetch(i).dst][tid] = ld[i];
@@ -1519,7 +1526,10 @@ __global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
         case S_DIV: v = tmp[in.a][tid] / tmp[in.b][tid]; break;
         case S_MOD: v = prim_mod(tmp[in.a][tid], tmp[in.b][tid]); break;
         case S_MIN: v = prim_min(tmp[in.a][tid], tmp[in.b][tid], a.sparkle != 0u); break;
-        case S_STORE: a.rings[(size_t)in.buf * (a.ring_mask + 1) + (t & a.ring_mask)] = tmp[in.a][tid]; continue;
+        case S_STORE:
+            a.rings[(size_t)in.buf * (a.ring_mask + 1) + (t & a.ring_mask)] = tmp[in.a][tid];
+            if (in.imm != 0u && in.imm <= STAGE_CARRY) carry[par][in.imm - 1u][tid] = tmp[in.a][tid];
+            continue;
         case S_READ_DYN: case S_READ_INPUT_DYN: case S_STEP_DYN: {   // Delay by a signal amount (reference.rs:200-215)
             uint64_t fr;
             v = 0.0f;
@@ -1530,14 +1540,14 @@ __global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
             }
             break;
         }
-        default: v = stage_load(a, in, t); break;   // a load that was not hoisted (register budget)
+        default: v = load(in); break;   // a load that was not hoisted (register budget)
         }
         tmp[in.dst][tid] = v;
     }
     const float r = tmp[pg.result_reg][tid];
     if (pg.dst_ring != 0xFFFFFFFFu) a.rings[(size_t)pg.dst_ring * (a.ring_mask + 1) + (t & a.ring_mask)] = r;
     if (pg.out_row >= 0 && t >= a.idx) a.out[(size_t)pg.out_row * a.n_times + (t - a.idx)] = r;
-    if (a.stride) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stride's ring stores are in memory before the next one reads them
+    if (a.stride && !a.carry_only) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stride's ring stores are in memory before the next one reads them
     }
 }
 

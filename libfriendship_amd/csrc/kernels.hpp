@@ -181,7 +181,15 @@ struct StageArgs {
     uint64_t stride;           // 0: thread wi computes frame w0 + wi; else the frames w0 + wi + k * stride inside the window, in order
                                // (StagedPlan::fused_stride: a long steady call of the fused form in ONE launch)
     uint32_t sparkle;          // FR_SEMANTICS_SPARKLE
+    uint32_t carry_only;       // strided launches: every read of a ring that this launch stores comes from the carry (below), so
+                               // a stride's stores need not be in memory before the next stride starts
 };
+// Carry (feedback plans, stage.cpp): a strided thread that reads back, `stride` frames later, what it stored to a ring in its
+// previous iteration need not go through memory for it -- a dependent L2 round trip per iteration, all there is to a one-sample
+// loop.  S_STORE.imm = carry slot + 1 keeps the stored value (double-buffered by iteration parity, so that the order of stores
+// and reads inside an iteration does not matter); S_READ.imm = carry slot + 1 (only where d_lo == the launch's stride and the
+// ring is one the program stores) takes it from there, except in the thread's first iteration of the launch.  0 = no carry.
+constexpr uint32_t STAGE_CARRY = 8;
 hipError_t launch_stage(const StageArgs &a, hipStream_t s);
 
 // One step of the partial-block exchange (friendship_render.h FR_SHARD_PARTIALS): row i, window frame t:

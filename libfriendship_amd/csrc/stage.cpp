@@ -866,6 +866,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
             std::vector<StageInstr> minstrs;
             std::vector<StageProg> mprogs;
             std::vector<uint32_t> clevel(comps.size(), 0);
+            bool carry_only = true;
             for (size_t c = 0; c < comps.size(); ++c) {   // (producers first: every dependency's level is final)
                 for (uint32_t i : comps[c])
                     for (uint32_t q : deps[i])
@@ -889,8 +890,36 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
                         mp.out_row = pg.out_row;
                     }
                 }
+                // Carry (kernels.hpp STAGE_CARRY): the program's own result becomes an explicit store too, every ring it stores
+                // gets a slot (the first 8), and a read of one of them exactly `stride` frames back -- what the same thread stored
+                // one iteration ago -- is marked to come from the slot.  A one-sample loop then runs without a memory round trip
+                // per frame.
+                if (mp.dst_ring != NO_RING) {
+                    StageInstr stx{};
+                    stx.op = S_STORE; stx.a = (uint8_t)mp.result_reg; stx.buf = mp.dst_ring;
+                    minstrs.push_back(stx);
+                    mp.dst_ring = NO_RING;
+                }
                 mp.n_instr = (uint32_t)(fbase + minstrs.size()) - mp.first_instr;
                 if (mp.n_instr > MAX_PROG_INSTR) throw Error(FR_ERR_UNSUPPORTED, "a feedback loop's expression exceeds the stage programs' budget");
+                {
+                    const uint64_t stride = min_delay == ~0ull ? 0 : gcd_delay;
+                    std::unordered_map<uint32_t, uint32_t> slot_of;   // ring -> carry slot + 1 (0: it has none)
+                    StageInstr *ins = minstrs.data() + (mp.first_instr - fbase);
+                    for (uint32_t k = 0; k < mp.n_instr; ++k)
+                        if (ins[k].op == S_STORE) {
+                            auto it = slot_of.find(ins[k].buf);
+                            if (it == slot_of.end()) it = slot_of.emplace(ins[k].buf, slot_of.size() < STAGE_CARRY ? (uint32_t)slot_of.size() + 1u : 0u).first;
+                            ins[k].imm = it->second;
+                        }
+                    for (uint32_t k = 0; k < mp.n_instr; ++k) {
+                        if (ins[k].op != S_READ) continue;
+                        auto it = slot_of.find(ins[k].buf);
+                        if (it == slot_of.end()) continue;                      // a bank's ring, or one an earlier level stored
+                        if (stride != 0 && ins[k].d_lo == stride && it->second != 0u) ins[k].imm = it->second;
+                        else { ins[k].imm = 0xFFu; carry_only = false; }        // further back than one iteration: through memory, in order
+                    }
+                }
                 mprogs.push_back(mp);
             }
             std::vector<size_t> order(mprogs.size());
@@ -901,6 +930,7 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
             sp.fused_max_frames = 0;
             sp.fused_stride = min_delay == ~0ull ? 0 : gcd_delay;
             sp.feedback = true;
+            sp.fused_carry_only = carry_only;
             sp.instrs.insert(sp.instrs.end(), minstrs.begin(), minstrs.end());
             sp.fused_level_first.clear();
             for (size_t k = 0; k < order.size(); ++k) {
@@ -949,8 +979,11 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
                 const size_t f0 = pg.first_instr - sp.instrs.size();
                 for (uint32_t i = 0; i < pg.n_instr; ++i) if (finstrs[f0 + i].op == S_STORE) mine.insert(finstrs[f0 + i].buf);
                 for (uint32_t i = 0; i < pg.n_instr && sp.fused_stride; ++i) {
-                    const StageInstr &in = finstrs[f0 + i];
+                    StageInstr &in = finstrs[f0 + i];
                     if (in.op == S_READ && !bank_rings.count(in.buf) && !mine.count(in.buf)) sp.fused_stride = 0;
+                    // (a ring the program stores itself: a strided thread must read it AFTER its own earlier stores -- compiled
+                    //  programs fetch their other loads one iteration ahead, kernels.hpp STAGE_CARRY)
+                    if (in.op == S_READ && mine.count(in.buf)) in.imm = 0xFFu;
                 }
             }
             sp.instrs.insert(sp.instrs.end(), finstrs.begin(), finstrs.end());

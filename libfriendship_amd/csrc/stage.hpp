@@ -83,6 +83,7 @@ struct StagedPlan {
     bool feedback = false;
     std::vector<uint32_t> fused_level_first;
     uint32_t post_first = 0, post_count = 0;
+    bool fused_carry_only = false;   // every fused program reads the rings it stores through the carry only (kernels.hpp STAGE_CARRY)
     uint32_t n_rings = 0;
     uint64_t lmax = 0;                     // deepest look-back any ring must serve
     // How far back in the INPUT history the staged part can read when it computes frame t (ring look-backs + the delays

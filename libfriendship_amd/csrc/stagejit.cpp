@@ -1,5 +1,6 @@
 // stagejit.cpp -- source generation for compiled stage programs (see jit.hpp).  No HIP runtime calls in this file:
 // tests/cpp/plan_tests.cpp builds it for the CPU and runs the generated functions against the oracle.
+#include <algorithm>
 #include <cstdio>
 #include <map>
 #include <sstream>
@@ -93,18 +94,49 @@ extern "C" __global__ void __launch_bounds__(256) jit_stage(JitStageArgs a) {
     if (wi >= span) return;
     const JitStageProg pg = a.progs[blockIdx.y];
     cu32 P = (cu32)(a.ptab + pg.param_off);
-    for (u64 off = wi; off < a.w_len; off += span) {
-        const u64 t = a.w0 + off;
-        float r;
-        switch (pg.shape) {
-SHAPE_CASES
-        default: r = 0.0f; break;
+    // carry (kernels.hpp STAGE_CARRY): what this thread stored to its rings one iteration ago stays in registers
+    float cy[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, ny[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    // A strided thread's loads that depend on the frame alone (inputs, rings of banks and of earlier launches) are requested a
+    // BLOCK of BLK iterations at a time, then the block's iterations computed: the iterations of a short loop cost a memory
+    // latency per BLK instead of one each (a one-sample loop runs one thread per program through every frame of the call).
+    float ldb[BLK][MAXLD];
+    for (u64 base = wi; base < a.w_len; base += (u64)BLK * span) {
+#pragma unroll
+        for (int b = 0; b < BLK; ++b) {
+            const u64 off = base + (u64)b * span;
+#pragma unroll
+            for (int i = 0; i < MAXLD; ++i) ldb[b][i] = 0.0f;
+            if (off < a.w_len) {
+                const u64 t = a.w0 + off;
+                float *ldn = ldb[b];
+                switch (pg.shape) {
+LOAD_CASES
+                default: break;
+                }
+            }
         }
-        if (pg.dst_ring != 0xFFFFFFFFu) ring_store(a, pg.dst_ring, t, r);
-        if (pg.out_row >= 0 && t >= a.idx) a.out[(size_t)pg.out_row * a.n_times + (t - a.idx)] = r;
+#pragma unroll
+        for (int b = 0; b < BLK; ++b) {
+            const u64 off = base + (u64)b * span;
+            if (off < a.w_len) {
+                const u64 t = a.w0 + off;
+                const bool carried = off != wi;
+                (void)carried;
+                const float *ld = ldb[b];
+                float r;
+                switch (pg.shape) {
+SHAPE_CASES
+                default: r = 0.0f; break;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) cy[i] = ny[i];
+                if (pg.dst_ring != 0xFFFFFFFFu) ring_store(a, pg.dst_ring, t, r);
+                if (pg.out_row >= 0 && t >= a.idx) a.out[(size_t)pg.out_row * a.n_times + (t - a.idx)] = r;
 #if defined(__AMDGCN__)
-        if (a.stride) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stride's ring stores are in memory before the next one reads them
+                if (a.stride && !a.carry_only) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stride's ring stores are in memory before the next one reads them
 #endif
+            }
+        }
     }
 }
 )JIT";
@@ -120,7 +152,7 @@ bool literal_worthy(uint32_t bits) {
 }  // namespace
 
 bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<StageInstr> &instrs, uint32_t max_shapes, bool force,
-                    StageJitPlan &out, bool sparkle) {
+                    StageJitPlan &out, bool sparkle, uint32_t block) {
     if (progs.empty()) return false;
     struct Shape { uint32_t first; std::vector<uint32_t> members; std::vector<bool> literal; };
     std::map<std::string, uint32_t> ids;
@@ -133,6 +165,7 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
         for (uint32_t i = 0; i < pg.n_instr; ++i) {
             const StageInstr &in = instrs[pg.first_instr + i];
             key.push_back((char)in.op); key.push_back((char)in.dst); key.push_back((char)in.a); key.push_back((char)in.b);
+            if (in.op == S_READ || in.op == S_STORE) key.push_back((char)in.imm);   // carry slot + 1 (kernels.hpp STAGE_CARRY)
         }
         key.push_back((char)pg.result_reg);
         auto it = ids.emplace(std::move(key), (uint32_t)shapes.size());
@@ -159,11 +192,44 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
     }
 
     // source
-    std::ostringstream fns, cases;
+    constexpr uint32_t MAXLD = 16;   // loads per program fetched ahead, a block of iterations at a time (the rest where they are used)
+    uint32_t max_nld = 1;
+    std::ostringstream fns, cases, load_cases;
     for (size_t si = 0; si < shapes.size(); ++si) {
         const Shape &s = shapes[si];
         const StageProg &p0 = progs[s.first];
-        fns << "__device__ __forceinline__ float shape" << si << "(const JitStageArgs &a, cu32 P, u64 t) {\n    (void)a; (void)P; (void)t;\n";
+        // loads that depend on the frame alone: their values are parameters `ld[]` of the shape function, produced by shapeN_ld
+        std::vector<int> ld_of(p0.n_instr, -1);
+        {
+            std::ostringstream lf;
+            lf << "__device__ __forceinline__ void shape" << si << "_ld(const JitStageArgs &a, cu32 P, u64 t, float *ld) {\n    (void)a; (void)P; (void)t; (void)ld;\n";
+            uint32_t kk = 0, nld = 0;
+            for (uint32_t i = 0; i < p0.n_instr; ++i) {
+                const StageInstr &in = instrs[p0.first_instr + i];
+                // (S_READ.imm != 0: a ring the program stores itself -- carried, or 0xFF: read through memory AFTER the stores of the
+                //  iterations before, so not ahead of them)
+                const bool pure = in.op == S_INPUT || in.op == S_READ_INPUT || (in.op == S_READ && in.imm == 0);
+                if (pure && nld < MAXLD) {
+                    lf << "    ld[" << nld << "] = ";
+                    if (in.op == S_INPUT) lf << "in_at(a, P[" << kk << "], t)";
+                    else if (in.op == S_READ) lf << "ring_read(a, P[" << kk << "], P[" << kk + 1 << "], t)";
+                    else lf << "in_delayed(a, P[" << kk << "], P[" << kk + 1 << "], t)";
+                    lf << ";\n";
+                    ld_of[i] = (int)nld++;
+                }
+                switch (in.op) {   // parameters consumed (the same walk as below)
+                case S_CONST: if (!s.literal[i]) kk += 1; break;
+                case S_INPUT: case S_STORE: case S_READ_DYN: case S_READ_INPUT_DYN: case S_STEP_DYN: kk += 1; break;
+                case S_READ: case S_READ_INPUT: case S_STEP: kk += 2; break;
+                default: break;
+                }
+            }
+            lf << "}\n";
+            fns << lf.str();
+            max_nld = std::max(max_nld, nld);
+        }
+        fns << "__device__ __forceinline__ float shape" << si << "(const JitStageArgs &a, cu32 P, u64 t, const float *ld, const float *cy, float *ny, bool carried) {\n"
+               "    (void)a; (void)P; (void)t; (void)ld; (void)cy; (void)ny; (void)carried;\n";
         int var_of[256];
         for (int &x : var_of) x = -1;
         std::vector<bool> is_one(p0.n_instr, false);
@@ -171,8 +237,15 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
         for (uint32_t i = 0; i < p0.n_instr; ++i) {
             const StageInstr &in = instrs[p0.first_instr + i];
             char buf[96];
+            if (ld_of[i] >= 0) {   // fetched ahead
+                fns << "    float v" << i << " = ld[" << ld_of[i] << "];\n";
+                k += in.op == S_INPUT ? 1 : 2;
+                var_of[in.dst] = (int)i;
+                continue;
+            }
             if (in.op == S_STORE) {
                 fns << "    ring_store(a, P[" << k << "], t, v" << var_of[in.a] << ");\n";
+                if (in.imm != 0 && in.imm <= 8) fns << "    ny[" << in.imm - 1 << "] = v" << var_of[in.a] << ";\n";
                 k += 1;
                 continue;
             }
@@ -186,7 +259,11 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
                 } else { fns << "f32(P[" << k << "])"; k += 1; }
                 break;
             case S_INPUT: fns << "in_at(a, P[" << k << "], t)"; k += 1; break;
-            case S_READ: fns << "ring_read(a, P[" << k << "], P[" << k + 1 << "], t)"; k += 2; break;
+            case S_READ:
+                if (in.imm != 0 && in.imm <= 8) fns << "(carried ? cy[" << in.imm - 1 << "] : ring_read(a, P[" << k << "], P[" << k + 1 << "], t))";
+                else fns << "ring_read(a, P[" << k << "], P[" << k + 1 << "], t)";
+                k += 2;
+                break;
             case S_READ_INPUT: fns << "in_delayed(a, P[" << k << "], P[" << k + 1 << "], t)"; k += 2; break;
             case S_STEP: fns << "step(P[" << k << "], P[" << k + 1 << "], t)"; k += 2; break;
             case S_READ_DYN: fns << "ring_read_dyn(a, P[" << k << "], v" << var_of[in.a] << ", t)"; k += 1; break;
@@ -205,14 +282,16 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
             var_of[in.dst] = (int)i;
         }
         fns << "    return v" << var_of[p0.result_reg] << ";\n}\n";
-        cases << "        case " << si << ": r = shape" << si << "(a, P, t); break;\n";
+        cases << "        case " << si << ": r = shape" << si << "(a, P, t, ld, cy, ny, carried); break;\n";
+        load_cases << "        case " << si << ": shape" << si << "_ld(a, P, t, ldn); break;\n";
     }
     std::ostringstream src;
-    src << "#pragma clang fp contract(off)\n#define FR_SPARKLE " << (sparkle ? 1 : 0) << "\n" << FR_STR(FR_JIT_STAGE_ARGS_TEXT) << "\n";
+    src << "#pragma clang fp contract(off)\n#define FR_SPARKLE " << (sparkle ? 1 : 0) << "\n#define MAXLD " << max_nld << "\n#define BLK " << std::max(1u, std::min(block, std::max(1u, 32u / max_nld))) << "\n" << FR_STR(FR_JIT_STAGE_ARGS_TEXT) << "\n";
     std::string body = kStageSkeleton;
     auto put = [&](const std::string &tag, const std::string &text) { body.replace(body.find(tag), tag.size(), text); };
     put("SHAPE_FUNCTIONS", fns.str());
     put("SHAPE_CASES", cases.str());
+    put("LOAD_CASES", load_cases.str());
     src << body;
     out.source = src.str();
     out.n_shapes = (uint32_t)shapes.size();
