@@ -1213,6 +1213,7 @@ struct fr_renderer {
                 a.w_len = slen;
                 a.stride = launch_stride;
                 a.carry_only = (launch_stride && sp.feedback && sp.fused_carry_only) ? 1u : 0u;
+                a.use_carry = (launch_stride && sp.feedback) ? 1u : 0u;
                 a.sparkle = mirror.sparkle ? 1u : 0u;
                 Scope sc(this, &t_stage, st);
                 HIP_CHECK(launch_stage(a, st));

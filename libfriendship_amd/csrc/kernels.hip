@@ -1487,7 +1487,10 @@ __device__ __forceinline__ float stage_load(const StageArgs &a, const StageInstr
 
 __global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
     __shared__ float tmp[STAGE_REGS][256];
-    __shared__ float carry[2][STAGE_CARRY][256];   // (kernels.hpp STAGE_CARRY: what this thread stored one iteration ago)
+    // (kernels.hpp STAGE_CARRY: what this thread stored one iteration ago; dynamic LDS, only launches of feedback plans ask for it:
+    //  the interpreter's 48 KB of registers already allow only three workgroups per CU)
+    extern __shared__ float carry_mem[];
+    auto carry = [&](uint32_t par, uint32_t slot) -> float & { return carry_mem[((size_t)par * STAGE_CARRY + slot) * 256u + threadIdx.x]; };
     const uint64_t wi0 = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     // one frame per thread, or (stride != 0) the frames wi0, wi0 + stride, ... of the window in order: the planner's
     // fused_stride divides every delay with which this launch reads a ring it also writes, so a thread reads only what it
@@ -1501,9 +1504,9 @@ __global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
     uint32_t par = 0;
     for (uint64_t wi = wi0; wi < a.w_len; wi += span, par ^= 1u) {
     const uint64_t t = a.w0 + wi;
-    const bool carried = wi != wi0;   // (the first iteration reads what an earlier launch stored)
+    const bool carried = wi != wi0 && a.use_carry != 0u;   // (the first iteration reads what an earlier launch stored)
     auto load = [&](const StageInstr &in) -> float {
-        if (in.op == S_READ && in.imm != 0u && in.imm <= STAGE_CARRY && carried) return carry[par ^ 1u][in.imm - 1u][tid];
+        if (in.op == S_READ && in.imm != 0u && in.imm <= STAGE_CARRY && carried) return carry(par ^ 1u, in.imm - 1u);
         return stage_load(a, in, t);
     };
     // 1. the program's loads (ring reads at t - d, inputs, constants), all in flight together
@@ -1528,7 +1531,7 @@ __global__ void __launch_bounds__(256) stage_kernel(StageArgs a) {
         case S_MIN: v = prim_min(tmp[in.a][tid], tmp[in.b][tid], a.sparkle != 0u); break;
         case S_STORE:
             a.rings[(size_t)in.buf * (a.ring_mask + 1) + (t & a.ring_mask)] = tmp[in.a][tid];
-            if (in.imm != 0u && in.imm <= STAGE_CARRY) carry[par][in.imm - 1u][tid] = tmp[in.a][tid];
+            if (in.imm != 0u && in.imm <= STAGE_CARRY && a.use_carry) carry(par, in.imm - 1u) = tmp[in.a][tid];
             continue;
         case S_READ_DYN: case S_READ_INPUT_DYN: case S_STEP_DYN: {   // Delay by a signal amount (reference.rs:200-215)
             uint64_t fr;
@@ -1556,7 +1559,8 @@ hipError_t launch_stage(const StageArgs &a, hipStream_t s) {
     if (a.n_progs > 65535u) return hipErrorInvalidValue;
     uint64_t bx = ((a.stride ? std::min(a.stride, a.w_len) : a.w_len) + 255) / 256;
     if (bx > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(stage_kernel, dim3((uint32_t)bx, a.n_progs), dim3(256), 0, s, a);
+    const size_t carry_bytes = a.use_carry ? (size_t)2 * STAGE_CARRY * 256 * sizeof(float) : 0;
+    hipLaunchKernelGGL(stage_kernel, dim3((uint32_t)bx, a.n_progs), dim3(256), carry_bytes, s, a);
     return hipGetLastError();
 }
 

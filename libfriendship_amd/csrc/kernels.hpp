@@ -183,6 +183,7 @@ struct StageArgs {
     uint32_t sparkle;          // FR_SEMANTICS_SPARKLE
     uint32_t carry_only;       // strided launches: every read of a ring that this launch stores comes from the carry (below), so
                                // a stride's stores need not be in memory before the next stride starts
+    uint32_t use_carry;        // the programs carry annotations (feedback plans): the launch gets the carry's LDS
 };
 // Carry (feedback plans, stage.cpp): a strided thread that reads back, `stride` frames later, what it stored to a ring in its
 // previous iteration need not go through memory for it -- a dependent L2 round trip per iteration, all there is to a one-sample
