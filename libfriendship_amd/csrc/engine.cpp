@@ -165,6 +165,7 @@ struct fr_renderer {
     DevBuf d_chunk_ws, d_chunk_rows;
     uint32_t d_chunk_rows_n = 0;
     bool jit_chunks = true;                 // FR_JIT_CHUNKS=0: one workgroup per (voice, tile) always (A/B)
+    uint32_t stage_block_env = 0;           // FR_STAGE_BLOCK: iterations per block of compiled strided programs (A/B; 0 = the rule in build_plan)
     uint64_t jit_chunk_target = 0;          // FR_JIT_CHUNK_TARGET: workgroups below which a voice is cut further (0: 1024, tracks 16384)
     // FR_HOST_MAPPED (A/B): bit 0 = kernels write the output through the mapping, bit 1 = the bank kernel reads the
     // input row through the mapping; 0 = the staged copies of round 1 (H2D row, D2H of the whole buffer)
@@ -828,7 +829,8 @@ struct fr_renderer {
             HIP_CHECK(hipMemcpyAsync(p.d_instrs.p, p.sp.instrs.data(), p.sp.instrs.size() * sizeof(StageInstr), hipMemcpyHostToDevice, st));
             HIP_CHECK(hipMemcpyAsync(p.d_progs.p, p.sp.progs.data(), p.sp.progs.size() * sizeof(StageProg), hipMemcpyHostToDevice, st));
             StageJitPlan sj;
-            if (allow_jit && stage_jit_mode != 0 && plan_stage_jit(p.sp.progs, p.sp.instrs, 32, stage_jit_mode == 2, sj, mirror.sparkle, !p.sp.feedback ? 2u : (p.sp.fused_stride >= 16 ? 16u : 1u))) {
+            if (allow_jit && stage_jit_mode != 0 && plan_stage_jit(p.sp.progs, p.sp.instrs, 32, stage_jit_mode == 2, sj, mirror.sparkle,
+                                                                              stage_block_env ? stage_block_env : ((p.sp.feedback && p.sp.fused_stride >= 16) ? 16u : 1u))) {
                 try {
                     p.stage_jit = jit_cache.get_source(sj.source, "jit_stage");
                     if (!p.stage_jit) {   // still compiling: the interpreter serves the calls until the plan is rebuilt
@@ -1449,6 +1451,7 @@ fr_status fr_renderer_create(const fr_config *cfg, fr_renderer **out) {
     if (const char *sv = std::getenv("FR_STAGE_JIT")) r->stage_jit_mode = sv[0] == '0' ? 0 : (sv[0] == '1' ? 1 : 2);
     if (const char *fv = std::getenv("FR_STAGE_STRIDED")) r->fused_strided_ok = fv[0] != '0';
     if (const char *cv = std::getenv("FR_JIT_CHUNKS")) r->jit_chunks = cv[0] != '0';
+    if (const char *bv = std::getenv("FR_STAGE_BLOCK")) r->stage_block_env = (uint32_t)std::max(0, std::atoi(bv));
     if (const char *cv = std::getenv("FR_JIT_CHUNK_TARGET")) r->jit_chunk_target = (uint64_t)std::max(1, std::atoi(cv));
     if (const char *xv = std::getenv("FR_EXCHANGE_TILES")) { r->x_max_tiles = (uint32_t)std::min(64, std::max(1, std::atoi(xv))); r->x_tiles_explicit = true; }
     if (const char *xv = std::getenv("FR_EXCHANGE_MIN_TILE")) { r->x_min_tile = (uint32_t)std::min(1 << 20, std::max(64, std::atoi(xv))); r->x_tiles_explicit = true; }

@@ -86,11 +86,12 @@ struct StageJitPlan {
 // Groups the programs by skeleton and writes the kernel source.  Returns false when specialisation is not worth a
 // compile: more than `max_shapes` skeletons, or (unless `force`) fewer than 4 programs per skeleton on average.
 // `block`: iterations of a strided thread whose frame-only loads are fetched together before any of them is computed (every shape
-// is inlined once per iteration of a block).  2 serves the few-stride launches of effects chains; feedback loops with many
-// iterations per thread take 16 when the stride leaves enough threads to be latency-bound (>= 16 frames), and 1 below that, where
-// a lone wave per program is bound by its instruction stream and every extra instruction counts (profiles/r03_feedback.txt).
+// is inlined once per iteration of a block).  Feedback loops with many iterations per thread take 16 when the stride leaves enough
+// threads to be latency-bound (>= 16 frames); 1 otherwise: below that a lone wave per program is bound by its instruction stream and
+// every extra instruction counts, and the 2-stride launches of effects chains measured the same at 1, 2 and 4
+// (profiles/r03_feedback.txt; FR_STAGE_BLOCK overrides).
 bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<StageInstr> &instrs, uint32_t max_shapes, bool force,
-                    StageJitPlan &out, bool sparkle = false, uint32_t block = 2);
+                    StageJitPlan &out, bool sparkle = false, uint32_t block = 1);
 
 // Text of `template <bool FAST> float leaf(const float *x, float p0, ...)` for one leaf shape, preceded by the helper
 // functions it calls.  FAST = the body in which Modulo(x, 1.0) is one v_fract_f32 (valid under the conditions of
