@@ -20,6 +20,13 @@
 //   * Minimum = select(fcmp ult a, b, a, b) (sparkle.rs:492-498): NaN in either operand returns `a`;
 //   * Delay amount `ult 0` (negative or NaN) returns 0.0 from the function (sparkle.rs:525-542).
 //
+// Dependency cycles: like the reference (whose RouteGraph never refuses the edge, routegraph.rs:218-237) the oracle has no cycle
+// check; get_edge_value recurses through a Delay at t - d exactly as reference.rs:197-216 does, so a loop closed through a Delay
+// of >= 1 frames evaluates to the feedback filter the reference would compute (cost: t / d stack frames per sample, exponential
+// in the number of taps) and a loop without one overflows the stack, as the reference's would.  No reference test holds a cyclic
+// graph: parity for feedback is against this restatement only -- "parity unpinned" beyond it.  Tracks
+// (fr_set_track_inputs) are ordinary stored inputs here; the declaration is accepted and ignored.
+//
 // Sharding (fr_set_shard): the oracle renders the rows a rank owns by plain evaluation -- output slots are
 // independent (reference.rs:78-82), so that IS the unsharded result for those rows -- and leaves the rest
 // untouched; FR_SHARD_GATHER moves rows to rank 0 through the host callback.  It never splits a voice.
