@@ -890,7 +890,7 @@ struct fr_renderer {
         }
         js << "],\"stage_programs\":" << (p.sp.progs.size() - p.sp.fused_count - p.sp.post_count) << ",\"stage_instrs\":" << p.sp.instrs.size()
            << ",\"fused_programs\":" << p.sp.fused_count << ",\"fused_max_frames\":" << p.sp.fused_max_frames << ",\"fused_stride\":" << p.sp.fused_stride
-           << ",\"feedback\":" << (p.sp.feedback ? "true" : "false") << ",\"feedback_loops\":" << fg.fb_target.size()
+           << ",\"feedback\":" << (p.sp.feedback ? "true" : "false") << ",\"feedback_loops\":" << p.sp.feedback_loops
            << ",\"fused_levels\":" << (p.sp.fused_level_first.empty() ? 0 : p.sp.fused_level_first.size() - 1) << ",\"copy_programs\":" << p.sp.post_count
            << ",\"stage_levels\":" << (p.sp.level_first.empty() ? 0 : p.sp.level_first.size() - 1)
            << ",\"stage_jit\":" << (p.stage_jit ? "true" : "false") << ",\"stage_shapes\":" << p.stage_shapes

@@ -1078,9 +1078,10 @@ struct Lowering::Impl {
             throw;
         }
         if (full) { base_nodes = fg.nodes.size(); base_ctxs = ctxs.size(); base_cells = cells.size(); }
-        // (feedback graphs are re-lowered from scratch after an edit: an OP_FBREF leaf keeps its id while what it stands for
-        //  changes, which the matcher's and the planner's per-node memos would not see)
-        if (!fg.fb_target.empty()) valid = false;
+        // (Feedback and incremental updates: the Delay that cuts a loop is registered as a reader of its source, so an edit
+        //  anywhere on the loop invalidates it and the loop is cut again with a NEW OP_FBREF leaf; a leaf that survives an update
+        //  still stands for the same node.  Leaves of loops that no longer exist stay behind as garbage: plan_stages counts only
+        //  the ones the rendered rows reach.)
         return fg;
     }
 };

@@ -448,10 +448,29 @@ StagedPlan plan_stages(const FlatGraph &g, bool allow_banks, bool allow_programs
     // Feedback (graph.hpp OP_FBREF): what the cut Delays read must be stageable too, nothing the pull interpreter evaluates
     // may reach one (its stack is sized by the graph's depth; a loop has none), and the plan has only its fused form --
     // below -- run with threads striding by the gcd of the loop delays, each thread reading what it stored itself.
-    const bool feedback = !g.fb_target.empty();
+    // (only the loops the rendered rows reach: after edits the graph may hold OP_FBREF leaves of loops that are gone)
+    std::vector<uint32_t> live_targets;
+    if (!g.fb_target.empty()) {
+        std::unordered_set<uint32_t> seen;
+        std::vector<uint32_t> st;
+        for (uint32_t row = 0; row < n_rows; ++row)
+            if (!sharded || partials || mine(row)) st.push_back(g.outputs[row]);
+        while (!st.empty()) {
+            const uint32_t n = st.back();
+            st.pop_back();
+            if (!seen.insert(n).second) continue;
+            const FlatNode &x = g.nodes[n];
+            if (x.op == OP_CONST || x.op == OP_INPUT) continue;
+            if (x.op == OP_FBREF) { live_targets.push_back(g.fb_target[x.a]); st.push_back(g.fb_target[x.a]); continue; }
+            st.push_back(x.a);
+            st.push_back(x.b);
+        }
+    }
+    const bool feedback = !live_targets.empty();
+    sp.feedback_loops = (uint32_t)live_targets.size();
     if (feedback) {
         if (partials) throw Error(FR_ERR_UNSUPPORTED, "feedback through Delay is not available under partial-block sharding");
-        for (uint32_t t : g.fb_target)
+        for (uint32_t t : live_targets)
             if (!allow_programs || !P.supported(t))
                 throw Error(FR_ERR_UNSUPPORTED, "a feedback loop needs the staged evaluator and contains something it cannot take "
                                                 "(a Delay by an unbounded signal or by 2^31 frames or more, or FR_MODE_PULL)");

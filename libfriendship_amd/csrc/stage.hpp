@@ -81,6 +81,7 @@ struct StagedPlan {
     // and progs[post_first .. post_first + post_count) copy rings to output rows after them.  Rings are brought up to date by
     // replaying the frames from 0 (there is no look-back window that bounds a loop).
     bool feedback = false;
+    uint32_t feedback_loops = 0;     // cut loops the rendered rows reach
     std::vector<uint32_t> fused_level_first;
     uint32_t post_first = 0, post_count = 0;
     bool fused_carry_only = false;   // every fused program reads the rings it stores through the carry only (kernels.hpp STAGE_CARRY)

@@ -222,3 +222,70 @@ def random_feedback_graph(seed, n_frames=16, n_nodes=14, n_inputs=2, n_outputs=3
                 continue
             return out, n_out, d
     return None
+
+
+def safe_feedback_edits(rng, steps, n_edits, n_inputs=2, n_outputs=3):
+    """Edits that keep every loop evaluable by the oracle's recursion: another value for a constant operand (never a Delay's
+    amount), another amount in 1..6 for a Delay that has a constant one, an output re-pointed at an existing node, a new node
+    over two existing ones (sometimes given an output).  Returns the new steps (also appended to `steps`)."""
+    kind, inbound = {}, {}
+    for s in steps:
+        if s[0] == "node":
+            kind[s[1]] = PRIMITIVES[s[2].kind]
+        elif s[0] == "edge":
+            inbound[(s[2], s[4])] = s
+        elif s[0] == "deledge":
+            inbound.pop((s[2], s[4]), None)
+    out = []
+    for _ in range(n_edits):
+        r = rng.random()
+        consts = [k for k, e in inbound.items() if e[1] == 1 and k[0] != 0 and not (kind.get(k[0]) == "Delay" and k[1] == 1)]
+        amounts = [k for k, e in inbound.items() if e[1] == 1 and kind.get(k[0]) == "Delay" and k[1] == 1]
+        nodes = [h for h in kind if h != 1]
+        if r < 0.4 and consts:
+            k = consts[rng.integers(len(consts))]
+            old = inbound[k]
+            new = ("edge", 1, k[0], f32_bits(float(np.float32(rng.normal() * 2))), k[1])
+            out += [("deledge",) + old[1:], new]
+            inbound[k] = new
+        elif r < 0.55 and amounts:
+            k = amounts[rng.integers(len(amounts))]
+            old = inbound[k]
+            d = float(np.array([old[3]], dtype=np.uint32).view(np.float32)[0])
+            if 1.0 <= d <= 6.0:   # (a pass-through Delay stays one: it may be what keeps a zero-delay path out of a loop's count;
+                #             a loop's Delay never gets shorter: the oracle's recursion costs paths ** (frames / delay))
+                new = ("edge", 1, k[0], f32_bits(float(rng.integers(int(d), 8))), k[1])
+                out += [("deledge",) + old[1:], new]
+                inbound[k] = new
+        elif r < 0.75 and nodes:
+            o = int(rng.integers(n_outputs))
+            old = inbound.get((0, o))
+            new = ("edge", int(nodes[rng.integers(len(nodes))]), 0, 0, o)
+            if old is not None:
+                out.append(("deledge",) + old[1:])
+            out.append(new)
+            inbound[(0, o)] = new
+        elif nodes:
+            h = max(kind) + 1
+            k2 = ["Sum2", "Multiply", "Minimum"][rng.integers(3)]
+            out.append(("node", h, Effect.primitive(k2)))
+            kind[h] = k2
+            for slot in range(2):
+                if rng.random() < 0.6:
+                    e = ("edge", int(nodes[rng.integers(len(nodes))]), h, 0, slot)
+                elif rng.random() < 0.5:
+                    e = ("edge", 0, h, int(rng.integers(n_inputs)), slot)
+                else:
+                    e = ("edge", 1, h, f32_bits(float(np.float32(rng.normal()))), slot)
+                out.append(e)
+                inbound[(h, slot)] = e
+            if rng.random() < 0.5:
+                o = int(rng.integers(n_outputs))
+                old = inbound.get((0, o))
+                if old is not None:
+                    out.append(("deledge",) + old[1:])
+                e = ("edge", h, 0, 0, o)
+                out.append(e)
+                inbound[(0, o)] = e
+    steps.extend(out)
+    return out

@@ -1904,6 +1904,7 @@ def test_feedback_that_cannot_be_evaluated_is_refused(hip_lib):
             assert ei.value.status == FR_ERR_UNSUPPORTED, kw
 
 
+@pytest.mark.timeout(600)   # (the oracle's recursion is exponential in what a bad estimate lets through)
 @pytest.mark.parametrize("seed0", [0, 40])
 def test_random_feedback_graphs(hip_lib, oracle_lib, seed0):
     """Random graphs of the seven primitives with one Delay re-pointed at a node that depends on it (randgraph.py), two
@@ -2073,3 +2074,42 @@ def test_feedback_inside_composite_instances(hip_lib, oracle_lib):
         _fb_calls(hip, ref, 2, [(0, 20), (20, 33), (100, 10), (7, 5)], seed=31)
         plan = hip.plan()
         assert plan["feedback"] and plan["feedback_loops"] == 2, plan
+
+
+@pytest.mark.timeout(600)   # (the oracle's recursion is exponential in what a bad estimate lets through)
+@pytest.mark.parametrize("seed0", [0, 60])
+def test_feedback_graphs_edited_during_playback(hip_lib, oracle_lib, seed0):
+    """Graph edits between calls on graphs with feedback loops (constants, loop delays, outputs re-pointed, new nodes): the lowering
+    is incremental -- an edit anywhere on a loop invalidates the Delay that cuts it, and the loop is cut again -- the loop's state is
+    rebuilt by replay with the NEW graph (everything heard so far through the edited graph), and a second engine
+    that is told the final graph from scratch renders the same bits."""
+    done = incremental = 0
+    for seed in range(seed0, seed0 + 60):
+        made = randgraph.random_feedback_graph(seed, n_frames=20, budget=2e4)
+        if made is None:
+            continue
+        steps, n_out, _d = made
+        steps = list(steps)
+        rng = np.random.default_rng(seed + 5)
+        with Renderer(hip_lib) as hip, Renderer(oracle_lib) as ref:
+            randgraph.install_steps(hip, steps)
+            randgraph.install_steps(ref, steps)
+            idx = 0
+            try:
+                for k in range(4):
+                    n = int(rng.integers(3, 7))
+                    rows = [rng.normal(size=n).astype(np.float32), rng.integers(-2, 5, size=n).astype(np.float32)]
+                    got = hip.fill_buffer(n_out, idx, idx + n, rows)
+                    exp = ref.fill_buffer(n_out, idx, idx + n, rows)
+                    assert same_bits(got, exp), f"seed {seed}, call {k}: " + first_diff(got, exp)
+                    if k:
+                        incremental += hip.plan()["lowering"] == "incremental"
+                    idx += n
+                    edits = randgraph.safe_feedback_edits(rng, steps, 2)
+                    randgraph.install_steps(hip, edits)
+                    randgraph.install_steps(ref, edits)
+            except RenderError as e:
+                assert e.status == FR_ERR_UNSUPPORTED, (seed, e)
+                continue
+        done += 1
+    assert done >= 15 and incremental >= done, (done, incremental)

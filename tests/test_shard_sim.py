@@ -277,6 +277,7 @@ def test_random_patches_sharded_every_way(sim, oracle_lib, seed):
         job.close()
 
 
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("world", [2, 3])
 def test_voices_mode_with_feedback_loops(sim, oracle_lib, world):
     """Voice sharding of graphs with feedback through Delay: every rank lowers and plans only its rows -- a loop is cut, planned

@@ -489,6 +489,7 @@ def test_feedback_that_cannot_be_evaluated_is_refused(sim):
     G.test_feedback_that_cannot_be_evaluated_is_refused(sim)
 
 
+@pytest.mark.timeout(600)   # (the oracle's recursion is exponential in what a bad estimate lets through)
 @pytest.mark.parametrize("seed0", [0, 40])
 def test_random_feedback_graphs(sim, oracle_lib, seed0):
     G.test_random_feedback_graphs(sim, oracle_lib, seed0)
@@ -496,3 +497,9 @@ def test_random_feedback_graphs(sim, oracle_lib, seed0):
 
 def test_feedback_inside_composite_instances(sim, oracle_lib):
     G.test_feedback_inside_composite_instances(sim, oracle_lib)
+
+
+@pytest.mark.timeout(600)   # (the oracle's recursion is exponential in what a bad estimate lets through)
+@pytest.mark.parametrize("seed0", [0, 60])
+def test_feedback_graphs_edited_during_playback(sim, oracle_lib, seed0):
+    G.test_feedback_graphs_edited_during_playback(sim, oracle_lib, seed0)
