@@ -91,7 +91,9 @@ struct StageJitPlan {
 // every extra instruction counts, and the 2-stride launches of effects chains measured the same at 1, 2 and 4
 // (profiles/r03_feedback.txt; FR_STAGE_BLOCK overrides).
 bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<StageInstr> &instrs, uint32_t max_shapes, bool force,
-                    StageJitPlan &out, bool sparkle = false, uint32_t block = 1);
+                    StageJitPlan &out, bool sparkle = false, uint32_t block = 1, bool defer_stores = false);
+// `defer_stores`: a block's ring and output stores are issued after its iterations (only for plans whose strided threads read their
+// own rings through the carry alone, StagedPlan::fused_carry_only: nothing inside a block then reads what the block stores).
 
 // Text of `template <bool FAST> float leaf(const float *x, float p0, ...)` for one leaf shape, preceded by the helper
 // functions it calls.  FAST = the body in which Modulo(x, 1.0) is one v_fract_f32 (valid under the conditions of

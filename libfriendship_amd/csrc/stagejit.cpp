@@ -13,6 +13,11 @@ namespace fr {
 static const char *kStageSkeleton = R"JIT(
 typedef unsigned int __attribute__((address_space(4))) const *cu32;
 typedef unsigned long long u64;
+#if MAXP > 0
+typedef const unsigned int *PRM;   // the program's parameter row, preloaded into registers by the kernel
+#else
+typedef cu32 PRM;
+#endif
 
 // A zero the optimiser cannot see through.  With a LITERAL zero in reach this toolchain's AMDGPU backend applies folds that
 // are only valid without signed zeros -- `0.0 - y` becomes a negate modifier (-0 where IEEE gives +0 for y = +0), and
@@ -44,17 +49,43 @@ __device__ __forceinline__ float jit_min(float a, float b) {   // Rust >= 1.20 f
     return take_a ? a : other;
 }
 __device__ __forceinline__ float f32(unsigned int bits) { return __builtin_bit_cast(float, bits); }
+// (Loads are issued unconditionally, from a harmless address when the frame is out of range, and the result selected afterwards:
+//  a load under a branch is waited for at the join, one memory latency each, where straight-line loads are in flight together --
+//  what the block-wise fetch of strided programs below is for.)
 __device__ __forceinline__ float in_at(const JitStageArgs &a, unsigned int slot, u64 t) {
     if (slot >= a.n_inputs) return jit_opaque(0.0f);
     JitInput s = a.n_inputs <= 8u ? a.inline_inputs[slot] : a.inputs[slot];
-    if (t < s.base || t >= s.len) return jit_opaque(0.0f);
-    return s.data[t - s.base];
+    const bool ok = t >= s.base && t < s.len;
+    const float *p = ok ? s.data + (t - s.base) : (const float *)a.ptab;   // (the parameter table: always a readable address in HBM)
+    const float v = *p;
+    return ok ? v : jit_opaque(0.0f);
 }
 __device__ __forceinline__ float in_delayed(const JitStageArgs &a, unsigned int slot, unsigned int d, u64 t) {
     return t >= d ? in_at(a, slot, t - d) : jit_opaque(0.0f);
 }
 __device__ __forceinline__ float ring_read(const JitStageArgs &a, unsigned int buf, unsigned int d, u64 t) {
-    return t >= d ? a.rings[(size_t)buf * (a.ring_mask + 1) + ((t - d) & a.ring_mask)] : jit_opaque(0.0f);
+    const bool ok = t >= d;
+    const float v = a.rings[(size_t)buf * (a.ring_mask + 1) + (ok ? ((t - d) & a.ring_mask) : 0ull)];
+    return ok ? v : jit_opaque(0.0f);
+}
+// The same reads in two halves, for the block-wise fetch of strided programs: the load itself -- always issued, from a harmless
+// address when the frame is out of range -- and the test that decides between its result and +0 afterwards.  (Written as one
+// expression the compiler moves the load under the test's branch again and waits for it where the branch ends.)
+__device__ __forceinline__ bool in_ok(const JitStageArgs &a, unsigned int slot, u64 t) {
+    if (slot >= a.n_inputs) return false;
+    JitInput s = a.n_inputs <= 8u ? a.inline_inputs[slot] : a.inputs[slot];
+    return t >= s.base && t < s.len;
+}
+__device__ __forceinline__ float in_raw(const JitStageArgs &a, unsigned int slot, u64 t) {
+    const float *p = (const float *)a.ptab;   // (always a readable address in HBM)
+    if (slot < a.n_inputs) {
+        JitInput s = a.n_inputs <= 8u ? a.inline_inputs[slot] : a.inputs[slot];
+        if (t >= s.base && t < s.len) p = s.data + (t - s.base);
+    }
+    return *p;
+}
+__device__ __forceinline__ float ring_raw(const JitStageArgs &a, unsigned int buf, unsigned int d, u64 t) {
+    return a.rings[(size_t)buf * (a.ring_mask + 1) + (t >= d ? ((t - d) & a.ring_mask) : 0ull)];
 }
 __device__ __forceinline__ void ring_store(const JitStageArgs &a, unsigned int buf, u64 t, float v) {
     a.rings[(size_t)buf * (a.ring_mask + 1) + (t & a.ring_mask)] = v;
@@ -93,28 +124,60 @@ extern "C" __global__ void __launch_bounds__(256) jit_stage(JitStageArgs a) {
     const u64 span = a.stride ? a.stride : a.w_len;
     if (wi >= span) return;
     const JitStageProg pg = a.progs[blockIdx.y];
+#if MAXP > 0
+    // the program's parameter row, once, into scalar registers (it was re-read through the scalar cache at every use of every
+    // iteration, each read waited for)
+    unsigned int P[MAXP];
+    {
+        cu32 prow = (cu32)(a.ptab + pg.param_off);
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) P[i] = prow[i];
+    }
+#else
     cu32 P = (cu32)(a.ptab + pg.param_off);
+#endif
     // carry (kernels.hpp STAGE_CARRY): what this thread stored to its rings one iteration ago stays in registers
     float cy[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, ny[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     // A strided thread's loads that depend on the frame alone (inputs, rings of banks and of earlier launches) are requested a
     // BLOCK of BLK iterations at a time, then the block's iterations computed: the iterations of a short loop cost a memory
     // latency per BLK instead of one each (a one-sample loop runs one thread per program through every frame of the call).
+    if (wi < a.w_len && a.stride) {
+        const u64 t = a.w0 + wi;
+        switch (pg.shape) {
+CARRY_CASES
+        default: break;
+        }
+    }
     float ldb[BLK][MAXLD];
+#if DEFER
+    // DEFER (plans whose strided threads read their own rings through the carry only): the block's ring and output stores are
+    // issued together AFTER its iterations are computed.  vmcnt counts loads and stores alike and in order, so a thread that
+    // stored in every iteration waited, at the next iteration's first load, for that store to reach L2 -- a memory round trip
+    // per frame of a one-sample loop either way.  Nothing inside the block reads what it stores (that is what the carry is).
+    float svb[BLK][MAXST], rb[BLK];
+#endif
     for (u64 base = wi; base < a.w_len; base += (u64)BLK * span) {
 #pragma unroll
         for (int b = 0; b < BLK; ++b) {
+            // (no branch on the lane's frame around the loads: a lane past the window's end re-reads its last frame's operands --
+            //  loads inside a divergent region are waited for where it ends, one memory latency each)
             const u64 off = base + (u64)b * span;
+            const u64 t = a.w0 + (off < a.w_len ? off : a.w_len - 1);
+            float *ldn = ldb[b];
 #pragma unroll
-            for (int i = 0; i < MAXLD; ++i) ldb[b][i] = 0.0f;
-            if (off < a.w_len) {
-                const u64 t = a.w0 + off;
-                float *ldn = ldb[b];
-                switch (pg.shape) {
+            for (int i = 0; i < MAXLD; ++i) ldn[i] = 0.0f;
+            switch (pg.shape) {
 LOAD_CASES
-                default: break;
-                }
+            default: break;
             }
         }
+        // every load of the block is issued before any is used: one wait here instead of one per load
+#if defined(__AMDGCN__)
+#pragma unroll
+        for (int b = 0; b < BLK; ++b)
+#pragma unroll
+            for (int i = 0; i < MAXLD; ++i) asm volatile("" : "+v"(ldb[b][i]));
+#endif
 #pragma unroll
         for (int b = 0; b < BLK; ++b) {
             const u64 off = base + (u64)b * span;
@@ -123,6 +186,12 @@ LOAD_CASES
                 const bool carried = off != wi;
                 (void)carried;
                 const float *ld = ldb[b];
+#if DEFER
+                float *sv = svb[b];
+#else
+                float *sv = nullptr;
+#endif
+                (void)sv;
                 float r;
                 switch (pg.shape) {
 SHAPE_CASES
@@ -130,13 +199,33 @@ SHAPE_CASES
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) cy[i] = ny[i];
+#if DEFER
+                rb[b] = r;
+#else
                 if (pg.dst_ring != 0xFFFFFFFFu) ring_store(a, pg.dst_ring, t, r);
                 if (pg.out_row >= 0 && t >= a.idx) a.out[(size_t)pg.out_row * a.n_times + (t - a.idx)] = r;
 #if defined(__AMDGCN__)
                 if (a.stride && !a.carry_only) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stride's ring stores are in memory before the next one reads them
 #endif
+#endif
             }
         }
+#if DEFER
+#pragma unroll
+        for (int b = 0; b < BLK; ++b) {
+            const u64 off = base + (u64)b * span;
+            if (off < a.w_len) {
+                const u64 t = a.w0 + off;
+                const float *sv = svb[b];
+                switch (pg.shape) {
+STORE_CASES
+                default: break;
+                }
+                if (pg.dst_ring != 0xFFFFFFFFu) ring_store(a, pg.dst_ring, t, rb[b]);
+                if (pg.out_row >= 0 && t >= a.idx) a.out[(size_t)pg.out_row * a.n_times + (t - a.idx)] = rb[b];
+            }
+        }
+#endif
     }
 }
 )JIT";
@@ -152,7 +241,7 @@ bool literal_worthy(uint32_t bits) {
 }  // namespace
 
 bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<StageInstr> &instrs, uint32_t max_shapes, bool force,
-                    StageJitPlan &out, bool sparkle, uint32_t block) {
+                    StageJitPlan &out, bool sparkle, uint32_t block, bool defer_stores) {
     if (progs.empty()) return false;
     struct Shape { uint32_t first; std::vector<uint32_t> members; std::vector<bool> literal; };
     std::map<std::string, uint32_t> ids;
@@ -193,8 +282,8 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
 
     // source
     constexpr uint32_t MAXLD = 16;   // loads per program fetched ahead, a block of iterations at a time (the rest where they are used)
-    uint32_t max_nld = 1;
-    std::ostringstream fns, cases, load_cases;
+    uint32_t max_nld = 1, max_nst = 1, max_np = 1;
+    std::ostringstream fns, cases, load_cases, store_cases, carry_cases;
     for (size_t si = 0; si < shapes.size(); ++si) {
         const Shape &s = shapes[si];
         const StageProg &p0 = progs[s.first];
@@ -202,7 +291,7 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
         std::vector<int> ld_of(p0.n_instr, -1);
         {
             std::ostringstream lf;
-            lf << "__device__ __forceinline__ void shape" << si << "_ld(const JitStageArgs &a, cu32 P, u64 t, float *ld) {\n    (void)a; (void)P; (void)t; (void)ld;\n";
+            lf << "__device__ __forceinline__ void shape" << si << "_ld(const JitStageArgs &a, PRM P, u64 t, float *ld) {\n    (void)a; (void)P; (void)t; (void)ld;\n";
             uint32_t kk = 0, nld = 0;
             for (uint32_t i = 0; i < p0.n_instr; ++i) {
                 const StageInstr &in = instrs[p0.first_instr + i];
@@ -211,9 +300,9 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
                 const bool pure = in.op == S_INPUT || in.op == S_READ_INPUT || (in.op == S_READ && in.imm == 0);
                 if (pure && nld < MAXLD) {
                     lf << "    ld[" << nld << "] = ";
-                    if (in.op == S_INPUT) lf << "in_at(a, P[" << kk << "], t)";
-                    else if (in.op == S_READ) lf << "ring_read(a, P[" << kk << "], P[" << kk + 1 << "], t)";
-                    else lf << "in_delayed(a, P[" << kk << "], P[" << kk + 1 << "], t)";
+                    if (in.op == S_INPUT) lf << "in_raw(a, P[" << kk << "], t)";
+                    else if (in.op == S_READ) lf << "ring_raw(a, P[" << kk << "], P[" << kk + 1 << "], t)";
+                    else lf << "in_raw(a, P[" << kk << "], t >= P[" << kk + 1 << "] ? t - P[" << kk + 1 << "] : ~0ull)";
                     lf << ";\n";
                     ld_of[i] = (int)nld++;
                 }
@@ -227,9 +316,47 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
             lf << "}\n";
             fns << lf.str();
             max_nld = std::max(max_nld, nld);
+            max_np = std::max(max_np, kk);
         }
-        fns << "__device__ __forceinline__ float shape" << si << "(const JitStageArgs &a, cu32 P, u64 t, const float *ld, const float *cy, float *ny, bool carried) {\n"
-               "    (void)a; (void)P; (void)t; (void)ld; (void)cy; (void)ny; (void)carried;\n";
+        {   // what a thread's carry starts as: the rings' values `stride` frames before its first frame (an earlier launch's, or +0)
+            std::ostringstream cf;
+            cf << "__device__ __forceinline__ void shape" << si << "_cy(const JitStageArgs &a, PRM P, u64 t, float *cy) {\n    (void)a; (void)P; (void)t; (void)cy;\n";
+            uint32_t kk = 0;
+            for (uint32_t i = 0; i < p0.n_instr; ++i) {
+                const StageInstr &in = instrs[p0.first_instr + i];
+                if (in.op == S_READ && in.imm != 0 && in.imm <= 8) cf << "    cy[" << in.imm - 1 << "] = ring_read(a, P[" << kk << "], P[" << kk + 1 << "], t);\n";
+                switch (in.op) {
+                case S_CONST: if (!s.literal[i]) kk += 1; break;
+                case S_INPUT: case S_STORE: case S_READ_DYN: case S_READ_INPUT_DYN: case S_STEP_DYN: kk += 1; break;
+                case S_READ: case S_READ_INPUT: case S_STEP: kk += 2; break;
+                default: break;
+                }
+            }
+            cf << "}\n";
+            fns << cf.str();
+            carry_cases << "        case " << si << ": shape" << si << "_cy(a, P, t, cy); break;\n";
+        }
+        {   // the program's ring stores as a function of their values (DEFER: issued after a block's iterations)
+            std::ostringstream sf;
+            sf << "__device__ __forceinline__ void shape" << si << "_st(const JitStageArgs &a, PRM P, u64 t, const float *sv) {\n    (void)a; (void)P; (void)t; (void)sv;\n";
+            uint32_t kk = 0, nst = 0;
+            for (uint32_t i = 0; i < p0.n_instr; ++i) {
+                const StageInstr &in = instrs[p0.first_instr + i];
+                if (in.op == S_STORE) sf << "    ring_store(a, P[" << kk << "], t, sv[" << nst++ << "]);\n";
+                switch (in.op) {
+                case S_CONST: if (!s.literal[i]) kk += 1; break;
+                case S_INPUT: case S_STORE: case S_READ_DYN: case S_READ_INPUT_DYN: case S_STEP_DYN: kk += 1; break;
+                case S_READ: case S_READ_INPUT: case S_STEP: kk += 2; break;
+                default: break;
+                }
+            }
+            sf << "}\n";
+            fns << sf.str();
+            max_nst = std::max(max_nst, nst);
+        }
+        fns << "__device__ __forceinline__ float shape" << si << "(const JitStageArgs &a, PRM P, u64 t, const float *ld, const float *cy, float *ny, bool carried, float *sv) {\n"
+               "    (void)a; (void)P; (void)t; (void)ld; (void)cy; (void)ny; (void)carried; (void)sv;\n";
+        uint32_t n_st = 0;
         int var_of[256];
         for (int &x : var_of) x = -1;
         std::vector<bool> is_one(p0.n_instr, false);
@@ -237,14 +364,18 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
         for (uint32_t i = 0; i < p0.n_instr; ++i) {
             const StageInstr &in = instrs[p0.first_instr + i];
             char buf[96];
-            if (ld_of[i] >= 0) {   // fetched ahead
-                fns << "    float v" << i << " = ld[" << ld_of[i] << "];\n";
+            if (ld_of[i] >= 0) {   // fetched ahead (raw): the range test decides between it and +0 here, on registers
+                fns << "    float v" << i << " = (";
+                if (in.op == S_INPUT) fns << "in_ok(a, P[" << k << "], t)";
+                else if (in.op == S_READ) fns << "t >= P[" << k + 1 << "]";
+                else fns << "t >= P[" << k + 1 << "] && in_ok(a, P[" << k << "], t - P[" << k + 1 << "])";
+                fns << ") ? ld[" << ld_of[i] << "] : jit_opaque(0.0f);\n";
                 k += in.op == S_INPUT ? 1 : 2;
                 var_of[in.dst] = (int)i;
                 continue;
             }
             if (in.op == S_STORE) {
-                fns << "    ring_store(a, P[" << k << "], t, v" << var_of[in.a] << ");\n";
+                fns << "#if DEFER\n    sv[" << n_st++ << "] = v" << var_of[in.a] << ";\n#else\n    ring_store(a, P[" << k << "], t, v" << var_of[in.a] << ");\n#endif\n";
                 if (in.imm != 0 && in.imm <= 8) fns << "    ny[" << in.imm - 1 << "] = v" << var_of[in.a] << ";\n";
                 k += 1;
                 continue;
@@ -260,7 +391,7 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
                 break;
             case S_INPUT: fns << "in_at(a, P[" << k << "], t)"; k += 1; break;
             case S_READ:
-                if (in.imm != 0 && in.imm <= 8) fns << "(carried ? cy[" << in.imm - 1 << "] : ring_read(a, P[" << k << "], P[" << k + 1 << "], t))";
+                if (in.imm != 0 && in.imm <= 8) fns << "cy[" << in.imm - 1 << "]";   // (the thread's first frame: shapeN_cy read the ring)
                 else fns << "ring_read(a, P[" << k << "], P[" << k + 1 << "], t)";
                 k += 2;
                 break;
@@ -282,16 +413,20 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
             var_of[in.dst] = (int)i;
         }
         fns << "    return v" << var_of[p0.result_reg] << ";\n}\n";
-        cases << "        case " << si << ": r = shape" << si << "(a, P, t, ld, cy, ny, carried); break;\n";
+        cases << "        case " << si << ": r = shape" << si << "(a, P, t, ld, cy, ny, carried, sv); break;\n";
+        store_cases << "                case " << si << ": shape" << si << "_st(a, P, t, sv); break;\n";
         load_cases << "        case " << si << ": shape" << si << "_ld(a, P, t, ldn); break;\n";
     }
     std::ostringstream src;
-    src << "#pragma clang fp contract(off)\n#define FR_SPARKLE " << (sparkle ? 1 : 0) << "\n#define MAXLD " << max_nld << "\n#define BLK " << std::max(1u, std::min(block, std::max(1u, 32u / max_nld))) << "\n" << FR_STR(FR_JIT_STAGE_ARGS_TEXT) << "\n";
+    src << "#pragma clang fp contract(off)\n#define FR_SPARKLE " << (sparkle ? 1 : 0) << "\n#define MAXLD " << max_nld << "\n#define MAXP " << (max_np <= 64 ? max_np : 0u) << "\n#define MAXST " << max_nst << "\n#define DEFER " << ((defer_stores && max_nst <= 8) ? 1 : 0)
+        << "\n#define BLK " << std::max(1u, std::min(block, std::max(1u, 32u / (max_nld + ((defer_stores && max_nst <= 8) ? max_nst + 1 : 0))))) << "\n" << FR_STR(FR_JIT_STAGE_ARGS_TEXT) << "\n";
     std::string body = kStageSkeleton;
     auto put = [&](const std::string &tag, const std::string &text) { body.replace(body.find(tag), tag.size(), text); };
     put("SHAPE_FUNCTIONS", fns.str());
     put("SHAPE_CASES", cases.str());
     put("LOAD_CASES", load_cases.str());
+    put("STORE_CASES", store_cases.str());
+    put("CARRY_CASES", carry_cases.str());
     src << body;
     out.source = src.str();
     out.n_shapes = (uint32_t)shapes.size();
@@ -317,6 +452,7 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
         }
         out.progs[p] = jp;
     }
+    out.ptab.insert(out.ptab.end(), max_np, 0u);   // (the kernel preloads MAXP words of every row: the last rows read into this)
     return true;
 }
 
