@@ -830,7 +830,7 @@ struct fr_renderer {
             HIP_CHECK(hipMemcpyAsync(p.d_progs.p, p.sp.progs.data(), p.sp.progs.size() * sizeof(StageProg), hipMemcpyHostToDevice, st));
             StageJitPlan sj;
             if (allow_jit && stage_jit_mode != 0 && plan_stage_jit(p.sp.progs, p.sp.instrs, 32, stage_jit_mode == 2, sj, mirror.sparkle,
-                                                                              stage_block_env ? stage_block_env : ((p.sp.feedback && (p.sp.fused_stride >= 16 || p.sp.fused_carry_only)) ? 16u : 1u),
+                                                                              stage_block_env ? stage_block_env : (p.sp.feedback ? 16u : 1u),
                                                                               p.sp.feedback && p.sp.fused_carry_only)) {
                 try {
                     p.stage_jit = jit_cache.get_source(sj.source, "jit_stage");

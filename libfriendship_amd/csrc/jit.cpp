@@ -285,8 +285,8 @@ static std::string disk_key_text(const std::string &src, const std::string &arch
     (void)hiprtcVersion(&major, &minor);
     if (hipRuntimeGetVersion(&rt) != hipSuccess) { (void)hipGetLastError(); rt = 0; }
     if (hipDriverGetVersion(&drv) != hipSuccess) { (void)hipGetLastError(); drv = 0; }
-    // "fr-jit-11": bumped whenever this engine's code generators change what they print for the same request
-    std::string key = "fr-jit-11|" + arch + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) + "|hip " +
+    // "fr-jit-12": bumped whenever this engine's code generators change what they print for the same request
+    std::string key = "fr-jit-12|" + arch + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) + "|hip " +
                       std::to_string(HIP_VERSION_MAJOR) + "." + std::to_string(HIP_VERSION_MINOR) + "." + std::to_string(HIP_VERSION_PATCH) + " " +
                       HIP_VERSION_GITHASH + "|runtime " + std::to_string(rt) + "|driver " + std::to_string(drv) + "|";
     for (const char *o : kJitOptions) { key += o; key += ' '; }

@@ -49,24 +49,17 @@ __device__ __forceinline__ float jit_min(float a, float b) {   // Rust >= 1.20 f
     return take_a ? a : other;
 }
 __device__ __forceinline__ float f32(unsigned int bits) { return __builtin_bit_cast(float, bits); }
-// (Loads are issued unconditionally, from a harmless address when the frame is out of range, and the result selected afterwards:
-//  a load under a branch is waited for at the join, one memory latency each, where straight-line loads are in flight together --
-//  what the block-wise fetch of strided programs below is for.)
 __device__ __forceinline__ float in_at(const JitStageArgs &a, unsigned int slot, u64 t) {
     if (slot >= a.n_inputs) return jit_opaque(0.0f);
     JitInput s = a.n_inputs <= 8u ? a.inline_inputs[slot] : a.inputs[slot];
-    const bool ok = t >= s.base && t < s.len;
-    const float *p = ok ? s.data + (t - s.base) : (const float *)a.ptab;   // (the parameter table: always a readable address in HBM)
-    const float v = *p;
-    return ok ? v : jit_opaque(0.0f);
+    if (t < s.base || t >= s.len) return jit_opaque(0.0f);
+    return s.data[t - s.base];
 }
 __device__ __forceinline__ float in_delayed(const JitStageArgs &a, unsigned int slot, unsigned int d, u64 t) {
     return t >= d ? in_at(a, slot, t - d) : jit_opaque(0.0f);
 }
 __device__ __forceinline__ float ring_read(const JitStageArgs &a, unsigned int buf, unsigned int d, u64 t) {
-    const bool ok = t >= d;
-    const float v = a.rings[(size_t)buf * (a.ring_mask + 1) + (ok ? ((t - d) & a.ring_mask) : 0ull)];
-    return ok ? v : jit_opaque(0.0f);
+    return t >= d ? a.rings[(size_t)buf * (a.ring_mask + 1) + ((t - d) & a.ring_mask)] : jit_opaque(0.0f);
 }
 // The same reads in two halves, for the block-wise fetch of strided programs: the load itself -- always issued, from a harmless
 // address when the frame is out of range -- and the test that decides between its result and +0 afterwards.  (Written as one
@@ -242,6 +235,10 @@ bool literal_worthy(uint32_t bits) {
 
 bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<StageInstr> &instrs, uint32_t max_shapes, bool force,
                     StageJitPlan &out, bool sparkle, uint32_t block, bool defer_stores) {
+    // Plans without feedback keep the plain form -- every load where it is used, parameters through the scalar cache: their
+    // launches compute one frame per thread (or a handful of strides) and the extra set-up of the deep form only costs (config
+    // D's launch 8.9 -> 10.5 us with it).
+    const bool deep = block > 1 || defer_stores;
     if (progs.empty()) return false;
     struct Shape { uint32_t first; std::vector<uint32_t> members; std::vector<bool> literal; };
     std::map<std::string, uint32_t> ids;
@@ -297,7 +294,7 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
                 const StageInstr &in = instrs[p0.first_instr + i];
                 // (S_READ.imm != 0: a ring the program stores itself -- carried, or 0xFF: read through memory AFTER the stores of the
                 //  iterations before, so not ahead of them)
-                const bool pure = in.op == S_INPUT || in.op == S_READ_INPUT || (in.op == S_READ && in.imm == 0);
+                const bool pure = deep && (in.op == S_INPUT || in.op == S_READ_INPUT || (in.op == S_READ && in.imm == 0));
                 if (pure && nld < MAXLD) {
                     lf << "    ld[" << nld << "] = ";
                     if (in.op == S_INPUT) lf << "in_raw(a, P[" << kk << "], t)";
@@ -418,7 +415,7 @@ bool plan_stage_jit(const std::vector<StageProg> &progs, const std::vector<Stage
         load_cases << "        case " << si << ": shape" << si << "_ld(a, P, t, ldn); break;\n";
     }
     std::ostringstream src;
-    src << "#pragma clang fp contract(off)\n#define FR_SPARKLE " << (sparkle ? 1 : 0) << "\n#define MAXLD " << max_nld << "\n#define MAXP " << (max_np <= 64 ? max_np : 0u) << "\n#define MAXST " << max_nst << "\n#define DEFER " << ((defer_stores && max_nst <= 8) ? 1 : 0)
+    src << "#pragma clang fp contract(off)\n#define FR_SPARKLE " << (sparkle ? 1 : 0) << "\n#define MAXLD " << max_nld << "\n#define MAXP " << ((deep && max_np <= 64) ? max_np : 0u) << "\n#define MAXST " << max_nst << "\n#define DEFER " << ((defer_stores && max_nst <= 8) ? 1 : 0)
         << "\n#define BLK " << std::max(1u, std::min(block, std::max(1u, 32u / (max_nld + ((defer_stores && max_nst <= 8) ? max_nst + 1 : 0))))) << "\n" << FR_STR(FR_JIT_STAGE_ARGS_TEXT) << "\n";
     std::string body = kStageSkeleton;
     auto put = [&](const std::string &tag, const std::string &text) { body.replace(body.find(tag), tag.size(), text); };
