@@ -2113,3 +2113,31 @@ def test_feedback_graphs_edited_during_playback(hip_lib, oracle_lib, seed0):
                 continue
         done += 1
     assert done >= 15 and incremental >= done, (done, incremental)
+
+
+def test_track_voices_under_voice_sharding(hip_lib, oracle_lib):
+    """Two ranks (two renderers sharing the test GPU) render a job whose voices read per-partial track rows: every rank gets the
+    same graph and the same dense input matrix, declares the same track slots and renders its block of voices -- no exchange."""
+    import shard_harness
+    V, P = 5, 64
+    tree = synth.track_tree(V, P)
+    R = tree["n_inputs"]
+    job = shard_harness.Job(hip_lib, 2, "voices")
+    with Renderer(oracle_lib) as ref:
+        synth.install(ref, tree)
+        for ren in job.ranks:
+            ren.set_track_inputs(tree["first_track"])
+            synth.install(ren, tree)
+        idx = 0
+        for n in (R // V + 4, 70):
+            m = synth.track_rows(V, P, idx, idx + n)
+            exp = ref.fill_buffer_dense(V, idx, idx + n, m)
+
+            def one(_r, ren):
+                out = np.full((V, n), np.float32(-12345.0), dtype=np.float32)
+                return ren.fill_buffer_dense(V, idx, idx + n, m, out=out)
+            got = job.assemble(job.each(one), V)
+            assert same_bits(got, exp), first_diff(got, exp)
+            idx += n
+    assert sum(job.boxes.messages) == 0
+    job.close()
