@@ -656,6 +656,8 @@ protected:
         decltype(&fr_stream_begin) stream_begin;
         decltype(&fr_stream_block) stream_block;
         decltype(&fr_stream_end) stream_end;
+        decltype(&fr_set_track_inputs) set_track_inputs;
+        decltype(&fr_fill_buffer_dense) fill_dense;
     } api_{};
 
     template <class T>
@@ -718,6 +720,8 @@ public:
         sym(api_.stream_begin, "fr_stream_begin");
         sym(api_.stream_block, "fr_stream_block");
         sym(api_.stream_end, "fr_stream_end");
+        sym(api_.set_track_inputs, "fr_set_track_inputs");
+        sym(api_.fill_dense, "fr_fill_buffer_dense");
         fr_config cfg{FR_ABI_VERSION, device, mode, flags, semantics, 0, history_frames};
         fr_status s = api_.create(&cfg, &h_);
         if (s != FR_OK) {
@@ -766,6 +770,15 @@ public:
         check(api_.stream_block(h_, buff.data.data(), buff.cols, idx, row.data(), row.size()));
     }
     void stream_end() { check(api_.stream_end(h_)); }
+
+    // Control-rate tracks (friendship_render.h): input slots >= first_slot are read in place by the voices of the call that supplies
+    // them and never stored; fill_buffer_dense takes the inputs in the reference's own shape, an Array2 with one row per slot
+    // (renderer.rs:16, reference.rs:66-74).
+    void set_track_inputs(uint32_t first_slot) { check(api_.set_track_inputs(h_, first_slot)); }
+    void fill_buffer_dense(Array2 &buff, uint64_t idx, const Array2 &inputs) {
+        if (inputs.rows != 0 && inputs.cols != buff.cols) throw Panic(FR_ERR_INVALID_ARG, "fill_buffer_dense: inputs must have the buffer's frame count");
+        check(api_.fill_dense(h_, buff.data.data(), (uint32_t)buff.rows, buff.cols, idx, inputs.data.data(), (uint32_t)inputs.rows));
+    }
 
     void on_add_node(const routing::NodeHandle &node, const routing::NodeData &data) override {
         auto ce = lower(*data);

@@ -484,6 +484,28 @@ static void feedback_reference_as_written() {
     if (!refused) throw std::runtime_error("a delay-free loop rendered");
 }
 
+// The dense call (inputs as the reference's Array2) through the C++ plugin wrapper, and the track declaration: out = in0 * in1
+// with in1 declared a track -- refused on the device (a track read by something that is not a voice leaf), rendered by the
+// oracle (which stores tracks like any input); without the declaration both render it.
+static void dense_inputs_and_track_declaration() {
+    const char *lib = std::getenv("FRIENDSHIP_RENDERER_LIB");
+    const bool oracle = lib && std::string(lib).find("fr_oracle") != std::string::npos;
+    render::PluginRenderer r(lib ? lib : "libfriendship_hip.so");
+    routing::NodeData mul = routing::Effect::from_id(mult_id(), resman::ResMan());
+    r.on_add_node(NodeHandle::make(1), mul);
+    r.on_add_edge(Edge::make(NodeHandle::toplevel(), NodeHandle::make(1), EdgeWeight::make(0, 0)));
+    r.on_add_edge(Edge::make(NodeHandle::toplevel(), NodeHandle::make(1), EdgeWeight::make(1, 1)));
+    r.on_add_edge(Edge::new_to_null(NodeHandle::make(1), EdgeWeight::make(0, 0)));
+    Array2 in = Array2::zeros(2, 4), out = Array2::zeros(1, 4);
+    for (size_t t = 0; t < 4; ++t) { in.at(0, t) = (float)(t + 1); in.at(1, t) = 0.5f; }
+    r.fill_buffer_dense(out, 0, in);
+    ASSERT_EQ_ARR(out, array({0.5f, 1.f, 1.5f, 2.f}));
+    r.set_track_inputs(1);
+    bool refused = false;
+    try { r.fill_buffer_dense(out, 4, in); } catch (const std::exception &) { refused = true; }
+    if (refused == oracle) throw std::runtime_error(oracle ? "the oracle refused a declared track" : "a track read by a plain node was rendered");
+}
+
 static void mpsc_client_and_queries() {
     const char *lib = std::getenv("FRIENDSHIP_RENDERER_LIB");
     auto [client, rx] = friendship::client::MpscClient::make();
@@ -548,7 +570,7 @@ int main(int argc, char **argv) {
         {"render_mod", render_mod}, {"render_min", render_min},
         {"ext_render_passthrough", ext_render_passthrough}, {"ext_render_delay", ext_render_delay},
         {"load_multby2", load_multby2}, {"shipped_effect_files", shipped_effect_files}, {"block_streaming", block_streaming}, {"effect_desc_json", effect_desc_json},
-        {"routegraph_validation", routegraph_validation}, {"feedback_reference_as_written", feedback_reference_as_written},
+        {"routegraph_validation", routegraph_validation}, {"feedback_reference_as_written", feedback_reference_as_written}, {"dense_inputs_and_track_declaration", dense_inputs_and_track_declaration},
         {"mpsc_client_and_queries", mpsc_client_and_queries}};
     int failed = 0, ran = 0;
     for (auto &t : tests) {

@@ -23,7 +23,7 @@ def run(lib):
     env = dict(os.environ, FRIENDSHIP_RENDERER_LIB=lib)
     p = subprocess.run([build()], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert "18 passed; 0 failed" in p.stdout, p.stdout
+    assert "19 passed; 0 failed" in p.stdout, p.stdout
 
 
 def test_reference_tests_through_cpp_dispatch_on_oracle(oracle_lib):
