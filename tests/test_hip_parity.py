@@ -2141,3 +2141,20 @@ def test_track_voices_under_voice_sharding(hip_lib, oracle_lib):
             idx += n
     assert sum(job.boxes.messages) == 0
     job.close()
+
+
+def test_track_voices_with_the_abi_default_asynchronous_compile(hip_lib, oracle_lib):
+    """fr_config.flags = 0 (the C ABI's default) compiles run-time kernels on a worker thread and renders on the generic evaluators
+    meanwhile -- which cannot read tracks: for voices that read tracks the first call waits for the compiler instead of failing."""
+    V, P = 2, 128
+    tree = synth.track_tree(V, P)
+    R = tree["n_inputs"]
+    with Renderer(hip_lib, sync_compile=False) as hip, Renderer(oracle_lib) as ref:
+        hip.set_track_inputs(tree["first_track"])
+        synth.install(hip, tree)
+        synth.install(ref, tree)
+        n = R // V + 3
+        m = synth.track_rows(V, P, 0, n)
+        got, exp = hip.fill_buffer_dense(V, 0, n, m), ref.fill_buffer_dense(V, 0, n, m)
+        assert same_bits(got, exp), first_diff(got, exp)
+        assert hip.plan()["banks"][0]["tracks"]
