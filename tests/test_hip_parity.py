@@ -2158,3 +2158,39 @@ def test_track_voices_with_the_abi_default_asynchronous_compile(hip_lib, oracle_
         got, exp = hip.fill_buffer_dense(V, 0, n, m), ref.fill_buffer_dense(V, 0, n, m)
         assert same_bits(got, exp), first_diff(got, exp)
         assert hip.plan()["banks"][0]["tracks"]
+
+
+def test_feedback_while_the_stage_kernel_is_compiled_in_the_background(hip_lib, oracle_lib):
+    """Sixteen rows, each an echo loop of the same shape, under the ABI's default asynchronous compile: the first calls run the loops on
+    the interpreter, a later one on the compiled stage kernel (a new plan: the loops' state is rebuilt by replay); same bits
+    throughout."""
+    import time
+    with Renderer(hip_lib, sync_compile=False) as hip, Renderer(oracle_lib) as ref:
+        for r in (hip, ref):
+            r.on_add_node(1, "F32Constant")
+            for v in range(16):
+                b = 10 * (v + 1)
+                r.on_add_node(b, "Multiply")        # in0 * c_v
+                r.on_add_node(b + 1, "Sum2")        # x_v
+                r.on_add_node(b + 2, "Delay")
+                r.on_add_node(b + 3, "Multiply")
+                r.on_add_edge(0, b, 0, 0)
+                r.on_add_edge(1, b, f32_bits(0.31 + 0.1 * v), 1)
+                r.on_add_edge(b, b + 1, 0, 0)
+                r.on_add_edge(b + 3, b + 1, 0, 1)
+                r.on_add_edge(b + 1, b + 2, 0, 0)
+                r.on_add_edge(1, b + 2, f32_bits(3.0), 1)
+                r.on_add_edge(b + 2, b + 3, 0, 0)
+                r.on_add_edge(1, b + 3, f32_bits(0.5), 1)
+                r.on_add_edge(b + 1, 0, 0, v)
+        rng = np.random.default_rng(17)
+        idx, compiled = 0, False
+        for k in range(14):
+            n = 30
+            rows = [rng.normal(size=n).astype(np.float32)]
+            got, exp = hip.fill_buffer(16, idx, idx + n, rows), ref.fill_buffer(16, idx, idx + n, rows)
+            assert same_bits(got, exp), f"call {k}: " + first_diff(got, exp)
+            compiled = compiled or hip.plan()["stage_jit"]
+            idx += n
+            time.sleep(0.05)
+        assert hip.plan()["feedback"] and compiled, hip.plan()
